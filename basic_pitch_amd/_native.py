@@ -1,0 +1,143 @@
+"""ctypes binding of libbasicpitch_amd.so (C ABI in include/basic_pitch_amd.h).
+
+The product path FAILS LOUDLY when the HIP library is missing or no MI355X is visible: there is no
+CPU fallback in this package (the CPU restatement under oracle/ is test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from . import build as _build
+
+BP_OK = 0
+BP_MEM_HOST = 0
+BP_MEM_DEVICE = 1
+BP_FLAG_STAGE_TIMING = 1
+BP_N_STAGES = 8
+BP_PYR_STRIDE = 43712
+
+STAGE_NAMES = ["pyramid", "filterbank", "contour1", "contour2", "note1", "note2", "onset1", "onset2"]
+
+_ERR_NAMES = {
+    -1: "BP_ERR_INVALID_ARG",
+    -2: "BP_ERR_BAD_WEIGHTS",
+    -3: "BP_ERR_NO_DEVICE",
+    -4: "BP_ERR_HIP",
+    -5: "BP_ERR_OUT_OF_MEMORY",
+    -6: "BP_ERR_UNSUPPORTED",
+}
+
+
+class NativeLibraryError(RuntimeError):
+    """The HIP library is missing / unloadable, or a HIP call failed."""
+
+
+class bp_info(C.Structure):
+    _fields_ = [
+        ("device_ordinal", C.c_int),
+        ("compute_units", C.c_int),
+        ("max_windows", C.c_int64),
+        ("workspace_bytes", C.c_int64),
+        ("arch", C.c_char * 32),
+    ]
+
+
+class bp_stage_buffers(C.Structure):
+    _fields_ = [
+        ("audio", C.c_void_p),
+        ("pyr", C.c_void_p),
+        ("lp", C.c_void_p),
+        ("mm", C.c_void_p),
+        ("c1", C.c_void_p),
+        ("contour", C.c_void_p),
+        ("n1", C.c_void_p),
+        ("note", C.c_void_p),
+        ("o1", C.c_void_p),
+        ("onset", C.c_void_p),
+    ]
+
+
+# every symbol include/basic_pitch_amd.h declares (tests check they are all exported)
+EXPORTED_SYMBOLS = [
+    "bp_create",
+    "bp_destroy",
+    "bp_last_error",
+    "bp_infer",
+    "bp_infer_async",
+    "bp_infer_track",
+    "bp_track_n_windows",
+    "bp_track_n_frames",
+    "bp_set_stream",
+    "bp_synchronize",
+    "bp_get_info",
+    "bp_get_stage_ms",
+    "bp_run_stage",
+    "bp_pyramid_layout",
+    "bp_version",
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen the in-tree library and declare argtypes.  Raises NativeLibraryError if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("BASIC_PITCH_AMD_LIB") or _build.LIB_PATH
+    if not os.path.exists(p):
+        raise NativeLibraryError(
+            f"{p} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc, gfx950). basic_pitch_amd has no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(p)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise NativeLibraryError(f"cannot load {p}: {e}") from e
+    vp, i64, fp = C.c_void_p, C.c_int64, C.c_void_p
+    lib.bp_create.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_uint, i64, C.POINTER(vp)]
+    lib.bp_create.restype = C.c_int
+    lib.bp_destroy.argtypes = [vp]
+    lib.bp_destroy.restype = None
+    lib.bp_last_error.argtypes = [vp]
+    lib.bp_last_error.restype = C.c_char_p
+    lib.bp_infer.argtypes = [vp, fp, i64, fp, fp, fp, C.c_int]
+    lib.bp_infer.restype = C.c_int
+    lib.bp_infer_async.argtypes = [vp, fp, i64, fp, fp, fp]
+    lib.bp_infer_async.restype = C.c_int
+    lib.bp_infer_track.argtypes = [vp, fp, i64, fp, fp, fp, C.c_int]
+    lib.bp_infer_track.restype = C.c_int
+    lib.bp_track_n_windows.argtypes = [i64]
+    lib.bp_track_n_windows.restype = i64
+    lib.bp_track_n_frames.argtypes = [i64]
+    lib.bp_track_n_frames.restype = i64
+    lib.bp_set_stream.argtypes = [vp, vp]
+    lib.bp_set_stream.restype = C.c_int
+    lib.bp_synchronize.argtypes = [vp]
+    lib.bp_synchronize.restype = C.c_int
+    lib.bp_get_info.argtypes = [vp, C.POINTER(bp_info)]
+    lib.bp_get_info.restype = C.c_int
+    lib.bp_get_stage_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+    lib.bp_get_stage_ms.restype = C.c_int
+    lib.bp_run_stage.argtypes = [vp, C.c_int, C.POINTER(bp_stage_buffers), i64]
+    lib.bp_run_stage.restype = C.c_int
+    lib.bp_pyramid_layout.argtypes = [C.c_int, C.POINTER(i64), C.POINTER(i64)]
+    lib.bp_pyramid_layout.restype = C.c_int
+    lib.bp_version.argtypes = []
+    lib.bp_version.restype = C.c_char_p
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(lib: C.CDLL, handle, rc: int, what: str) -> None:
+    """Map a negative bp_status to the exception the reference's callers would see."""
+    if rc == BP_OK:
+        return
+    msg = lib.bp_last_error(handle)
+    text = f"{what}: {_ERR_NAMES.get(rc, rc)}: {msg.decode(errors='replace') if msg else ''}"
+    if rc in (-1, -2, -6):
+        raise ValueError(text)  # reference: ValueError for bad model / bad shapes (inference.py:148-154)
+    raise NativeLibraryError(text)

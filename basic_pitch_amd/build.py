@@ -1,0 +1,76 @@
+"""In-tree build of libbasicpitch_amd.so (hipcc, gfx950 only) — no JIT cache, no site-packages.
+
+hipcc cross-compiles without a GPU, so this runs in the dev container as well as on the GPU box
+(where the prebuilt .so shipped with the snapshot is normally reused).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from typing import List
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libbasicpitch_amd.so")
+HEADER = os.path.join(PKG_DIR, "..", "include", "basic_pitch_amd.h")
+
+SOURCES = [
+    "bp_api.hip",
+    "cqt_pyramid.hip",
+    "cqt_filterbank.hip",
+    "conv_contour1.hip",
+    "conv_stride3.hip",
+    "conv_heads.hip",
+    "note_decode.cpp",
+]
+
+
+def _sources() -> List[str]:
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = _sources() + [os.path.join(CSRC, "bp_common.h"), HEADER]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def find_hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X library cannot be built (there is no CPU fallback)")
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into basic_pitch_amd/lib/libbasicpitch_amd.so."""
+    if not force and not _stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [
+        find_hipcc(),
+        "--offload-arch=gfx950",
+        "-O3",
+        "-std=c++17",
+        "-fPIC",
+        "-shared",
+        "-Wall",
+        "-Wno-unused-function",
+        "-o",
+        LIB_PATH + ".tmp",
+    ] + _sources()
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

@@ -1,0 +1,680 @@
+// C ABI of libbasicpitch_amd.so (include/basic_pitch_amd.h): context, weights blob parsing, operand
+// packing for the MFMA kernels, HBM workspace and stage orchestration.
+//
+// Replaces, for the hot path only, what the reference delegates to TensorFlow / onnxruntime /
+// TFLite / CoreML behind basic_pitch/inference.py:71-182 (Model) and the window loop of
+// run_inference (inference.py:282-315).
+#include "../../include/basic_pitch_amd.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bp_common.h"
+
+namespace bp {
+// kernels (one translation unit each)
+void launch_pyramid(const float* audio, float* pyr, const float* lowpass, int n_windows, hipStream_t s);
+void launch_window_track(const float* samples, int64_t n_samples, int64_t first_window, int n_windows,
+                         float* audio, hipStream_t s);
+void launch_unwrap(const float* win_out, int n_freq, int64_t first_window, int n_windows,
+                   int64_t total_rows, float* out, hipStream_t s);
+void launch_filterbank(const float* audio, const float* pyr, const float* bfrag, const float* sqrt_len,
+                       float* lp, int* mm, int n_windows, LogConsts kc, int n_cu, hipStream_t s);
+void launch_contour1(const float* lp, const int* mm, const float* bfrag, const float* bias, float* c1,
+                     int n_windows, LogConsts kc, int n_cu, hipStream_t s);
+void launch_onset1(const float* lp, const int* mm, const float* bfrag, const float* bias, float* o1,
+                   int n_windows, LogConsts kc, int n_cu, hipStream_t s);
+void launch_note1(const float* contour, const float* bfrag, const float* bias, float* n1, int n_windows,
+                  int n_cu, hipStream_t s);
+void launch_contour2(const float* c1, const float* wgt, float bias, float* contour, int n_windows,
+                     hipStream_t s);
+void launch_note2(const float* n1, const float* wgt, float bias, float* note, int n_windows,
+                  hipStream_t s);
+void launch_onset2(const float* note, const float* o1, const float* wgt, float bias, float* onset,
+                   int n_windows, hipStream_t s);
+}  // namespace bp
+
+using namespace bp;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Tensor {
+  const float* data = nullptr;
+  uint32_t ndim = 0, dims[4] = {1, 1, 1, 1}, count = 0;
+};
+
+struct Blob {
+  std::vector<std::pair<std::string, Tensor>> t;
+  const Tensor* find(const char* name) const {
+    for (auto& kv : t)
+      if (kv.first == name) return &kv.second;
+    return nullptr;
+  }
+};
+
+bool parse_blob(const void* weights, size_t nbytes, Blob& out, std::string& err) {
+  const uint8_t* p = static_cast<const uint8_t*>(weights);
+  if (!p || nbytes < 16 || std::memcmp(p, "BPAMDW01", 8) != 0) {
+    err = "weights blob: bad magic (expected BPAMDW01)";
+    return false;
+  }
+  uint32_t version, n;
+  std::memcpy(&version, p + 8, 4);
+  std::memcpy(&n, p + 12, 4);
+  if (version != 1 || n > 1024 || nbytes < 16 + (size_t)52 * n) {
+    err = "weights blob: bad version or truncated directory";
+    return false;
+  }
+  const size_t data0 = 16 + (size_t)52 * n;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint8_t* e = p + 16 + (size_t)52 * i;
+    char name[25] = {0};
+    std::memcpy(name, e, 24);
+    Tensor t;
+    std::memcpy(&t.ndim, e + 24, 4);
+    std::memcpy(t.dims, e + 28, 16);
+    uint32_t off;
+    std::memcpy(&off, e + 44, 4);
+    std::memcpy(&t.count, e + 48, 4);
+    if (t.ndim > 4 || data0 + 4 * ((size_t)off + t.count) > nbytes) {
+      err = std::string("weights blob: tensor out of bounds: ") + name;
+      return false;
+    }
+    t.data = reinterpret_cast<const float*>(p + data0 + 4 * (size_t)off);
+    out.t.emplace_back(name, t);
+  }
+  return true;
+}
+
+bool expect(const Blob& b, const char* name, std::initializer_list<uint32_t> shape, const Tensor*& t,
+            std::string& err) {
+  t = b.find(name);
+  if (!t) {
+    err = std::string("weights blob: missing tensor ") + name;
+    return false;
+  }
+  uint32_t cnt = 1;
+  uint32_t i = 0;
+  for (uint32_t d : shape) {
+    if (i >= t->ndim || t->dims[i] != d) {
+      err = std::string("weights blob: wrong shape for ") + name;
+      return false;
+    }
+    cnt *= d;
+    ++i;
+  }
+  if (i != t->ndim || cnt != t->count) {
+    err = std::string("weights blob: wrong rank/count for ") + name;
+    return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+struct bp_context {
+  int device = 0;
+  unsigned flags = 0;
+  int n_cu = 256;
+  char arch[32] = {0};
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  int64_t cap = 0;
+  int64_t workspace_bytes = 0;
+  std::string err;
+
+  LogConsts kc{};
+  float b_contour2 = 0, b_note2 = 0, b_onset2 = 0;
+  // device constants
+  float *d_lowpass = nullptr, *d_sqrt_len = nullptr, *d_fb_bfrag = nullptr;
+  float *d_c1_bfrag = nullptr, *d_c1_bias = nullptr, *d_o1_bfrag = nullptr, *d_o1_bias = nullptr;
+  float *d_n1_bfrag = nullptr, *d_n1_bias = nullptr, *d_w_contour2 = nullptr, *d_w_note2 = nullptr,
+        *d_w_onset2 = nullptr;
+  // workspace (per chunk of `cap` windows)
+  float *audio = nullptr, *pyr = nullptr, *lp = nullptr, *c1 = nullptr, *contour = nullptr, *n1 = nullptr,
+        *note = nullptr, *o1 = nullptr, *onset = nullptr;
+  int* mm = nullptr;
+  // track path staging (grow-only)
+  float* track = nullptr;
+  int64_t track_cap = 0;
+  float* track_out = nullptr;  // [T, 88+88+264] staging when outputs are host pointers
+  int64_t track_out_cap = 0;
+
+  // stage timing: a ring of event sets, one per chunk, averaged by bp_get_stage_ms
+  static constexpr int kTimedRing = 128;
+  hipEvent_t ev[kTimedRing][BP_N_STAGES + 1] = {};
+  bool ev_valid = false;
+  int64_t timed_chunks = 0;  // chunks recorded since the last bp_get_stage_ms
+};
+
+#define BP_HIP(call)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      char buf_[512];                                                                      \
+      std::snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                    __FILE__, __LINE__);                                                   \
+      h->err = buf_;                                                                       \
+      return (e_ == hipErrorOutOfMemory) ? BP_ERR_OUT_OF_MEMORY : BP_ERR_HIP;              \
+    }                                                                                      \
+  } while (0)
+
+namespace {
+
+int upload(bp_handle h, const std::vector<float>& host, float** dev) {
+  BP_HIP(hipMalloc(dev, host.size() * sizeof(float)));
+  BP_HIP(hipMemcpy(*dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  h->workspace_bytes += host.size() * sizeof(float);
+  return BP_OK;
+}
+
+int alloc(bp_handle h, float** p, int64_t floats) {
+  BP_HIP(hipMalloc(p, floats * sizeof(float)));
+  h->workspace_bytes += floats * sizeof(float);
+  return BP_OK;
+}
+
+// ---- operand packing -----------------------------------------------------------------------
+// Filterbank B fragments [4 roles][55 steps][64 lanes] (cqt_filterbank.hip roles; 16x16x4: lane ->
+// B[k = lane >> 4][n = lane & 15]).
+bool pack_filterbank(const Tensor* re, const Tensor* im, std::vector<float>& out, std::string& err) {
+  // verify the clipped K ranges cover every non-zero tap
+  for (int f = 0; f < 36; ++f) {
+    const int lo = f < 16 ? 20 : f < 32 ? 48 : 68, hi = f < 16 ? 236 : f < 32 ? 208 : 188;
+    for (int i = 0; i < 256; ++i) {
+      if ((i < lo || i >= hi) && (re->data[f * 256 + i] != 0.f || im->data[f * 256 + i] != 0.f)) {
+        err = "CQT kernel support exceeds the tap ranges this build is specialised for";
+        return false;
+      }
+    }
+  }
+  out.assign(4 * 55 * 64, 0.f);
+  for (int role = 0; role < 4; ++role) {
+    for (int j = 0; j < 55; ++j) {
+      for (int lane = 0; lane < 64; ++lane) {
+        const int kk = lane >> 4, n = lane & 15;
+        float v = 0.f;
+        if (role < 2) {
+          if (j < 54) {
+            const int tap = 4 * (5 + j) + kk;
+            v = (role == 0 ? re : im)->data[n * 256 + tap];
+          }
+        } else {
+          const Tensor* main = (role == 2) ? re : im;
+          if (j < 40) {
+            const int tap = 4 * (12 + j) + kk;
+            v = main->data[(16 + n) * 256 + tap];
+          } else {
+            const int s = (role == 2 ? 17 : 32) + (j - 40);
+            const int tap = 4 * s + kk;
+            if (n < 4)
+              v = re->data[(32 + n) * 256 + tap];
+            else if (n < 8)
+              v = im->data[(32 + n - 4) * 256 + tap];
+          }
+        }
+        out[((size_t)role * 55 + j) * 64 + lane] = v;
+      }
+    }
+  }
+  return true;
+}
+
+// contour conv1 Toeplitz B fragments [4 waves][126][64] (conv_contour1.hip).
+void pack_contour1(const Tensor* w, std::vector<float>& out) {
+  static const int chan[4][2] = {{0, 1}, {2, 4}, {5, 3}, {6, 7}};
+  out.assign(4 * 126 * 64, 0.f);
+  for (int wave = 0; wave < 4; ++wave)
+    for (int slot = 0; slot < 2; ++slot)
+      for (int dt = 0; dt < 3; ++dt)
+        for (int ep = 0; ep < 21; ++ep)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int kodd = lane >> 5, n = lane & 31, o = n >> 2, jj = n & 3;
+            const int c = chan[wave][slot];
+            const int df = 2 * ep + kodd - jj;
+            float v = 0.f;
+            if (df >= 0 && df < 39) v = w->data[((o * 8 + c) * 3 + dt) * 39 + df];
+            out[((size_t)wave * 126 + slot * 63 + dt * 21 + ep) * 64 + lane] = v;
+          }
+}
+
+void pack_onset1(const Tensor* w, std::vector<float>& out) {
+  out.assign(100 * 64, 0.f);
+  for (int cp = 0; cp < 4; ++cp)
+    for (int dt = 0; dt < 5; ++dt)
+      for (int dw = 0; dw < 5; ++dw)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int c = 2 * cp + (lane >> 5), o = lane & 31;
+          out[((size_t)(cp * 5 + dt) * 5 + dw) * 64 + lane] = w->data[((o * 8 + c) * 5 + dt) * 5 + dw];
+        }
+}
+
+void pack_note1(const Tensor* w, std::vector<float>& out) {
+  out.assign(25 * 64, 0.f);
+  for (int s = 0; s < 25; ++s)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int k = 2 * s + (lane >> 5), o = lane & 31;
+      out[(size_t)s * 64 + lane] = (k < 49) ? w->data[o * 49 + k] : 0.f;
+    }
+}
+
+int free_all(bp_handle h) {
+  float* ptrs[] = {h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+                   h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
+                   h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
+                   h->track_out};
+  for (float* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (h->mm) (void)hipFree(h->mm);
+  if (h->ev_valid)
+    for (auto& row : h->ev)
+      for (auto& e : row) (void)hipEventDestroy(e);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  return BP_OK;
+}
+
+// One chunk (n <= cap) of windows already resident at `audio_dev`; outputs to device pointers.
+int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float* onset_dev,
+              float* contour_dev) {
+  hipStream_t s = h->stream;
+  const bool timing = (h->flags & BP_FLAG_STAGE_TIMING) != 0;
+  int e = 0;
+  hipEvent_t* ev = h->ev[h->timed_chunks % bp_context::kTimedRing];
+  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
+  launch_pyramid(audio_dev, h->pyr, h->d_lowpass, n, s);
+  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
+  launch_filterbank(audio_dev, h->pyr, h->d_fb_bfrag, h->d_sqrt_len, h->lp, h->mm, n, h->kc, h->n_cu, s);
+  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
+  launch_contour1(h->lp, h->mm, h->d_c1_bfrag, h->d_c1_bias, h->c1, n, h->kc, h->n_cu, s);
+  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
+  launch_contour2(h->c1, h->d_w_contour2, h->b_contour2, contour_dev, n, s);
+  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
+  launch_note1(contour_dev, h->d_n1_bfrag, h->d_n1_bias, h->n1, n, h->n_cu, s);
+  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
+  launch_note2(h->n1, h->d_w_note2, h->b_note2, note_dev, n, s);
+  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
+  launch_onset1(h->lp, h->mm, h->d_o1_bfrag, h->d_o1_bias, h->o1, n, h->kc, h->n_cu, s);
+  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
+  launch_onset2(note_dev, h->o1, h->d_w_onset2, h->b_onset2, onset_dev, n, s);
+  if (timing) {
+    BP_HIP(hipEventRecord(ev[e++], s));
+    h->timed_chunks++;
+  }
+  BP_HIP(hipGetLastError());
+  return BP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bp_version(void) { return "basic_pitch_amd 0.1.0 (gfx950)"; }
+
+const char* bp_last_error(bp_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned flags,
+              int64_t max_windows_hint, bp_handle* out) {
+  if (!out) {
+    g_create_error = "bp_create: out is NULL";
+    return BP_ERR_INVALID_ARG;
+  }
+  *out = nullptr;
+  Blob blob;
+  std::string err;
+  if (!parse_blob(weights, nbytes, blob, err)) {
+    g_create_error = err;
+    return BP_ERR_BAD_WEIGHTS;
+  }
+  const Tensor *re, *im, *lowp, *sq, *eps, *lsc, *bn, *c1w, *c1b, *c2w, *c2b, *n1w, *n1b, *n2w, *n2b, *o1w,
+      *o1b, *o2w, *o2b;
+  if (!expect(blob, "cqt_kernel_re", {36, 256}, re, err) || !expect(blob, "cqt_kernel_im", {36, 256}, im, err) ||
+      !expect(blob, "cqt_lowpass", {256}, lowp, err) || !expect(blob, "cqt_sqrt_len", {309}, sq, err) ||
+      !expect(blob, "log_eps", {1}, eps, err) || !expect(blob, "log_scale", {2}, lsc, err) ||
+      !expect(blob, "bn_affine", {2}, bn, err) || !expect(blob, "contour1_w", {8, 8, 3, 39}, c1w, err) ||
+      !expect(blob, "contour1_b", {8}, c1b, err) || !expect(blob, "contour2_w", {1, 8, 5, 5}, c2w, err) ||
+      !expect(blob, "contour2_b", {1}, c2b, err) || !expect(blob, "note1_w", {32, 1, 7, 7}, n1w, err) ||
+      !expect(blob, "note1_b", {32}, n1b, err) || !expect(blob, "note2_w", {1, 32, 7, 3}, n2w, err) ||
+      !expect(blob, "note2_b", {1}, n2b, err) || !expect(blob, "onset1_w", {32, 8, 5, 5}, o1w, err) ||
+      !expect(blob, "onset1_b", {32}, o1b, err) || !expect(blob, "onset2_w", {1, 33, 3, 3}, o2w, err) ||
+      !expect(blob, "onset2_b", {1}, o2b, err)) {
+    g_create_error = err;
+    return BP_ERR_BAD_WEIGHTS;
+  }
+  std::vector<float> fb;
+  if (!pack_filterbank(re, im, fb, err)) {
+    g_create_error = err;
+    return BP_ERR_UNSUPPORTED;
+  }
+
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+    g_create_error = "bp_create: no HIP device visible (this library has no CPU path)";
+    return BP_ERR_NO_DEVICE;
+  }
+  if (device_ordinal < 0 || device_ordinal >= n_dev) {
+    g_create_error = "bp_create: device_ordinal out of range";
+    return BP_ERR_INVALID_ARG;
+  }
+  hipDeviceProp_t prop;
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) {
+    g_create_error = "bp_create: hipSetDevice / hipGetDeviceProperties failed";
+    return BP_ERR_NO_DEVICE;
+  }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("bp_create: device is ") + prop.gcnArchName +
+                     ", this library only carries gfx950 (MI355X) code objects";
+    return BP_ERR_NO_DEVICE;
+  }
+
+  bp_handle h = new bp_context();
+  h->device = device_ordinal;
+  h->flags = flags;
+  h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  std::snprintf(h->arch, sizeof h->arch, "%s", prop.gcnArchName);
+  h->cap = max_windows_hint > 0 ? max_windows_hint : 256;
+  h->kc.eps = eps->data[0];
+  h->kc.s0 = lsc->data[0];
+  h->kc.s1 = lsc->data[1];
+  h->kc.bn_a = bn->data[0];
+  h->kc.bn_b = bn->data[1];
+  h->b_contour2 = c2b->data[0];
+  h->b_note2 = n2b->data[0];
+  h->b_onset2 = o2b->data[0];
+
+  auto fail = [&](int code) {
+    g_create_error = h->err;
+    free_all(h);
+    delete h;
+    return code;
+  };
+  auto vec = [](const Tensor* t) { return std::vector<float>(t->data, t->data + t->count); };
+  int rc;
+  {
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      h->err = std::string("hipStreamCreate failed: ") + hipGetErrorString(e);
+      return fail(BP_ERR_HIP);
+    }
+    h->stream = h->own_stream;
+  }
+  std::vector<float> c1f, o1f, n1f;
+  pack_contour1(c1w, c1f);
+  pack_onset1(o1w, o1f);
+  pack_note1(n1w, n1f);
+  if ((rc = upload(h, vec(lowp), &h->d_lowpass)) || (rc = upload(h, vec(sq), &h->d_sqrt_len)) ||
+      (rc = upload(h, fb, &h->d_fb_bfrag)) || (rc = upload(h, c1f, &h->d_c1_bfrag)) ||
+      (rc = upload(h, vec(c1b), &h->d_c1_bias)) || (rc = upload(h, o1f, &h->d_o1_bfrag)) ||
+      (rc = upload(h, vec(o1b), &h->d_o1_bias)) || (rc = upload(h, n1f, &h->d_n1_bfrag)) ||
+      (rc = upload(h, vec(n1b), &h->d_n1_bias)) || (rc = upload(h, vec(c2w), &h->d_w_contour2)) ||
+      (rc = upload(h, vec(n2w), &h->d_w_note2)) || (rc = upload(h, vec(o2w), &h->d_w_onset2)))
+    return fail(rc);
+
+  const int64_t cap = h->cap;
+  if ((rc = alloc(h, &h->audio, cap * kAudioN)) || (rc = alloc(h, &h->pyr, cap * kPyrStride)) ||
+      (rc = alloc(h, &h->lp, cap * kFrames * kBins)) || (rc = alloc(h, &h->c1, cap * 8 * kPlaneC)) ||
+      (rc = alloc(h, &h->contour, cap * kPlaneC)) || (rc = alloc(h, &h->n1, cap * 32 * kPlaneN)) ||
+      (rc = alloc(h, &h->note, cap * kPlaneN)) || (rc = alloc(h, &h->o1, cap * 32 * kPlaneN)) ||
+      (rc = alloc(h, &h->onset, cap * kPlaneN)))
+    return fail(rc);
+  {
+    hipError_t e = hipMalloc(&h->mm, cap * 2 * sizeof(int));
+    if (e != hipSuccess) {
+      h->err = std::string("hipMalloc(mm) failed: ") + hipGetErrorString(e);
+      return fail(BP_ERR_OUT_OF_MEMORY);
+    }
+  }
+  if (flags & BP_FLAG_STAGE_TIMING) {
+    for (auto& row : h->ev)
+      for (auto& e : row)
+        if (hipEventCreate(&e) != hipSuccess) {
+          h->err = "hipEventCreate failed";
+          return fail(BP_ERR_HIP);
+        }
+    h->ev_valid = true;
+  }
+  *out = h;
+  return BP_OK;
+}
+
+void bp_destroy(bp_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  free_all(h);
+  delete h;
+}
+
+int bp_set_stream(bp_handle h, void* hip_stream) {
+  if (!h) return BP_ERR_INVALID_ARG;
+  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  return BP_OK;
+}
+
+int bp_synchronize(bp_handle h) {
+  if (!h) return BP_ERR_INVALID_ARG;
+  BP_HIP(hipSetDevice(h->device));
+  BP_HIP(hipStreamSynchronize(h->stream));
+  return BP_OK;
+}
+
+int bp_get_info(bp_handle h, bp_info* out) {
+  if (!h || !out) return BP_ERR_INVALID_ARG;
+  out->device_ordinal = h->device;
+  out->compute_units = h->n_cu;
+  out->max_windows = h->cap;
+  out->workspace_bytes = h->workspace_bytes;
+  std::memset(out->arch, 0, sizeof out->arch);
+  std::snprintf(out->arch, sizeof out->arch, "%s", h->arch);
+  return BP_OK;
+}
+
+int bp_infer_async(bp_handle h, const float* audio_dev, int64_t n_windows, float* note_dev,
+                   float* onset_dev, float* contour_dev) {
+  if (!h) return BP_ERR_INVALID_ARG;
+  if (n_windows < 0 || (n_windows > 0 && (!audio_dev || !note_dev || !onset_dev || !contour_dev))) {
+    h->err = "bp_infer: null pointer or negative window count";
+    return BP_ERR_INVALID_ARG;
+  }
+  BP_HIP(hipSetDevice(h->device));
+  for (int64_t w0 = 0; w0 < n_windows; w0 += h->cap) {
+    const int n = (int)((n_windows - w0) < h->cap ? (n_windows - w0) : h->cap);
+    int rc = run_chunk(h, audio_dev + w0 * kAudioN, n, note_dev + w0 * kPlaneN, onset_dev + w0 * kPlaneN,
+                       contour_dev + w0 * kPlaneC);
+    if (rc) return rc;
+  }
+  return BP_OK;
+}
+
+int bp_infer(bp_handle h, const float* audio, int64_t n_windows, float* note, float* onset,
+             float* contour, int mem_kind) {
+  if (!h) return BP_ERR_INVALID_ARG;
+  if (mem_kind == BP_MEM_DEVICE) {
+    int rc = bp_infer_async(h, audio, n_windows, note, onset, contour);
+    if (rc) return rc;
+    BP_HIP(hipStreamSynchronize(h->stream));
+    return BP_OK;
+  }
+  if (mem_kind != BP_MEM_HOST) {
+    h->err = "bp_infer: unknown mem_kind";
+    return BP_ERR_INVALID_ARG;
+  }
+  if (n_windows < 0 || (n_windows > 0 && (!audio || !note || !onset || !contour))) {
+    h->err = "bp_infer: null pointer or negative window count";
+    return BP_ERR_INVALID_ARG;
+  }
+  BP_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  for (int64_t w0 = 0; w0 < n_windows; w0 += h->cap) {
+    const int n = (int)((n_windows - w0) < h->cap ? (n_windows - w0) : h->cap);
+    BP_HIP(hipMemcpyAsync(h->audio, audio + w0 * kAudioN, (size_t)n * kAudioN * 4, hipMemcpyHostToDevice, s));
+    int rc = run_chunk(h, h->audio, n, h->note, h->onset, h->contour);
+    if (rc) return rc;
+    BP_HIP(hipMemcpyAsync(note + w0 * kPlaneN, h->note, (size_t)n * kPlaneN * 4, hipMemcpyDeviceToHost, s));
+    BP_HIP(hipMemcpyAsync(onset + w0 * kPlaneN, h->onset, (size_t)n * kPlaneN * 4, hipMemcpyDeviceToHost, s));
+    BP_HIP(hipMemcpyAsync(contour + w0 * kPlaneC, h->contour, (size_t)n * kPlaneC * 4, hipMemcpyDeviceToHost, s));
+    BP_HIP(hipStreamSynchronize(s));
+  }
+  return BP_OK;
+}
+
+int64_t bp_track_n_windows(int64_t n_samples) {
+  if (n_samples <= 0) return 0;
+  return (n_samples + BP_OVERLAP_LEN / 2 + BP_HOP_SIZE - 1) / BP_HOP_SIZE;
+}
+
+int64_t bp_track_n_frames(int64_t n_samples) {
+  if (n_samples <= 0) return 0;
+  // int(n_samples / hop_size * 142) evaluated like the reference: float64 division, then product
+  const double n_expected_windows = (double)n_samples / (double)BP_HOP_SIZE;
+  int64_t rows = (int64_t)(n_expected_windows * (double)BP_FRAMES_PER_WINDOW);
+  const int64_t avail = bp_track_n_windows(n_samples) * BP_FRAMES_PER_WINDOW;
+  return rows < avail ? rows : avail;
+}
+
+int bp_infer_track(bp_handle h, const float* samples, int64_t n_samples, float* note, float* onset,
+                   float* contour, int mem_kind) {
+  if (!h) return BP_ERR_INVALID_ARG;
+  if (n_samples < 0 || (mem_kind != BP_MEM_HOST && mem_kind != BP_MEM_DEVICE)) {
+    h->err = "bp_infer_track: bad argument";
+    return BP_ERR_INVALID_ARG;
+  }
+  const int64_t n_win = bp_track_n_windows(n_samples);
+  const int64_t T = bp_track_n_frames(n_samples);
+  if (n_win == 0) return BP_OK;
+  if (!samples || (T > 0 && (!note || !onset || !contour))) {
+    h->err = "bp_infer_track: null pointer";
+    return BP_ERR_INVALID_ARG;
+  }
+  BP_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const float* d_samples = samples;
+  if (mem_kind == BP_MEM_HOST) {
+    if (n_samples > h->track_cap) {
+      if (h->track) BP_HIP(hipFree(h->track));
+      h->track = nullptr;
+      h->track_cap = 0;
+      BP_HIP(hipMalloc(&h->track, (size_t)n_samples * 4));
+      h->track_cap = n_samples;
+    }
+    BP_HIP(hipMemcpyAsync(h->track, samples, (size_t)n_samples * 4, hipMemcpyHostToDevice, s));
+    d_samples = h->track;
+  }
+  float *d_note = note, *d_onset = onset, *d_contour = contour;
+  if (mem_kind == BP_MEM_HOST) {
+    const int64_t need = T * (88 + 88 + 264);
+    if (need > h->track_out_cap) {
+      if (h->track_out) BP_HIP(hipFree(h->track_out));
+      h->track_out = nullptr;
+      h->track_out_cap = 0;
+      BP_HIP(hipMalloc(&h->track_out, (size_t)(need > 0 ? need : 1) * 4));
+      h->track_out_cap = need;
+    }
+    d_note = h->track_out;
+    d_onset = d_note + T * 88;
+    d_contour = d_onset + T * 88;
+  }
+  for (int64_t w0 = 0; w0 < n_win; w0 += h->cap) {
+    const int n = (int)((n_win - w0) < h->cap ? (n_win - w0) : h->cap);
+    launch_window_track(d_samples, n_samples, w0, n, h->audio, s);
+    int rc = run_chunk(h, h->audio, n, h->note, h->onset, h->contour);
+    if (rc) return rc;
+    if (T > 0) {
+      launch_unwrap(h->note, 88, w0, n, T, d_note, s);
+      launch_unwrap(h->onset, 88, w0, n, T, d_onset, s);
+      launch_unwrap(h->contour, 264, w0, n, T, d_contour, s);
+    }
+  }
+  BP_HIP(hipGetLastError());
+  if (mem_kind == BP_MEM_HOST && T > 0) {
+    BP_HIP(hipMemcpyAsync(note, d_note, (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
+    BP_HIP(hipMemcpyAsync(onset, d_onset, (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
+    BP_HIP(hipMemcpyAsync(contour, d_contour, (size_t)T * 264 * 4, hipMemcpyDeviceToHost, s));
+  }
+  BP_HIP(hipStreamSynchronize(s));
+  return BP_OK;
+}
+
+int bp_get_stage_ms(bp_handle h, float* ms, int n) {
+  if (!h || !ms || n < BP_N_STAGES) return BP_ERR_INVALID_ARG;
+  if (!(h->flags & BP_FLAG_STAGE_TIMING) || h->timed_chunks == 0) {
+    h->err = "bp_get_stage_ms: handle was not created with BP_FLAG_STAGE_TIMING or nothing ran yet";
+    return BP_ERR_UNSUPPORTED;
+  }
+  BP_HIP(hipStreamSynchronize(h->stream));
+  const int64_t cnt = h->timed_chunks < bp_context::kTimedRing ? h->timed_chunks : bp_context::kTimedRing;
+  double acc[BP_N_STAGES] = {0};
+  for (int64_t c = 0; c < cnt; ++c) {
+    for (int i = 0; i < BP_N_STAGES; ++i) {
+      float t = 0.f;
+      BP_HIP(hipEventElapsedTime(&t, h->ev[c][i], h->ev[c][i + 1]));
+      acc[i] += t;
+    }
+  }
+  for (int i = 0; i < BP_N_STAGES; ++i) ms[i] = (float)(acc[i] / (double)cnt);
+  h->timed_chunks = 0;
+  return BP_OK;
+}
+
+int bp_pyramid_layout(int level, int64_t* offset, int64_t* length) {
+  if (level < 1 || level > 8 || !offset || !length) return BP_ERR_INVALID_ARG;
+  *offset = pyr_off(level);
+  *length = level_len(level);
+  return BP_OK;
+}
+
+int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_windows) {
+  if (!h || !bf || n_windows <= 0 || n_windows > (1 << 20)) return BP_ERR_INVALID_ARG;
+  BP_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const int n = (int)n_windows;
+  auto need = [&](const void* p) { return p != nullptr; };
+  bool ok = true;
+  switch (stage) {
+    case BP_STAGE_PYRAMID:
+      if ((ok = need(bf->audio) && need(bf->pyr))) launch_pyramid(bf->audio, bf->pyr, h->d_lowpass, n, s);
+      break;
+    case BP_STAGE_FILTERBANK:
+      if ((ok = need(bf->audio) && need(bf->pyr) && need(bf->lp) && need(bf->mm)))
+        launch_filterbank(bf->audio, bf->pyr, h->d_fb_bfrag, h->d_sqrt_len, bf->lp, bf->mm, n, h->kc, h->n_cu, s);
+      break;
+    case BP_STAGE_CONTOUR1:
+      if ((ok = need(bf->lp) && need(bf->mm) && need(bf->c1)))
+        launch_contour1(bf->lp, bf->mm, h->d_c1_bfrag, h->d_c1_bias, bf->c1, n, h->kc, h->n_cu, s);
+      break;
+    case BP_STAGE_CONTOUR2:
+      if ((ok = need(bf->c1) && need(bf->contour)))
+        launch_contour2(bf->c1, h->d_w_contour2, h->b_contour2, bf->contour, n, s);
+      break;
+    case BP_STAGE_NOTE1:
+      if ((ok = need(bf->contour) && need(bf->n1)))
+        launch_note1(bf->contour, h->d_n1_bfrag, h->d_n1_bias, bf->n1, n, h->n_cu, s);
+      break;
+    case BP_STAGE_NOTE2:
+      if ((ok = need(bf->n1) && need(bf->note))) launch_note2(bf->n1, h->d_w_note2, h->b_note2, bf->note, n, s);
+      break;
+    case BP_STAGE_ONSET1:
+      if ((ok = need(bf->lp) && need(bf->mm) && need(bf->o1)))
+        launch_onset1(bf->lp, bf->mm, h->d_o1_bfrag, h->d_o1_bias, bf->o1, n, h->kc, h->n_cu, s);
+      break;
+    case BP_STAGE_ONSET2:
+      if ((ok = need(bf->note) && need(bf->o1) && need(bf->onset)))
+        launch_onset2(bf->note, bf->o1, h->d_w_onset2, h->b_onset2, bf->onset, n, s);
+      break;
+    default:
+      h->err = "bp_run_stage: unknown stage";
+      return BP_ERR_INVALID_ARG;
+  }
+  if (!ok) {
+    h->err = "bp_run_stage: a buffer this stage needs is NULL";
+    return BP_ERR_INVALID_ARG;
+  }
+  BP_HIP(hipGetLastError());
+  BP_HIP(hipStreamSynchronize(s));
+  return BP_OK;
+}
+
+}  // extern "C"

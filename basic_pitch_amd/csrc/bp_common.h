@@ -1,0 +1,69 @@
+// Shared constants and device helpers for the gfx950 Basic Pitch kernels.
+// Geometry follows the reference's frozen graph (basic_pitch/constants.py:25-47).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bp {
+
+constexpr int kAudioN = 43844;   // constants.py:47
+constexpr int kFrames = 172;     // constants.py:44
+constexpr int kBins = 309;       // models.py:172-177
+constexpr int kFreqC = 264;      // constants.py:36
+constexpr int kFreqN = 88;       // constants.py:35
+constexpr int kOctaves = 9;      // nnaudio.py:543
+constexpr int kBpo = 36;         // bins per octave
+constexpr int kTaps = 256;       // n_fft of the top-octave kernels / lowpass length
+constexpr int kPlaneC = kFrames * kFreqC;  // 45408
+constexpr int kPlaneN = kFrames * kFreqN;  // 15136
+constexpr int kPyrStride = 43712;
+
+// pyramid level k (1..8) lives at kPyrOff[k] inside a window's pyr row; level 0 is the audio itself
+__host__ __device__ constexpr int level_len(int k) {
+  int l = kAudioN;
+  for (int i = 0; i < k; ++i) l = (l - 2) / 2 + 1;  // nnaudio.py:269-279 (pad 127, 256 taps, stride 2)
+  return l;
+}
+__host__ __device__ constexpr int pyr_off(int k) {
+  int off = 0;
+  for (int i = 1; i < k; ++i) off += (level_len(i) + 3) & ~3;
+  return off;
+}
+static_assert(level_len(1) == 21922 && level_len(8) == 171, "pyramid geometry");
+static_assert(pyr_off(8) + level_len(8) <= kPyrStride, "pyr stride");
+
+// harmonic shifts round(36*log2(h)), h = 0.5,1,2..7   (nn.py:51-54, models.py:213-218)
+__host__ __device__ constexpr int harm_shift(int c) {
+  constexpr int s[8] = {-36, 0, 36, 57, 72, 84, 93, 101};
+  return s[c];
+}
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// order-preserving float <-> int map so per-window min/max can use integer atomics
+__device__ __forceinline__ int f2ord(float f) {
+  int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+struct LogConsts {
+  float eps;     // 1e-10                 (signal.py:175)
+  float s0, s1;  // 1/ln(10), 10          (math.py:21-32 as frozen: ONNX nodes 193-194)
+  float bn_a;    // folded BatchNorm scale (models.py:188-189; ONNX node 211)
+  float bn_b;    // folded BatchNorm shift (ONNX node 212)
+};
+
+// NormalizedLog tail + BN affine for one element (signal.py:177-183, divide_no_nan)
+__device__ __forceinline__ float norm_bn(float lp, float mn, float range, const LogConsts& k) {
+  float off = lp - mn;
+  float nrm = (range == 0.0f) ? 0.0f : off / range;
+  return __fadd_rn(__fmul_rn(nrm, k.bn_a), k.bn_b);  // Mul then Add in the frozen graph: no FMA contraction
+}
+
+__device__ __forceinline__ float sigmoidf_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+}  // namespace bp

@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json's metric on MI355X: audio windows/sec, end-to-end CQT + CNN.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (bp_infer_async: pyramid -> filterbank -> 3 branches of the CNN
+-> three posteriorgrams) over one batch of 256 synthetic 2-second 22.05 kHz windows that is already
+resident in HBM (BASELINE.json configs[1]: "Batch=256 synthetic 2 s @ 22.05 kHz mono windows,
+1xMI355X, fp32"); outputs stay in HBM.  Every rank owns its own batch (windows are independent
+units: file/window sharding, no collective on the data path — SURVEY.md §8e), so scaling is weak
+and `value` = windows processed by all ranks / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (contour conv1, 65 % of the path's FLOPs): algorithmic FLOP per launch /
+                mean launch duration measured with HIP events on the kernel's stream over the timed
+                steps, against the dense f32 MFMA peak (157.3 TFLOP/s)
+  cpu_baseline  the oracle (CPU restatement of the frozen graph, torch-CPU fp32, all host threads)
+                timed on rank 0 on a bounded sample of the same synthetic windows ("port": the
+                reference's own ONNX/TF runtimes are not installable here)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 256
+FLOP_PER_WINDOW = 1_048_159_296
+BYTES_PER_WINDOW = 478_096               # fp32 I/O: 175,376 in + 302,720 out
+C1_FLOP_PER_WINDOW = 680_030_208         # contour conv1: 2*8*8*3*39*172*264 (models.py:241-250)
+F32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: dense f32 matrix peak
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(seconds_budget: float = 12.0) -> dict:
+    """Oracle fp32 on the host cores, bounded sample (checker code, timed as the CPU baseline)."""
+    import torch
+
+    from oracle import bp_oracle as O
+
+    W = O.load_weights()
+    threads = torch.get_num_threads()
+    rng = np.random.default_rng(0)
+    chunk = 8
+    x = rng.uniform(-1, 1, (chunk, O.AUDIO_N_SAMPLES)).astype(np.float32)
+    O.forward(x[:2], W, np.float32)  # warm-up (thread pools, allocator)
+    done = 0
+    t0 = time.perf_counter()
+    while True:
+        O.forward(x, W, np.float32)
+        done += chunk
+        el = time.perf_counter() - t0
+        if el >= seconds_budget or done >= 4096:
+            break
+    return {
+        "value": done / el,
+        "unit": "windows/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{done} uniform[-1,1) windows in batches of {chunk}, {el:.1f} s, torch-CPU fp32 oracle",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from basic_pitch_amd.inference import Model
+
+    B = args.batch
+    dev = torch.device("cuda", local_rank)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    audio = (torch.rand((B, 43844), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0).contiguous()
+    out = {
+        "note": torch.empty((B, 172, 88), device=dev),
+        "onset": torch.empty((B, 172, 88), device=dev),
+        "contour": torch.empty((B, 172, 264), device=dev),
+    }
+    model = Model(device=local_rank, max_windows=B, stage_timing=True)
+
+    def step():
+        model._predict_device(audio, out=out, sync=False)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if args.warmup:
+        model.stage_ms()  # reset the per-stage accumulation
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    stage = model.stage_ms()  # mean per-launch ms over the timed steps (HIP events on the kernels' stream)
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ok = bool(torch.isfinite(out["note"]).all() and torch.isfinite(out["onset"]).all() and torch.isfinite(out["contour"]).all())
+
+    if rank == 0:
+        total_windows = B * args.steps * world
+        value = total_windows / elapsed
+        c1_ms = stage["contour1"]
+        achieved = C1_FLOP_PER_WINDOW * B / (c1_ms * 1e-3) / 1e12
+        line = {
+            "metric": "audio windows/sec (2 s @ 22.05 kHz) end-to-end CQT+CNN",
+            "value": value,
+            "unit": "windows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"batch={B} synthetic uniform[-1,1) 2 s @ 22.05 kHz mono windows per GPU, fp32, "
+                "HBM-resident in/out (BASELINE.json configs[1])",
+                "windows_per_step_per_gpu": B,
+                "sharding": "independent windows per rank, no collective",
+            },
+            "roofline": {
+                "kernel": "contour1_kernel (Conv2D 8->8 3x39 + norm/BN/stack, f32 MFMA 32x32x2)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "launch_ms": c1_ms,
+                "algorithmic_flop_per_launch": C1_FLOP_PER_WINDOW * B,
+            },
+            "path_roofline": {
+                "flop_frac_f32_peak": FLOP_PER_WINDOW * value / world / (F32_MFMA_PEAK_TFLOPS * 1e12),
+                "hbm_frac_algorithmic": BYTES_PER_WINDOW * value / world / (HBM_PEAK_GBS * 1e9),
+            },
+            "stage_ms": stage,
+            "outputs_finite": ok,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        elif not args.no_cpu_baseline:
+            line["cpu_baseline"] = None  # measured at N=1 only
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,174 @@
+/*
+ * basic_pitch_amd.h — C ABI of libbasicpitch_amd.so, the MI355X (gfx950) native executor of the
+ * Basic Pitch inference hot path (harmonic CQT + CNN -> note / onset / contour posteriorgrams).
+ *
+ * This is the drop-in boundary.  The reference (spotify/basic-pitch v0.4.0, pure Python) has no FFI
+ * of its own: its plugin point is `basic_pitch.inference.Model` (inference.py:71-182), whose
+ * `predict(x)` hands a float32 [n, 43844, 1] batch to a third-party runtime and gets three float32
+ * arrays back.  Each entry point below names the reference interface it replaces; INTEGRATION.md
+ * shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - every function returns BP_OK (0) or a negative bp_status; the message for the last failure on a
+ *     handle is bp_last_error(handle) (bp_last_error(NULL) for bp_create failures);
+ *   - outputs are caller-allocated, C-contiguous float32; the library never keeps a caller pointer
+ *     after the call returns (weights are copied by bp_create) — the reference's consumer
+ *     (note_creation.py:338-341) mutates the returned arrays in place, so they must be caller-owned;
+ *   - calls on one handle are serialised by the caller; use one handle per GPU per host thread.
+ */
+#ifndef BASIC_PITCH_AMD_H
+#define BASIC_PITCH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- geometry of the frozen graph (basic_pitch/constants.py:25-47) ---- */
+#define BP_AUDIO_SAMPLE_RATE 22050
+#define BP_FFT_HOP 256
+#define BP_AUDIO_N_SAMPLES 43844 /* constants.py:47  (2 s @ 22.05 kHz minus one hop) */
+#define BP_N_FRAMES 172          /* constants.py:44  ANNOT_N_FRAMES */
+#define BP_N_BINS_CQT 309        /* models.py:172-177 (103 semitones x 3) */
+#define BP_N_FREQ_CONTOUR 264    /* constants.py:36 */
+#define BP_N_FREQ_NOTE 88        /* constants.py:35 */
+#define BP_N_OVERLAP_FRAMES 30   /* inference.py:190 DEFAULT_OVERLAPPING_FRAMES */
+#define BP_OVERLAP_LEN 7680      /* inference.py:304 */
+#define BP_HOP_SIZE 36164        /* inference.py:305 */
+#define BP_FRAMES_PER_WINDOW 142 /* inference.py:278 (172 - 30) */
+
+typedef struct bp_context* bp_handle;
+
+typedef enum bp_status {
+  BP_OK = 0,
+  BP_ERR_INVALID_ARG = -1,   /* reference: ValueError (bad shape / null pointer) */
+  BP_ERR_BAD_WEIGHTS = -2,   /* reference: ValueError "cannot be loaded" (inference.py:148-154) */
+  BP_ERR_NO_DEVICE = -3,     /* no usable gfx950 device / HIP runtime failure at create */
+  BP_ERR_HIP = -4,           /* a HIP call failed; see bp_last_error */
+  BP_ERR_OUT_OF_MEMORY = -5,
+  BP_ERR_UNSUPPORTED = -6
+} bp_status;
+
+/* where `audio` / output pointers live */
+typedef enum bp_mem_kind {
+  BP_MEM_HOST = 0,  /* pageable or pinned host memory; the library copies H2D / D2H */
+  BP_MEM_DEVICE = 1 /* device pointers on the handle's GPU (zero-copy; used by bench.py) */
+} bp_mem_kind;
+
+/* bp_create flags */
+#define BP_FLAG_STAGE_TIMING 1u /* record HIP events around every stage; read with bp_get_stage_ms */
+
+/*
+ * Weights blob ("BPAMDW01", little endian) — produced by tools/extract_weights.py from the
+ * reference's nmp.onnx (basic_pitch/saved_models/icassp_2022/):
+ *   char magic[8]="BPAMDW01"; u32 version=1; u32 n_tensors;
+ *   n_tensors x { char name[24]; u32 ndim; u32 dims[4]; u32 offset_in_floats; u32 count; }
+ *   float32 data[]
+ * Required tensors: cqt_kernel_re/im [36,256], cqt_lowpass [256], cqt_sqrt_len [309], log_eps [1],
+ * log_scale [2], bn_affine [2], {contour1,contour2,note1,note2,onset1,onset2}_{w,b}.
+ *
+ * Replaces: inference.Model.__init__(model_path) (inference.py:78-154) — load a serialized model.
+ * `max_windows_hint` sizes the resident HBM workspace (about 5.8 MB per window); larger batches
+ * are processed in chunks of that size.  0 selects the default (256).
+ */
+int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned flags,
+              int64_t max_windows_hint, bp_handle* out);
+
+/* Replaces: Model going out of scope. */
+void bp_destroy(bp_handle h);
+
+/* Error text for the last failing call on `h` (NULL: last bp_create failure in this thread). */
+const char* bp_last_error(bp_handle h);
+
+/*
+ * Replaces: Model.predict(x) (inference.py:156-182) for x = float32 [n_windows, 43844(,1)].
+ *   note    float32 [n_windows, 172,  88]   (ONNX output StatefulPartitionedCall:1)
+ *   onset   float32 [n_windows, 172,  88]   (StatefulPartitionedCall:2)
+ *   contour float32 [n_windows, 172, 264]   (StatefulPartitionedCall:0)
+ * Blocking: returns after the outputs are complete (host) or enqueued+synchronised (device).
+ */
+int bp_infer(bp_handle h, const float* audio, int64_t n_windows, float* note, float* onset,
+             float* contour, int mem_kind);
+
+/* Same as bp_infer with BP_MEM_DEVICE but only enqueues on the handle's stream (no sync). */
+int bp_infer_async(bp_handle h, const float* audio_dev, int64_t n_windows, float* note_dev,
+                   float* onset_dev, float* contour_dev);
+
+/*
+ * Replaces: run_inference() minus decode (inference.py:282-315): get_audio_input's 3840-sample zero
+ * lead-in + window_audio_file (inference.py:194-244), the per-window predict loop (308-310) and
+ * unwrap_output (247-279), all on the device.  `samples` = mono 22.05 kHz float32 [n_samples].
+ * Outputs have bp_track_n_frames(n_samples) rows: note/onset [T,88], contour [T,264].
+ */
+int bp_infer_track(bp_handle h, const float* samples, int64_t n_samples, float* note, float* onset,
+                   float* contour, int mem_kind);
+
+/* ceil((n_samples + 3840) / 36164) windows (inference.py:207,242); 0 for n_samples <= 0 */
+int64_t bp_track_n_windows(int64_t n_samples);
+/* min(n_windows*142, int(n_samples / 36164 * 142)) rows (inference.py:277-279) */
+int64_t bp_track_n_frames(int64_t n_samples);
+
+/* Run on an externally owned hipStream_t (e.g. torch's current stream); NULL = library stream. */
+int bp_set_stream(bp_handle h, void* hip_stream);
+int bp_synchronize(bp_handle h);
+
+/* ---- introspection ---- */
+typedef struct bp_info {
+  int device_ordinal;
+  int compute_units;
+  int64_t max_windows;     /* resident workspace capacity (windows per chunk) */
+  int64_t workspace_bytes; /* HBM held by this handle */
+  char arch[32];           /* "gfx950..." */
+} bp_info;
+int bp_get_info(bp_handle h, bp_info* out);
+
+/* Stage ids for bp_get_stage_ms / bp_run_stage. */
+enum {
+  BP_STAGE_PYRAMID = 0,   /* 8 x decimate-by-2          audio -> pyr          */
+  BP_STAGE_FILTERBANK = 1,/* 9-level CQT filterbank     audio,pyr -> lp, mm   */
+  BP_STAGE_CONTOUR1 = 2,  /* norm+BN+stack+conv 3x39    lp,mm -> c1           */
+  BP_STAGE_CONTOUR2 = 3,  /* conv 5x5 + sigmoid         c1 -> contour         */
+  BP_STAGE_NOTE1 = 4,     /* conv 7x7 s3 + ReLU         contour -> n1         */
+  BP_STAGE_NOTE2 = 5,     /* conv 7x3 + sigmoid         n1 -> note            */
+  BP_STAGE_ONSET1 = 6,    /* norm+BN+stack+conv 5x5 s3  lp,mm -> o1           */
+  BP_STAGE_ONSET2 = 7,    /* concat + conv 3x3 + sigm.  note,o1 -> onset      */
+  BP_N_STAGES = 8
+};
+
+/* With BP_FLAG_STAGE_TIMING: mean milliseconds per stage over the chunks (<= 128 most recent) run
+ * since the previous call; synchronises the stream and resets the accumulation. */
+int bp_get_stage_ms(bp_handle h, float* ms, int n);
+
+/*
+ * Test hook: run ONE stage on caller-supplied DEVICE buffers (layouts in DESIGN.md "HBM layout"):
+ *   audio [n,43844]  pyr [n,BP_PYR_STRIDE]  lp [n,172,309]  mm int32 [n,2] (ordered-int min,max)
+ *   c1 [n,8,172,264]  contour [n,172,264]  n1 [n,32,172,88]  note [n,172,88]  o1 [n,32,172,88]
+ *   onset [n,172,88].  Unused pointers for a stage may be NULL.  Synchronous.
+ */
+#define BP_PYR_STRIDE 43712
+typedef struct bp_stage_buffers {
+  const float* audio;
+  float* pyr;
+  float* lp;
+  int32_t* mm;
+  float* c1;
+  float* contour;
+  float* n1;
+  float* note;
+  float* o1;
+  float* onset;
+} bp_stage_buffers;
+int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* buf, int64_t n_windows);
+
+/* Offsets (in floats) of pyramid levels 1..8 inside one window's pyr row, and their lengths. */
+int bp_pyramid_layout(int level /*1..8*/, int64_t* offset, int64_t* length);
+
+const char* bp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BASIC_PITCH_AMD_H */
