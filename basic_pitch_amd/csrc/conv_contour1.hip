@@ -18,6 +18,8 @@
 //     channel c only changes the column offset.  z is stored as 4 phase planes (bin mod 4) so the
 //     stride-4 reads of the 32 lanes are consecutive dwords — bank-conflict free, row stride
 //     450 = 2 (mod 32) keeps that true across the frame wrap inside a tile.
+//   * Taps that fall outside the cropped 264-bin stack are zeroed per lane (one compare + select
+//     per MFMA; the conv's "same" padding is defined on the stack, not on the 309-bin CQT row).
 //   * The four K-partials are summed in a fixed order through LDS, + bias, ReLU, 16-byte stores.
 //
 // Roofline (this kernel): bound = f32 MFMA (157.3 TFLOP/s).  Algorithmic work 8*8*3*39*172*264*2 =
@@ -52,7 +54,7 @@ static_assert(c1_rho(0) == 0 && c1_rho(3) == 1 && c1_rho(6) == 1 && c1_rho(7) ==
 // One channel slot: 3 rows x 21 tap pairs.  Tap e = 2*ep + kodd reads bin 4*m_f + e - 19 + s_c.
 template <int RHO, int SLOT>
 __device__ __forceinline__ void c1_channel(const float* __restrict__ baseLo,
-                                           const float* __restrict__ baseHi,
+                                           const float* __restrict__ baseHi, int fbase,
                                            const float (&breg)[kC1Steps], f32x16& acc) {
 #pragma unroll
   for (int dt = 0; dt < 3; ++dt) {
@@ -62,21 +64,24 @@ __device__ __forceinline__ void c1_channel(const float* __restrict__ baseLo,
       const int r0 = ((d0 % 4) + 4) % 4;
       const int q0 = (d0 - r0) / 4;               // floor(d0 / 4) >= -5
       const int imm = dt * kC1Ts + r0 * kC1Plane + q0 + 5;
-      const float a = (r0 < 3) ? baseLo[imm] : baseHi[imm];
+      float a = (r0 < 3) ? baseLo[imm] : baseHi[imm];
+      // "same" padding acts on the cropped 264-bin stack (nn.py:87): taps outside it are zero even
+      // where the shifted CQT row still has data.  fbase = 4*m_f + kodd - 19 -> stack bin of this tap.
+      a = ((unsigned)(fbase + 2 * ep) < (unsigned)kFreqC) ? a : 0.0f;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, breg[SLOT * 63 + dt * 21 + ep], acc, 0, 0, 0);
     }
   }
 }
 
 template <int RHO_A, int RHO_B>
-__device__ __forceinline__ void c1_tile(const float* __restrict__ zl, int lane_base, int kodd, int aA,
-                                        int aB, const float (&breg)[kC1Steps], f32x16& acc) {
+__device__ __forceinline__ void c1_tile(const float* __restrict__ zl, int lane_base, int kodd, int fbase,
+                                        int aA, int aB, const float (&breg)[kC1Steps], f32x16& acc) {
   // kodd = 1 lanes read the next tap: +1 phase plane, or (phase 3 -> 0) next group
   const float* bA = zl + lane_base + aA;
   const float* bB = zl + lane_base + aB;
   const int dLo = kodd * kC1Plane, dHi = kodd * (1 - 3 * kC1Plane);
-  c1_channel<RHO_A, 0>(bA + dLo, bA + dHi, breg, acc);
-  c1_channel<RHO_B, 1>(bB + dLo, bB + dHi, breg, acc);
+  c1_channel<RHO_A, 0>(bA + dLo, bA + dHi, fbase, breg, acc);
+  c1_channel<RHO_B, 1>(bB + dLo, bB + dHi, fbase, breg, acc);
 }
 
 __global__ __launch_bounds__(kC1Threads, 2) void contour1_kernel(
@@ -142,15 +147,16 @@ __global__ __launch_bounds__(kC1Threads, 2) void contour1_kernel(
       const int tr = m / kC1Groups;
       const int mf = m - tr * kC1Groups;
       const int lane_base = tr * kC1Ts + mf + kC1Qoff - 5;
+      const int fbase = 4 * mf + kodd - 19;
 
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
       switch (wave) {
         case 0:
-        case 1: c1_tile<0, 0>(zl, lane_base, kodd, aA, aB, breg, acc); break;
-        case 2: c1_tile<0, 1>(zl, lane_base, kodd, aA, aB, breg, acc); break;
-        default: c1_tile<1, 1>(zl, lane_base, kodd, aA, aB, breg, acc); break;
+        case 1: c1_tile<0, 0>(zl, lane_base, kodd, fbase, aA, aB, breg, acc); break;
+        case 2: c1_tile<0, 1>(zl, lane_base, kodd, fbase, aA, aB, breg, acc); break;
+        default: c1_tile<1, 1>(zl, lane_base, kodd, fbase, aA, aB, breg, acc); break;
       }
 
       // K-partials -> LDS.  C layout 32x32: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)

@@ -99,6 +99,9 @@ __global__ __launch_bounds__(kS3Threads, 2) void onset1_kernel(
       const int tr = m / kFreqN;
       const int w = m - tr * kFreqN;
       const float* base = zl + tr * kO1Ts + 3 * w + kO1Goff - 1;
+      // "same" padding acts on the cropped 264-bin stack (nn.py:87): stack bins -1 (w = 0, dw = 0) and
+      // 264 (w = 87, dw = 4) are zero even where the shifted CQT row has data there.
+      const bool edge_lo = (w == 0), edge_hi = (w == kFreqN - 1);
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -110,7 +113,9 @@ __global__ __launch_bounds__(kS3Threads, 2) void onset1_kernel(
         for (int dt = 0; dt < 5; ++dt) {
 #pragma unroll
           for (int dw = 0; dw < 5; ++dw) {
-            const float a = bc[dt * kO1Ts + dw];
+            float a = bc[dt * kO1Ts + dw];
+            if (dw == 0) a = edge_lo ? 0.0f : a;
+            if (dw == 4) a = edge_hi ? 0.0f : a;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, breg[(cp * 5 + dt) * 5 + dw], acc, 0, 0, 0);
           }
         }

@@ -1,0 +1,213 @@
+"""GPU parity tests proper: every HIP stage and the whole path vs the oracle, through the C ABI.
+
+Tolerances (floating point path; north-star bar: posteriorgrams within 1e-4 fp32):
+  * stage tests feed the ORACLE's fp32 tensors into one HIP stage and compare with the oracle's fp32
+    output of that stage: what remains is summation-order noise, bounds stated per stage below;
+  * end-to-end: |hip - fp64 oracle| <= max(1e-4, 2 * |fp32 oracle - fp64 oracle|) per tensor — the
+    reference's own fp32 execution is only defined up to that noise (SURVEY.md §7 hard part 1), and
+    plainly <= 1e-4 on the noise-like synthetic inputs BASELINE.json's configs use.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, make_windows
+from oracle import bp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+F32 = torch.float32
+
+
+@pytest.fixture(scope="module")
+def runner():
+    from stage_harness import StageRunner
+
+    return StageRunner()
+
+
+@pytest.fixture(scope="module")
+def cases(weights):
+    x = np.concatenate([make_windows("uniform", 2, 0), make_windows("normal", 1, 1), make_windows("tones", 1, 2)])
+    r32 = O.forward(x, weights, np.float32, intermediates=True)
+    r64 = O.forward(x, weights, np.float64, intermediates=True)
+    return x, r32, r64
+
+
+def test_native_library_is_loaded(runner):
+    import ctypes
+
+    info = runner.model.info()
+    assert info["arch"].startswith("gfx950")
+    maps = open("/proc/self/maps").read()
+    assert "libbasicpitch_amd.so" in maps
+    assert isinstance(runner.lib, ctypes.CDLL)
+
+
+def test_stage_pyramid(runner, cases):
+    from stage_harness import pyr_unpack
+
+    x, r32, r64 = cases
+    n = x.shape[0]
+    out = runner.run("pyramid", n, {"audio": x}, {"pyr": ((n, 43712), F32)})
+    lv = pyr_unpack(out["pyr"], runner.lib)
+    for k in range(1, 9):
+        # 256-tap fp32 dot products of O(1) data: 2e-6 absolute
+        assert np.abs(lv[k] - r64["levels"][k]).max() <= 2e-6, k
+
+
+def test_stage_filterbank(runner, cases):
+    from stage_harness import ord_decode, pyr_pack
+
+    x, r32, r64 = cases
+    n = x.shape[0]
+    out = runner.run(
+        "filterbank", n, {"audio": x, "pyr": pyr_pack(r32["levels"], runner.lib)},
+        {"lp": ((n, 172, 309), F32), "mm": ((n, 2), torch.int32)},
+    )
+    assert np.isfinite(out["lp"]).all()
+    mag = np.sqrt(np.maximum(10.0 ** (out["lp"].astype(np.float64) / 10.0) - 1e-10, 0))
+    # magnitudes are O(1); fp32 oracle itself is ~2.5e-6 from fp64
+    assert np.abs(mag - r64["mag"]).max() <= 1e-5
+    # log-power: compare where the bin is not cancellation noise (mag > 1e-3 of the window max)
+    big = r64["mag"] > 1e-3 * r64["mag"].max(axis=(1, 2), keepdims=True)
+    assert np.abs(out["lp"] - r64["lp"])[big].max() <= 2e-3
+    mm = ord_decode(out["mm"])
+    assert np.array_equal(mm[:, 0], out["lp"].min(axis=(1, 2)))
+    assert np.array_equal(mm[:, 1], out["lp"].max(axis=(1, 2)))
+
+
+@pytest.mark.parametrize(
+    "stage,ins,outs,key,tol",
+    [
+        ("contour1", ("lp", "mm"), {"c1": (8, 172, 264)}, "c1", 5e-5),
+        ("contour2", ("c1",), {"contour": (172, 264)}, "contour", 2e-6),
+        ("note1", ("contour",), {"n1": (32, 172, 88)}, "n1", 5e-6),
+        ("note2", ("n1",), {"note": (172, 88)}, "note", 2e-6),
+        ("onset1", ("lp", "mm"), {"o1": (32, 172, 88)}, "o1", 2e-4),
+        ("onset2", ("note", "o1"), {"onset": (172, 88)}, "onset", 2e-6),
+    ],
+)
+def test_stage_cnn(runner, cases, stage, ins, outs, key, tol):
+    from stage_harness import ord_encode
+
+    x, r32, r64 = cases
+    n = x.shape[0]
+    feed = {}
+    for k in ins:
+        feed[k] = ord_encode(r32["minmax"]) if k == "mm" else r32[k]
+    out = runner.run(stage, n, feed, {k: ((n,) + s, F32) for k, s in outs.items()})
+    got = out[key]
+    assert np.isfinite(got).all()
+    d = np.abs(got - r32[key]).max()
+    scale = max(1.0, float(np.abs(r32[key]).max()))
+    assert d <= tol * scale, (stage, d)
+
+
+def _noise_aware(got, r32, r64, floor=1e-4):
+    for k in ("note", "onset", "contour"):
+        ours = np.abs(got[k] - r64[k]).max()
+        orc = np.abs(r32[k] - r64[k]).max()
+        assert ours <= max(floor, 2.0 * orc), (k, ours, orc)
+
+
+def test_end_to_end_synthetic(runner, cases):
+    x, r32, r64 = cases
+    got = runner.model.predict(x)
+    _noise_aware(got, r32, r64)
+    # the headline claim: noise-like inputs (the bench workload) meet 1e-4 outright
+    for k in ("note", "onset", "contour"):
+        assert np.abs(got[k][:3] - r64[k][:3]).max() <= 1e-4, k
+    # reference I/O contract: fresh, writable, C-contiguous float32 (note_creation.py:338-341 mutates)
+    for k, shape in (("note", (4, 172, 88)), ("onset", (4, 172, 88)), ("contour", (4, 172, 264))):
+        a = got[k]
+        assert a.shape == shape and a.dtype == np.float32 and a.flags.c_contiguous and a.flags.writeable
+    got3 = runner.model.predict(x[:, :, None])  # (n, 43844, 1) like the reference
+    for k in got:
+        assert np.array_equal(got[k], got3[k])
+
+
+def test_device_path_equals_host_path(runner, cases):
+    x = cases[0]
+    a = runner.model.predict(x)
+    b = runner.model.predict(torch.from_numpy(x).cuda())
+    for k in a:
+        assert b[k].is_cuda and np.array_equal(a[k], b[k].cpu().numpy())
+
+
+def test_batch_invariance_and_chunking(weights):
+    """Windows are independent units: a window's result must not depend on its batch or position,
+    nor on how the library chunks a large batch (BASELINE.json configs[1] size, B = 256)."""
+    from basic_pitch_amd import Model
+
+    x = make_windows("uniform", 256, seed=11)
+    x[7] = 0.0  # a silent window in the middle (divide_no_nan path)
+    x[8] = make_windows("tones", 1, 5)[0]
+    big = Model(max_windows=256)
+    small = Model(max_windows=48)  # forces 6 chunks incl. a ragged tail
+    a = big.predict(x)
+    b = small.predict(x)
+    for k in a:
+        assert np.isfinite(a[k]).all()
+        assert np.array_equal(a[k], b[k]), k
+    perm = np.random.default_rng(0).permutation(256)
+    c = big.predict(x[perm])
+    for k in a:
+        assert np.array_equal(a[k][perm], c[k]), k
+    idx = [0, 7, 8, 100, 255]
+    d = big.predict(x[idx])
+    for k in a:
+        assert np.array_equal(a[k][idx], d[k]), k
+    # spot-check values at full size against the fp64 oracle
+    r64 = O.forward(x[idx], weights, np.float64)
+    r32 = O.forward(x[idx], weights, np.float32)
+    _noise_aware(d, r32, r64)
+    big.close(), small.close()
+
+
+def test_edge_cases():
+    from basic_pitch_amd import Model
+
+    m = Model(max_windows=4)
+    e = m.predict(np.zeros((0, 43844), np.float32))
+    assert e["note"].shape == (0, 172, 88) and e["contour"].shape == (0, 172, 264)
+    with pytest.raises(ValueError):
+        m.predict(np.zeros((2, 1000), np.float32))
+    with pytest.raises(ValueError):
+        m.predict(np.zeros((43844,), np.float32))
+    z = m.predict(np.zeros((1, 43844), np.float32))
+    for k in z:
+        assert np.isfinite(z[k]).all() and np.ptp(z[k][0, 20:150, 10:70]) < 1e-6
+    big = m.predict(np.full((1, 43844), 1.0, np.float32))  # DC input
+    assert all(np.isfinite(v).all() for v in big.values())
+    # tracks: empty, shorter than one hop, exactly one hop
+    for n in (0, 1, 5000, 36164, 36165):
+        r = m.predict_track(np.zeros(n, np.float32) + 0.01)
+        T = min(int(np.ceil((n + 3840) / 36164)) * 142, int(n / 36164 * 142)) if n else 0
+        assert r["note"].shape == (T, 88) and r["contour"].shape == (T, 264)
+    m.close()
+
+
+def test_track_path_equals_windowed_path_and_golden(weights, clip_22k):
+    """Config 1 of BASELINE.json: the reference's test clip end to end.  The on-device windowing /
+    un-overlapping path must equal the reference-structured per-window path bit for bit, and both
+    must agree with the reference's golden posteriorgrams (5e-3: resampler-limited, see oracle test)."""
+    from basic_pitch_amd import Model, inference as inf
+
+    m = Model()
+    wav = os.path.join(GOLDEN, "vocadito_10.wav")
+    a = inf.run_inference(wav, m)
+    b = inf.run_inference_windowed(wav, m)
+    g = np.load(os.path.join(GOLDEN, "vocadito_10_model_output.npz"))
+    for k in ("note", "onset", "contour"):
+        assert a[k].shape == g[k].shape
+        assert np.array_equal(a[k], b[k]), k
+        assert np.abs(a[k] - g[k]).max() <= 5e-3, (k, np.abs(a[k] - g[k]).max())
+        assert np.abs(a[k] - g[k]).mean() <= 1e-4
+    # and tightly against the oracle on the identical 22.05 kHz samples
+    r64 = O.run_track(clip_22k, weights, np.float64, batch=6)
+    r32 = O.run_track(clip_22k, weights, np.float32, batch=6)
+    _noise_aware(a, r32, r64)
+    m.close()

@@ -1,0 +1,192 @@
+"""CPU-side tests: the C-ABI library loads and exports what the header declares, host logic mirrors
+the reference (windowing, un-overlapping, audio ingest, shard planning).  No compute calls."""
+import ctypes as C
+import os
+import re
+import struct
+import wave
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from oracle import bp_oracle as O
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from basic_pitch_amd import _native, build
+
+    build.build_library()
+    return _native.load_library()
+
+
+def test_library_exports_every_header_symbol(lib):
+    from basic_pitch_amd import _native
+
+    header = open(os.path.join(ROOT, "include", "basic_pitch_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(bp_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_native.EXPORTED_SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert b"gfx950" in lib.bp_version()
+
+
+def test_library_is_in_tree():
+    from basic_pitch_amd import build
+
+    assert os.path.realpath(build.LIB_PATH).startswith(os.path.realpath(ROOT))
+
+
+def test_track_geometry_matches_reference_formulas(lib):
+    """inference.py:207,242 (window count) and 277-279 (row count) for many lengths."""
+    rng = np.random.default_rng(0)
+    lengths = [1, 100, 3839, 3840, 3841, 32324, 32325, 36164, 36165, 43844, 200607, 3_969_000] + [
+        int(v) for v in rng.integers(1, 5_000_000, 200)
+    ]
+    for n in lengths:
+        padded = n + 3840
+        n_win = len(range(0, padded, 36164))
+        assert lib.bp_track_n_windows(n) == n_win, n
+        rows = min(n_win * 142, int(n / 36164 * 142))
+        assert lib.bp_track_n_frames(n) == rows, n
+    assert lib.bp_track_n_windows(0) == 0 and lib.bp_track_n_frames(0) == 0
+    assert lib.bp_track_n_windows(200607) == 6 and lib.bp_track_n_frames(200607) == 787
+
+
+def test_pyramid_layout(lib):
+    lens = [21922, 10961, 5480, 2740, 1370, 685, 342, 171]
+    end = 0
+    for k in range(1, 9):
+        off, ln = C.c_int64(), C.c_int64()
+        assert lib.bp_pyramid_layout(k, C.byref(off), C.byref(ln)) == 0
+        assert ln.value == lens[k - 1] and off.value >= end and off.value % 4 == 0
+        end = off.value + ln.value
+    assert end <= 43712
+    assert lib.bp_pyramid_layout(0, C.byref(off), C.byref(ln)) != 0
+
+
+def test_create_rejects_bad_weights(lib):
+    h = C.c_void_p()
+    assert lib.bp_create(b"garbage", 7, 0, 0, 0, C.byref(h)) == -2
+    assert b"magic" in lib.bp_last_error(None)
+    blob = open(os.path.join(ROOT, "basic_pitch_amd", "assets", "nmp_weights.bin"), "rb").read()
+    assert lib.bp_create(blob[:1000], 1000, 0, 0, 0, C.byref(h)) == -2  # truncated
+    # a blob with a missing tensor
+    n = struct.unpack_from("<I", blob, 12)[0]
+    renamed = bytearray(blob)
+    renamed[16 : 16 + 24] = b"not_a_tensor".ljust(24, b"\0")
+    assert lib.bp_create(bytes(renamed), len(renamed), 0, 0, 0, C.byref(h)) == -2
+    assert n == 19
+
+
+def test_model_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from basic_pitch_amd import Model
+    from basic_pitch_amd._native import NativeLibraryError
+
+    with pytest.raises(NativeLibraryError, match="no HIP device"):
+        Model()
+    with pytest.raises(ValueError):
+        Model("/nonexistent/model.bin")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "basic_pitch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "bp_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_window_and_unwrap_mirror_reference(clip_22k):
+    from basic_pitch_amd import inference as inf
+
+    hop = inf.AUDIO_N_SAMPLES - 30 * inf.FFT_HOP
+    wins = list(inf.window_audio_file(clip_22k, hop))
+    assert len(wins) == 6  # tests/test_inference.py:168
+    for w, times in wins:
+        assert w.shape == (43844, 1) and times["start"] <= times["end"]
+    assert np.array_equal(clip_22k[:43844], wins[0][0][:, 0])
+    got = list(inf.get_audio_input(os.path.join(GOLDEN, "vocadito_10.wav"), 30 * 256, hop))
+    assert len(got) == 6 and got[0][2] == 200607 and got[0][0].shape == (1, 43844, 1)
+    ow, n = O.window_track(clip_22k)
+    assert np.array_equal(np.concatenate([g[0][:, :, 0] for g in got]), ow)
+    # unwrap: same rows as the oracle's restatement
+    rng = np.random.default_rng(0)
+    out = rng.random((6, 172, 88)).astype(np.float32)
+    a = inf.unwrap_output(out, 200607, 30, hop)
+    b = O.unwrap_output(out, 200607)
+    assert a.shape == (787, 88) and np.array_equal(a, b)
+    assert inf.unwrap_output(out[0], 200607, 30, hop) is None  # rank != 3 (inference.py:264-265)
+
+
+def _write_wav(path, data, sr, sampwidth):
+    with wave.open(path, "wb") as w:
+        w.setnchannels(data.shape[1])
+        w.setsampwidth(sampwidth)
+        w.setframerate(sr)
+        w.writeframes(data.tobytes())
+
+
+def test_wav_reader_and_resampler(tmp_path):
+    from basic_pitch_amd import audio
+
+    sr = 44100
+    t = np.arange(sr) / sr
+    sig = 0.5 * np.sin(2 * np.pi * 440 * t)
+    st = np.stack([sig, 0.5 * sig], axis=1)
+    p16 = str(tmp_path / "a16.wav")
+    _write_wav(p16, (st * 32767).astype("<i2"), sr, 2)
+    x, fs = audio.read_wav(p16)
+    assert fs == sr and x.shape == (sr, 2) and np.abs(x[:, 0] - sig).max() < 1e-4
+    y, fs2 = audio.load(p16)
+    assert fs2 == 22050 and y.dtype == np.float32 and y.shape == (22050,)
+    ref = 0.75 * 0.5 * np.sin(2 * np.pi * 440 * np.arange(22050) / 22050)
+    assert np.abs(y[200:-200] - ref[200:-200]).max() < 2e-3
+    p32 = str(tmp_path / "a32.wav")
+    _write_wav(p32, (st * (2**31 - 1)).astype("<i4"), sr, 4)
+    x32, _ = audio.read_wav(p32)
+    assert np.abs(x32[:, 0] - sig).max() < 1e-6
+    # 24-bit
+    v = (st[:, :1] * (2**23 - 1)).astype(np.int32)
+    b = np.zeros((v.shape[0], 3), np.uint8)
+    b[:, 0], b[:, 1], b[:, 2] = v[:, 0] & 255, (v[:, 0] >> 8) & 255, (v[:, 0] >> 16) & 255
+    p24 = str(tmp_path / "a24.wav")
+    with wave.open(p24, "wb") as w:
+        w.setnchannels(1), w.setsampwidth(3), w.setframerate(sr), w.writeframes(b.tobytes())
+    x24, _ = audio.read_wav(p24)
+    assert np.abs(x24[:, 0] - sig).max() < 1e-6
+    assert abs(audio.get_duration(p16) - 1.0) < 1e-9
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.wav").write_bytes(b"nope")
+        audio.read_wav(str(tmp_path / "bad.wav"))
+
+
+def test_golden_clip_ingest(clip_22k):
+    assert clip_22k.dtype == np.float32 and np.abs(clip_22k).max() <= 1.0
+
+
+def test_shard_planning():
+    from basic_pitch_amd.sharding import plan_shards, shard_imbalance, split_windows
+
+    costs = [3_969_000] * 1000  # BASELINE.json configs[2]: 1000 equal 3-minute tracks over 8 GPUs
+    shards = plan_shards(costs, 8)
+    assert sorted(i for s in shards for i in s) == list(range(1000))
+    assert {len(s) for s in shards} == {125}
+    rng = np.random.default_rng(1)
+    ragged = rng.integers(10_000, 10_000_000, 333).tolist()
+    sh = plan_shards(ragged, 8)
+    assert sorted(i for s in sh for i in s) == list(range(333))
+    assert shard_imbalance(ragged, sh) < 1.02
+    assert plan_shards([], 4) == [[], [], [], []]
+    assert plan_shards([5.0], 2) == [[0], []]
+    assert split_windows(110, 8) == [(0, 14), (14, 28), (28, 42), (42, 56), (56, 70), (70, 84), (84, 97), (97, 110)]
+    with pytest.raises(ValueError):
+        plan_shards([1], 0)
