@@ -21,8 +21,10 @@ void launch_window_track(const float* samples, int64_t n_samples, int64_t first_
                          float* audio, hipStream_t s);
 void launch_unwrap(const float* win_out, int n_freq, int64_t first_window, int n_windows,
                    int64_t total_rows, float* out, hipStream_t s);
+size_t filterbank_scratch_floats(int n_windows);
 void launch_filterbank(const float* audio, const float* pyr, const float* bfrag, const float* sqrt_len,
-                       float* lp, int* mm, int n_windows, LogConsts kc, int n_cu, hipStream_t s);
+                       float* lp, int* mm, float* scratch, int n_windows, LogConsts kc, int n_cu,
+                       hipStream_t s);
 void launch_contour1(const float* lp, const int* mm, const float* bfrag, const float* bias, float* c1,
                      int n_windows, LogConsts kc, int n_cu, hipStream_t s);
 void launch_onset1(const float* lp, const int* mm, const float* bfrag, const float* bias, float* o1,
@@ -138,6 +140,8 @@ struct bp_context {
   float *audio = nullptr, *pyr = nullptr, *lp = nullptr, *c1 = nullptr, *contour = nullptr, *n1 = nullptr,
         *note = nullptr, *o1 = nullptr, *onset = nullptr;
   int* mm = nullptr;
+  float* fb_scratch = nullptr;  // filterbank partial extrema (grow-only; >= cap windows)
+  int64_t fb_scratch_windows = 0;
   // track path staging (grow-only)
   float* track = nullptr;
   int64_t track_cap = 0;
@@ -266,7 +270,7 @@ int free_all(bp_handle h) {
   float* ptrs[] = {h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
-                   h->track_out};
+                   h->track_out, h->fb_scratch};
   for (float* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->mm) (void)hipFree(h->mm);
@@ -274,6 +278,16 @@ int free_all(bp_handle h) {
     for (auto& row : h->ev)
       for (auto& e : row) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  return BP_OK;
+}
+
+int ensure_fb_scratch(bp_handle h, int64_t n) {
+  if (n <= h->fb_scratch_windows) return BP_OK;
+  if (h->fb_scratch) BP_HIP(hipFree(h->fb_scratch));
+  h->fb_scratch = nullptr;
+  h->fb_scratch_windows = 0;
+  BP_HIP(hipMalloc(&h->fb_scratch, filterbank_scratch_floats((int)n) * sizeof(float)));
+  h->fb_scratch_windows = n;
   return BP_OK;
 }
 
@@ -287,7 +301,8 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
   if (timing) BP_HIP(hipEventRecord(ev[e++], s));
   launch_pyramid(audio_dev, h->pyr, h->d_lowpass, n, s);
   if (timing) BP_HIP(hipEventRecord(ev[e++], s));
-  launch_filterbank(audio_dev, h->pyr, h->d_fb_bfrag, h->d_sqrt_len, h->lp, h->mm, n, h->kc, h->n_cu, s);
+  launch_filterbank(audio_dev, h->pyr, h->d_fb_bfrag, h->d_sqrt_len, h->lp, h->mm, h->fb_scratch, n, h->kc,
+                    h->n_cu, s);
   if (timing) BP_HIP(hipEventRecord(ev[e++], s));
   launch_contour1(h->lp, h->mm, h->d_c1_bfrag, h->d_c1_bias, h->c1, n, h->kc, h->n_cu, s);
   if (timing) BP_HIP(hipEventRecord(ev[e++], s));
@@ -427,6 +442,7 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       return fail(BP_ERR_OUT_OF_MEMORY);
     }
   }
+  if ((rc = ensure_fb_scratch(h, cap))) return fail(rc);
   if (flags & BP_FLAG_STAGE_TIMING) {
     for (auto& row : h->ev)
       for (auto& e : row)
@@ -638,8 +654,12 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
       if ((ok = need(bf->audio) && need(bf->pyr))) launch_pyramid(bf->audio, bf->pyr, h->d_lowpass, n, s);
       break;
     case BP_STAGE_FILTERBANK:
-      if ((ok = need(bf->audio) && need(bf->pyr) && need(bf->lp) && need(bf->mm)))
-        launch_filterbank(bf->audio, bf->pyr, h->d_fb_bfrag, h->d_sqrt_len, bf->lp, bf->mm, n, h->kc, h->n_cu, s);
+      if ((ok = need(bf->audio) && need(bf->pyr) && need(bf->lp) && need(bf->mm))) {
+        int rc = ensure_fb_scratch(h, n);
+        if (rc) return rc;
+        launch_filterbank(bf->audio, bf->pyr, h->d_fb_bfrag, h->d_sqrt_len, bf->lp, bf->mm, h->fb_scratch, n,
+                          h->kc, h->n_cu, s);
+      }
       break;
     case BP_STAGE_CONTOUR1:
       if ((ok = need(bf->lp) && need(bf->mm) && need(bf->c1)))

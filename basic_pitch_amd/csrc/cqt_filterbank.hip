@@ -1,5 +1,6 @@
 // CQT filterbank: per pyramid level, 172 frames x 36 complex Hann-windowed kernels, then
-// magnitude * sqrt(length), log-power, and the per-window min / max of the log-power.
+// magnitude * sqrt(length), log-power, and the per-window min / max of the log-power (partial
+// extrema per tile, folded by a one-wave-per-window reduction: no atomics).
 //
 // Reference behaviour (spotify/basic-pitch v0.4.0):
 //   basic_pitch/layers/nnaudio.py:216-256  get_cqt_complex: reflect-pad 128, conv1d(real), -conv1d(imag),
@@ -89,7 +90,7 @@ __device__ __forceinline__ void fb_role_compute(const float* __restrict__ sig_ld
 template <int LEVEL>
 __global__ __launch_bounds__(kFbThreads) void cqt_filterbank_kernel(
     const float* __restrict__ sig, int64_t sig_stride, const float* __restrict__ bfrag,
-    const float* __restrict__ sqrt_len, float* __restrict__ lp, int* __restrict__ mm, int n_windows,
+    const float* __restrict__ sqrt_len, float* __restrict__ lp, float2* __restrict__ mmp, int n_windows,
     LogConsts kc) {
   constexpr int HOP = 256 >> LEVEL;
   constexpr int PADH = fb_pad(HOP);
@@ -167,49 +168,67 @@ __global__ __launch_bounds__(kFbThreads) void cqt_filterbank_kernel(
       vmin = fminf(vmin, __shfl_xor(vmin, o));
       vmax = fmaxf(vmax, __shfl_xor(vmax, o));
     }
-    if (lane == 0 && vmin <= vmax) {
-      atomicMin(mm + 2 * b, f2ord(vmin));
-      atomicMax(mm + 2 * b + 1, f2ord(vmax));
-    }
+    // per-(window, level, tile, wave) partial extrema; mm_reduce_kernel folds the 396 of a window.
+    // (No atomics: 22 k same-line L2 atomics per level serialise; min/max are order-free anyway.)
+    if (lane == 0)
+      mmp[(((int64_t)b * kOctaves + LEVEL) * kFbTilesPerLevel + t0 / kFbTileFrames) * 4 + role] =
+          make_float2(vmin, vmax);
     // the next iteration's staging barrier also orders exch reuse
   }
 }
 
-__global__ void mm_init_kernel(int* __restrict__ mm, int n_windows) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_windows) {
-    mm[2 * i] = 0x7fffffff;
-    mm[2 * i + 1] = (int)0x80000000;
+constexpr int kMmPartials = kOctaves * kFbTilesPerLevel * 4;  // 396 per window
+
+// one wave per window: fold the partial extrema into mm[b] = (ord(min), ord(max))
+__global__ __launch_bounds__(64) void mm_reduce_kernel(const float2* __restrict__ mmp,
+                                                       int* __restrict__ mm) {
+  const int b = blockIdx.x;
+  float vmin = __int_as_float(0x7f800000), vmax = -__int_as_float(0x7f800000);
+  for (int i = threadIdx.x; i < kMmPartials; i += 64) {
+    const float2 p = mmp[(int64_t)b * kMmPartials + i];
+    vmin = fminf(vmin, p.x);
+    vmax = fmaxf(vmax, p.y);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    vmin = fminf(vmin, __shfl_xor(vmin, o));
+    vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+  }
+  if (threadIdx.x == 0) {
+    mm[2 * b] = f2ord(vmin);
+    mm[2 * b + 1] = f2ord(vmax);
   }
 }
 
 template <int LEVEL>
 static void launch_fb_level(const float* audio, const float* pyr, const float* bfrag,
-                            const float* sqrt_len, float* lp, int* mm, int n_windows, LogConsts kc,
+                            const float* sqrt_len, float* lp, float2* mmp, int n_windows, LogConsts kc,
                             int grid, hipStream_t stream) {
   const float* sig = (LEVEL == 0) ? audio : pyr + pyr_off(LEVEL);
   const int64_t stride = (LEVEL == 0) ? kAudioN : kPyrStride;
   const int items = n_windows * kFbTilesPerLevel;
   const int g = items < grid ? items : grid;
   hipLaunchKernelGGL(cqt_filterbank_kernel<LEVEL>, dim3(g), dim3(kFbThreads), 0, stream, sig, stride,
-                     bfrag, sqrt_len, lp, mm, n_windows, kc);
+                     bfrag, sqrt_len, lp, mmp, n_windows, kc);
 }
 
+size_t filterbank_scratch_floats(int n_windows) { return (size_t)n_windows * kMmPartials * 2; }
+
 void launch_filterbank(const float* audio, const float* pyr, const float* bfrag,
-                       const float* sqrt_len, float* lp, int* mm, int n_windows, LogConsts kc,
-                       int n_cu, hipStream_t stream) {
-  hipLaunchKernelGGL(mm_init_kernel, dim3((n_windows + 255) / 256), dim3(256), 0, stream, mm,
-                     n_windows);
+                       const float* sqrt_len, float* lp, int* mm, float* scratch, int n_windows,
+                       LogConsts kc, int n_cu, hipStream_t stream) {
+  float2* mmp = reinterpret_cast<float2*>(scratch);
   const int grid = n_cu * 4;
-  launch_fb_level<0>(audio, pyr, bfrag, sqrt_len, lp, mm, n_windows, kc, grid, stream);
-  launch_fb_level<1>(audio, pyr, bfrag, sqrt_len, lp, mm, n_windows, kc, grid, stream);
-  launch_fb_level<2>(audio, pyr, bfrag, sqrt_len, lp, mm, n_windows, kc, grid, stream);
-  launch_fb_level<3>(audio, pyr, bfrag, sqrt_len, lp, mm, n_windows, kc, grid, stream);
-  launch_fb_level<4>(audio, pyr, bfrag, sqrt_len, lp, mm, n_windows, kc, grid, stream);
-  launch_fb_level<5>(audio, pyr, bfrag, sqrt_len, lp, mm, n_windows, kc, grid, stream);
-  launch_fb_level<6>(audio, pyr, bfrag, sqrt_len, lp, mm, n_windows, kc, grid, stream);
-  launch_fb_level<7>(audio, pyr, bfrag, sqrt_len, lp, mm, n_windows, kc, grid, stream);
-  launch_fb_level<8>(audio, pyr, bfrag, sqrt_len, lp, mm, n_windows, kc, grid, stream);
+  launch_fb_level<0>(audio, pyr, bfrag, sqrt_len, lp, mmp, n_windows, kc, grid, stream);
+  launch_fb_level<1>(audio, pyr, bfrag, sqrt_len, lp, mmp, n_windows, kc, grid, stream);
+  launch_fb_level<2>(audio, pyr, bfrag, sqrt_len, lp, mmp, n_windows, kc, grid, stream);
+  launch_fb_level<3>(audio, pyr, bfrag, sqrt_len, lp, mmp, n_windows, kc, grid, stream);
+  launch_fb_level<4>(audio, pyr, bfrag, sqrt_len, lp, mmp, n_windows, kc, grid, stream);
+  launch_fb_level<5>(audio, pyr, bfrag, sqrt_len, lp, mmp, n_windows, kc, grid, stream);
+  launch_fb_level<6>(audio, pyr, bfrag, sqrt_len, lp, mmp, n_windows, kc, grid, stream);
+  launch_fb_level<7>(audio, pyr, bfrag, sqrt_len, lp, mmp, n_windows, kc, grid, stream);
+  launch_fb_level<8>(audio, pyr, bfrag, sqrt_len, lp, mmp, n_windows, kc, grid, stream);
+  hipLaunchKernelGGL(mm_reduce_kernel, dim3(n_windows), dim3(64), 0, stream, mmp, mm);
 }
 
 }  // namespace bp
