@@ -15,6 +15,7 @@ BP_OK = 0
 BP_MEM_HOST = 0
 BP_MEM_DEVICE = 1
 BP_FLAG_STAGE_TIMING = 1
+BP_FLAG_F32_MFMA = 2
 BP_N_STAGES = 8
 BP_PYR_STRIDE = 43712
 

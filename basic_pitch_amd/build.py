@@ -21,6 +21,7 @@ SOURCES = [
     "cqt_pyramid.hip",
     "cqt_filterbank.hip",
     "conv_contour1.hip",
+    "conv_contour1_f16.hip",
     "conv_stride3.hip",
     "conv_heads.hip",
     "note_decode.cpp",

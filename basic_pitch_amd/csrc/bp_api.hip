@@ -27,6 +27,8 @@ void launch_filterbank(const float* audio, const float* pyr, const float* bfrag,
                        hipStream_t s);
 void launch_contour1(const float* lp, const int* mm, const float* bfrag, const float* bias, float* c1,
                      int n_windows, LogConsts kc, int n_cu, hipStream_t s);
+void launch_contour1_f16(const float* lp, const int* mm, const void* bfrag, const float* bias, float* c1,
+                         int n_windows, LogConsts kc, int n_cu, hipStream_t s);
 void launch_onset1(const float* lp, const int* mm, const float* bfrag, const float* bias, float* o1,
                    int n_windows, LogConsts kc, int n_cu, hipStream_t s);
 void launch_note1(const float* contour, const float* bfrag, const float* bias, float* n1, int n_windows,
@@ -133,6 +135,7 @@ struct bp_context {
   float b_contour2 = 0, b_note2 = 0, b_onset2 = 0;
   // device constants
   float *d_lowpass = nullptr, *d_sqrt_len = nullptr, *d_fb_bfrag = nullptr;
+  float* d_c1h_bfrag = nullptr;  // f16 hi/lo B fragments of the split-precision contour1 (raw bytes)
   float *d_c1_bfrag = nullptr, *d_c1_bias = nullptr, *d_o1_bfrag = nullptr, *d_o1_bias = nullptr;
   float *d_n1_bfrag = nullptr, *d_n1_bias = nullptr, *d_w_contour2 = nullptr, *d_w_note2 = nullptr,
         *d_w_onset2 = nullptr;
@@ -228,6 +231,79 @@ bool pack_filterbank(const Tensor* re, const Tensor* im, std::vector<float>& out
   return true;
 }
 
+// IEEE binary16 <-> binary32 on the host (round to nearest even; inputs here are |x| < 8, no inf/nan)
+uint16_t f32_to_f16(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  const int32_t exp = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+  uint32_t man = x & 0x7fffffu;
+  if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));
+  if (exp >= 31) return (uint16_t)(sign | 0x7c00u);
+  if (exp <= 0) {
+    if (exp < -10) return (uint16_t)sign;
+    man |= 0x800000u;
+    const int shift = 14 - exp;  // 14..24
+    uint32_t half = man >> shift;
+    const uint32_t rem = man & ((1u << shift) - 1), mid = 1u << (shift - 1);
+    if (rem > mid || (rem == mid && (half & 1))) ++half;
+    return (uint16_t)(sign | half);
+  }
+  uint32_t half = ((uint32_t)exp << 10) | (man >> 13);
+  const uint32_t rem = man & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (half & 1))) ++half;  // may carry into the exponent: correct
+  return (uint16_t)(sign | half);
+}
+
+float f16_to_f32(uint16_t hv) {
+  const uint32_t sign = (uint32_t)(hv & 0x8000u) << 16;
+  uint32_t exp = (hv >> 10) & 0x1f, man = hv & 0x3ffu, x;
+  if (exp == 0) {
+    if (man == 0) {
+      x = sign;
+    } else {
+      int e = -1;
+      do {
+        ++e;
+        man <<= 1;
+      } while (!(man & 0x400u));
+      x = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
+    }
+  } else if (exp == 31) {
+    x = sign | 0x7f800000u | (man << 13);
+  } else {
+    x = sign | ((exp - 15 + 127) << 23) | (man << 13);
+  }
+  float f;
+  std::memcpy(&f, &x, 4);
+  return f;
+}
+
+// split-precision contour conv1 B fragments (conv_contour1_f16.hip):
+// [4 waves][16 k-steps][hi|lo][64 lanes][8 channels] f16; k-step = (frame dt, tap pair ep), lane ->
+// (tap parity h = lane>>5, column n = lane&31 = out channel o*4 + bin j); value W[o][c][dt][2ep+h-j].
+void pack_contour1_f16(const Tensor* w, std::vector<uint16_t>& out) {
+  out.assign((size_t)4 * 16 * 2 * 64 * 8, 0);
+  for (int wave = 0; wave < 4; ++wave)
+    for (int s = 0; s < 16; ++s) {
+      const int step = wave * 16 + s;
+      if (step >= 63) continue;
+      const int dt = step / 21, ep = step % 21;
+      for (int lane = 0; lane < 64; ++lane) {
+        const int hh = lane >> 5, n = lane & 31, o = n >> 2, jj = n & 3;
+        const int df = 2 * ep + hh - jj;
+        for (int c = 0; c < 8; ++c) {
+          float v = 0.f;
+          if (df >= 0 && df < 39) v = w->data[((o * 8 + c) * 3 + dt) * 39 + df];
+          const uint16_t hi = f32_to_f16(v);
+          const uint16_t lo = f32_to_f16(v - f16_to_f32(hi));
+          out[((((size_t)wave * 16 + s) * 2 + 0) * 64 + lane) * 8 + c] = hi;
+          out[((((size_t)wave * 16 + s) * 2 + 1) * 64 + lane) * 8 + c] = lo;
+        }
+      }
+    }
+}
+
 // contour conv1 Toeplitz B fragments [4 waves][126][64] (conv_contour1.hip).
 void pack_contour1(const Tensor* w, std::vector<float>& out) {
   static const int chan[4][2] = {{0, 1}, {2, 4}, {5, 3}, {6, 7}};
@@ -267,7 +343,7 @@ void pack_note1(const Tensor* w, std::vector<float>& out) {
 }
 
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_c1h_bfrag, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->fb_scratch};
@@ -304,7 +380,10 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
   launch_filterbank(audio_dev, h->pyr, h->d_fb_bfrag, h->d_sqrt_len, h->lp, h->mm, h->fb_scratch, n, h->kc,
                     h->n_cu, s);
   if (timing) BP_HIP(hipEventRecord(ev[e++], s));
-  launch_contour1(h->lp, h->mm, h->d_c1_bfrag, h->d_c1_bias, h->c1, n, h->kc, h->n_cu, s);
+  if (h->flags & BP_FLAG_F32_MFMA)
+    launch_contour1(h->lp, h->mm, h->d_c1_bfrag, h->d_c1_bias, h->c1, n, h->kc, h->n_cu, s);
+  else
+    launch_contour1_f16(h->lp, h->mm, h->d_c1h_bfrag, h->d_c1_bias, h->c1, n, h->kc, h->n_cu, s);
   if (timing) BP_HIP(hipEventRecord(ev[e++], s));
   launch_contour2(h->c1, h->d_w_contour2, h->b_contour2, contour_dev, n, s);
   if (timing) BP_HIP(hipEventRecord(ev[e++], s));
@@ -417,6 +496,13 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     h->stream = h->own_stream;
   }
   std::vector<float> c1f, o1f, n1f;
+  {
+    std::vector<uint16_t> c1h;
+    pack_contour1_f16(c1w, c1h);
+    std::vector<float> raw(c1h.size() / 2);
+    std::memcpy(raw.data(), c1h.data(), c1h.size() * 2);
+    if ((rc = upload(h, raw, &h->d_c1h_bfrag))) return fail(rc);
+  }
   pack_contour1(c1w, c1f);
   pack_onset1(o1w, o1f);
   pack_note1(n1w, n1f);
@@ -662,8 +748,12 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
       }
       break;
     case BP_STAGE_CONTOUR1:
-      if ((ok = need(bf->lp) && need(bf->mm) && need(bf->c1)))
-        launch_contour1(bf->lp, bf->mm, h->d_c1_bfrag, h->d_c1_bias, bf->c1, n, h->kc, h->n_cu, s);
+      if ((ok = need(bf->lp) && need(bf->mm) && need(bf->c1))) {
+        if (h->flags & BP_FLAG_F32_MFMA)
+          launch_contour1(bf->lp, bf->mm, h->d_c1_bfrag, h->d_c1_bias, bf->c1, n, h->kc, h->n_cu, s);
+        else
+          launch_contour1_f16(bf->lp, bf->mm, h->d_c1h_bfrag, h->d_c1_bias, bf->c1, n, h->kc, h->n_cu, s);
+      }
       break;
     case BP_STAGE_CONTOUR2:
       if ((ok = need(bf->c1) && need(bf->contour)))

@@ -67,6 +67,7 @@ class Model:
         device: int = 0,
         max_windows: int = 256,
         stage_timing: bool = False,
+        exact_f32_mfma: bool = False,
     ):
         self.model_type = Model.MODEL_TYPES.MI355X_HIP
         self._lib = _native.load_library()
@@ -76,6 +77,8 @@ class Model:
         except OSError as e:
             raise ValueError(f"File {model_path} cannot be loaded: {e}") from e
         flags = _native.BP_FLAG_STAGE_TIMING if stage_timing else 0
+        if exact_f32_mfma:  # A/B reference: contour conv1 on the exact-f32 MFMA kernel
+            flags |= _native.BP_FLAG_F32_MFMA
         rc = self._lib.bp_create(blob, len(blob), int(device), flags, int(max_windows), C.byref(self._handle))
         if rc != _native.BP_OK:
             self._handle = C.c_void_p()

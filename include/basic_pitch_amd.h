@@ -60,6 +60,8 @@ typedef enum bp_mem_kind {
 
 /* bp_create flags */
 #define BP_FLAG_STAGE_TIMING 1u /* record HIP events around every stage; read with bp_get_stage_ms */
+#define BP_FLAG_F32_MFMA 2u     /* contour conv1 on the exact-f32 MFMA kernel instead of the default
+                                   f16 hi/lo split-operand kernel (fp32-class accuracy, ~4x faster) */
 
 /*
  * Weights blob ("BPAMDW01", little endian) — produced by tools/extract_weights.py from the

@@ -106,6 +106,28 @@ def test_stage_cnn(runner, cases, stage, ins, outs, key, tol):
     assert d <= tol * scale, (stage, d)
 
 
+def test_contour1_exact_f32_variant(cases):
+    """The exact-f32 MFMA kernel (BP_FLAG_F32_MFMA) and the default f16 hi/lo split-operand kernel
+    compute the same operator: both within 5e-5 of the fp32 oracle on c1 (values up to ~4.6), and the
+    split kernel is not further from the fp64 oracle than the f32 one by more than 2e-5."""
+    from basic_pitch_amd import Model
+    from stage_harness import StageRunner, ord_encode
+
+    x, r32, r64 = cases
+    n = x.shape[0]
+    feed = {"lp": r32["lp"], "mm": ord_encode(r32["minmax"])}
+    outs = {}
+    for name, exact in (("split", False), ("f32", True)):
+        m = Model(max_windows=8, exact_f32_mfma=exact)
+        outs[name] = StageRunner(m).run("contour1", n, feed, {"c1": ((n, 8, 172, 264), F32)})["c1"]
+        m.close()
+    for name, got in outs.items():
+        assert np.abs(got - r32["c1"]).max() <= 5e-5 * float(np.abs(r32["c1"]).max()), name
+    e_split = np.abs(outs["split"] - r64["c1"]).max()
+    e_f32 = np.abs(outs["f32"] - r64["c1"]).max()
+    assert e_split <= e_f32 + 2e-5, (e_split, e_f32)
+
+
 def _noise_aware(got, r32, r64, floor=1e-4, factor=4.0):
     """|hip - fp64| <= max(1e-4, 4 * |fp32 oracle - fp64|), per tensor.
 
@@ -186,8 +208,8 @@ def test_edge_cases():
     with pytest.raises(ValueError):
         m.predict(np.zeros((43844,), np.float32))
     z = m.predict(np.zeros((1, 43844), np.float32))
-    for k in z:
-        assert np.isfinite(z[k]).all() and np.ptp(z[k][0, 20:150, 10:70]) < 1e-6
+    for k in z:  # silent window: finite, and constant along time away from the window edges
+        assert np.isfinite(z[k]).all() and np.ptp(z[k][0, 20:150, :], axis=0).max() < 1e-6
     big = m.predict(np.full((1, 43844), 1.0, np.float32))  # DC input
     assert all(np.isfinite(v).all() for v in big.values())
     # tracks: empty, shorter than one hop, exactly one hop
