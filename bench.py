@@ -36,7 +36,11 @@ BATCH = 256
 FLOP_PER_WINDOW = 1_048_159_296
 BYTES_PER_WINDOW = 478_096               # fp32 I/O: 175,376 in + 302,720 out
 C1_FLOP_PER_WINDOW = 680_030_208         # contour conv1: 2*8*8*3*39*172*264 (models.py:241-250)
-F32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: dense f32 matrix peak
+F32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: dense f32 matrix peak (= f32 vector peak)
+F16_MFMA_PEAK_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
+# contour1_f16_kernel issues 3 f16 MFMAs (hi*hi, lo*hi, hi*lo) of 32x32x16 per k-step, 63 k-steps per
+# 32-position tile, 9 tiles per 4-frame slab, 43 slabs per window (conv_contour1_f16.hip)
+C1_F16_EXECUTED_FLOP_PER_WINDOW = 43 * 9 * 63 * 3 * (2 * 32 * 32 * 16)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -76,6 +80,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact-f32", action="store_true", help="contour conv1 on the exact-f32 MFMA kernel (A/B)")
     args = ap.parse_args()
 
     import torch
@@ -105,7 +110,7 @@ def main() -> None:
         "onset": torch.empty((B, 172, 88), device=dev),
         "contour": torch.empty((B, 172, 264), device=dev),
     }
-    model = Model(device=local_rank, max_windows=B, stage_timing=True)
+    model = Model(device=local_rank, max_windows=B, stage_timing=True, exact_f32_mfma=args.exact_f32)
 
     def step():
         model._predict_device(audio, out=out, sync=False)
@@ -140,6 +145,15 @@ def main() -> None:
         value = total_windows / elapsed
         c1_ms = stage["contour1"]
         achieved = C1_FLOP_PER_WINDOW * B / (c1_ms * 1e-3) / 1e12
+        if args.exact_f32:
+            c1_kernel = "contour1_kernel (Conv2D 8->8 3x39 + norm/BN/stack; exact-f32 MFMA 32x32x2)"
+            c1_peak = F32_MFMA_PEAK_TFLOPS
+            c1_exec = 355 * 504 * (2 * 32 * 32 * 2) * B / (c1_ms * 1e-3) / 1e12
+        else:
+            c1_kernel = ("contour1_f16_kernel (Conv2D 8->8 3x39 + norm/BN/stack; f16 MFMA 32x32x16 on hi/lo-split "
+                         "operands, fp32 accumulate)")
+            c1_peak = F16_MFMA_PEAK_TFLOPS
+            c1_exec = C1_F16_EXECUTED_FLOP_PER_WINDOW * B / (c1_ms * 1e-3) / 1e12
         line = {
             "metric": "audio windows/sec (2 s @ 22.05 kHz) end-to-end CQT+CNN",
             "value": value,
@@ -151,7 +165,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32",  # fp32 data and accumulation; contour conv1 multiplies f16 hi+lo operand pairs
             "data": "synthetic",
             "config": {
                 "workload": f"batch={B} synthetic uniform[-1,1) 2 s @ 22.05 kHz mono windows per GPU, fp32, "
@@ -160,13 +174,15 @@ def main() -> None:
                 "sharding": "independent windows per rank, no collective",
             },
             "roofline": {
-                "kernel": "contour1_kernel (Conv2D 8->8 3x39 + norm/BN/stack, f32 MFMA 32x32x2)",
+                "kernel": c1_kernel,
                 "bound": "mfma",
                 "achieved": achieved,
-                "peak": F32_MFMA_PEAK_TFLOPS,
+                "peak": c1_peak,
                 "unit": "TFLOP/s",
-                "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                "frac": achieved / c1_peak,
                 "traffic": None,
+                "executed_mfma_tflops": c1_exec,  # incl. the 3-product split and Toeplitz padding
+                "executed_frac": c1_exec / c1_peak,
                 "launch_ms": c1_ms,
                 "algorithmic_flop_per_launch": C1_FLOP_PER_WINDOW * B,
             },
