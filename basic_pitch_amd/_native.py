@@ -16,10 +16,14 @@ BP_MEM_HOST = 0
 BP_MEM_DEVICE = 1
 BP_FLAG_STAGE_TIMING = 1
 BP_FLAG_F32_MFMA = 2
-BP_N_STAGES = 8
+BP_N_STAGES = 11
+BP_Z_ROW = 312
 BP_PYR_STRIDE = 43712
 
-STAGE_NAMES = ["pyramid", "filterbank", "contour1", "contour2", "note1", "note2", "onset1", "onset2"]
+STAGE_NAMES = [
+    "pyramid", "filterbank", "contour1", "contour2", "note1", "note2", "onset1", "onset2",
+    "zpack", "note", "onset",
+]
 
 _ERR_NAMES = {
     -1: "BP_ERR_INVALID_ARG",
@@ -57,6 +61,7 @@ class bp_stage_buffers(C.Structure):
         ("note", C.c_void_p),
         ("o1", C.c_void_p),
         ("onset", C.c_void_p),
+        ("zp", C.c_void_p),
     ]
 
 

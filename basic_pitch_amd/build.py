@@ -24,6 +24,7 @@ SOURCES = [
     "conv_contour1_f16.hip",
     "conv_stride3.hip",
     "conv_heads.hip",
+    "conv_branch.hip",
     "note_decode.cpp",
 ]
 

@@ -39,6 +39,11 @@ void launch_note2(const float* n1, const float* wgt, float bias, float* note, in
                   hipStream_t s);
 void launch_onset2(const float* note, const float* o1, const float* wgt, float bias, float* onset,
                    int n_windows, hipStream_t s);
+void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc, hipStream_t s);
+void launch_note_branch(const float* contour, const void* wfrag, const float* wf32, float* note,
+                        int n_windows, int n_cu, hipStream_t s);
+void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32,
+                         float* onset, int n_windows, int n_cu, hipStream_t s);
 }  // namespace bp
 
 using namespace bp;
@@ -136,6 +141,9 @@ struct bp_context {
   // device constants
   float *d_lowpass = nullptr, *d_sqrt_len = nullptr, *d_fb_bfrag = nullptr;
   float* d_c1h_bfrag = nullptr;  // f16 hi/lo B fragments of the split-precision contour1 (raw bytes)
+  // fused branches (conv_branch.hip): f16 hi/lo A fragments (raw bytes) + {bias1[32], extra[9], bias2}
+  float *d_note_wfrag = nullptr, *d_note_wf32 = nullptr, *d_onset_wfrag = nullptr, *d_onset_wf32 = nullptr;
+  float* zp = nullptr;  // uint32 [cap][172][kZRow] pre-split z
   float *d_c1_bfrag = nullptr, *d_c1_bias = nullptr, *d_o1_bfrag = nullptr, *d_o1_bias = nullptr;
   float *d_n1_bfrag = nullptr, *d_n1_bias = nullptr, *d_w_contour2 = nullptr, *d_w_note2 = nullptr,
         *d_w_onset2 = nullptr;
@@ -154,6 +162,8 @@ struct bp_context {
   // stage timing: a ring of event sets, one per chunk, averaged by bp_get_stage_ms
   static constexpr int kTimedRing = 128;
   hipEvent_t ev[kTimedRing][BP_N_STAGES + 1] = {};
+  int seq[BP_N_STAGES] = {};  // stage id of the interval between ev[.][i] and ev[.][i+1]
+  int n_seq = 0;
   bool ev_valid = false;
   int64_t timed_chunks = 0;  // chunks recorded since the last bp_get_stage_ms
 };
@@ -342,8 +352,52 @@ void pack_note1(const Tensor* w, std::vector<float>& out) {
     }
 }
 
+
+void put_split(std::vector<uint16_t>& out, size_t hi_base, size_t lo_base, size_t idx, float v) {
+  const uint16_t hi = f32_to_f16(v);
+  out[hi_base + idx] = hi;
+  out[lo_base + idx] = f32_to_f16(v - f16_to_f32(hi));
+}
+
+// Fused branch A fragments (conv_branch.hip): [A1 hi: KS1*64][A1 lo: KS1*64][A2 hi: 2*64][A2 lo: 2*64] x 8 f16.
+// A1 lane (i = out channel = lane & 31, h = lane >> 5), element e: conv1 weight of k = 8h + e of step s.
+// A2 lane (i = conv2 tap, h), element e of step s2: conv2 weight of the channel that C-register
+// 8*s2 + e of half h holds: (e & 3) + 16*s2 + 8*(e >> 2) + 4h.
+void pack_branch(int ks1, const Tensor* w1, const Tensor* w2, bool onset, std::vector<uint16_t>& out) {
+  const size_t a1h = 0, a1l = (size_t)ks1 * 64 * 8, a2h = 2 * a1l, a2l = a2h + 2 * 64 * 8;
+  out.assign(a2l + 2 * 64 * 8, 0);
+  const int kh2 = onset ? 3 : 7;
+  for (int s = 0; s < ks1; ++s)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int e = 0; e < 8; ++e) {
+        const int i = lane & 31, hh = lane >> 5;
+        float v = 0.f;
+        if (onset) {  // k-step = tap pair of the 5x5 window x 8 stack channels (models.py:295-304)
+          const int q = 2 * s + hh;
+          if (q < 25) v = w1->data[((i * 8 + e) * 5 + q / 5) * 5 + q % 5];
+        } else {  // k-step = frame-tap pair x 8 adjacent bins, 7 used (models.py:270-278)
+          const int dt = 2 * s + hh;
+          if (dt < 7 && e < 7) v = w1->data[(i * 7 + dt) * 7 + e];
+        }
+        put_split(out, a1h, a1l, ((size_t)s * 64 + lane) * 8 + e, v);
+      }
+  for (int s2 = 0; s2 < 2; ++s2)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int e = 0; e < 8; ++e) {
+        const int tap = lane & 31, hh = lane >> 5;
+        const int ch = (e & 3) + 16 * s2 + 8 * (e >> 2) + 4 * hh;
+        float v = 0.f;
+        if (tap < kh2 * 3) {
+          const int dt = tap / 3, dw = tap % 3;
+          v = onset ? w2->data[((1 + ch) * 3 + dt) * 3 + dw]   // channel 0 of the concat is the note map
+                    : w2->data[(ch * 7 + dt) * 3 + dw];
+        }
+        put_split(out, a2h, a2l, ((size_t)s2 * 64 + lane) * 8 + e, v);
+      }
+}
+
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_c1h_bfrag, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->zp, h->d_c1h_bfrag, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->fb_scratch};
@@ -374,28 +428,49 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
   const bool timing = (h->flags & BP_FLAG_STAGE_TIMING) != 0;
   int e = 0;
   hipEvent_t* ev = h->ev[h->timed_chunks % bp_context::kTimedRing];
-  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
+  if (timing) BP_HIP(hipEventRecord(ev[0], s));
+  // closes the interval of stage `id` (the kernels launched since the previous mark)
+#define BP_MARK(id)                                \
+  do {                                             \
+    if (timing) {                                  \
+      h->seq[e] = (id);                            \
+      BP_HIP(hipEventRecord(ev[++e], s));          \
+    }                                              \
+  } while (0)
   launch_pyramid(audio_dev, h->pyr, h->d_lowpass, n, s);
-  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
+  BP_MARK(BP_STAGE_PYRAMID);
   launch_filterbank(audio_dev, h->pyr, h->d_fb_bfrag, h->d_sqrt_len, h->lp, h->mm, h->fb_scratch, n, h->kc,
                     h->n_cu, s);
-  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
-  if (h->flags & BP_FLAG_F32_MFMA)
+  BP_MARK(BP_STAGE_FILTERBANK);
+  if (h->flags & BP_FLAG_F32_MFMA) {
     launch_contour1(h->lp, h->mm, h->d_c1_bfrag, h->d_c1_bias, h->c1, n, h->kc, h->n_cu, s);
-  else
+    BP_MARK(BP_STAGE_CONTOUR1);
+    launch_contour2(h->c1, h->d_w_contour2, h->b_contour2, contour_dev, n, s);
+    BP_MARK(BP_STAGE_CONTOUR2);
+    launch_note1(contour_dev, h->d_n1_bfrag, h->d_n1_bias, h->n1, n, h->n_cu, s);
+    BP_MARK(BP_STAGE_NOTE1);
+    launch_note2(h->n1, h->d_w_note2, h->b_note2, note_dev, n, s);
+    BP_MARK(BP_STAGE_NOTE2);
+    launch_onset1(h->lp, h->mm, h->d_o1_bfrag, h->d_o1_bias, h->o1, n, h->kc, h->n_cu, s);
+    BP_MARK(BP_STAGE_ONSET1);
+    launch_onset2(note_dev, h->o1, h->d_w_onset2, h->b_onset2, onset_dev, n, s);
+    BP_MARK(BP_STAGE_ONSET2);
+  } else {
+    launch_zpack(h->lp, h->mm, reinterpret_cast<uint32_t*>(h->zp), n, h->kc, s);
+    BP_MARK(BP_STAGE_ZPACK);
     launch_contour1_f16(h->lp, h->mm, h->d_c1h_bfrag, h->d_c1_bias, h->c1, n, h->kc, h->n_cu, s);
-  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
-  launch_contour2(h->c1, h->d_w_contour2, h->b_contour2, contour_dev, n, s);
-  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
-  launch_note1(contour_dev, h->d_n1_bfrag, h->d_n1_bias, h->n1, n, h->n_cu, s);
-  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
-  launch_note2(h->n1, h->d_w_note2, h->b_note2, note_dev, n, s);
-  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
-  launch_onset1(h->lp, h->mm, h->d_o1_bfrag, h->d_o1_bias, h->o1, n, h->kc, h->n_cu, s);
-  if (timing) BP_HIP(hipEventRecord(ev[e++], s));
-  launch_onset2(note_dev, h->o1, h->d_w_onset2, h->b_onset2, onset_dev, n, s);
+    BP_MARK(BP_STAGE_CONTOUR1);
+    launch_contour2(h->c1, h->d_w_contour2, h->b_contour2, contour_dev, n, s);
+    BP_MARK(BP_STAGE_CONTOUR2);
+    launch_note_branch(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, h->n_cu, s);
+    BP_MARK(BP_STAGE_NOTE);
+    launch_onset_branch(reinterpret_cast<const uint32_t*>(h->zp), note_dev, h->d_onset_wfrag, h->d_onset_wf32,
+                        onset_dev, n, h->n_cu, s);
+    BP_MARK(BP_STAGE_ONSET);
+  }
+#undef BP_MARK
   if (timing) {
-    BP_HIP(hipEventRecord(ev[e++], s));
+    h->n_seq = e;
     h->timed_chunks++;
   }
   BP_HIP(hipGetLastError());
@@ -503,6 +578,20 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     std::memcpy(raw.data(), c1h.data(), c1h.size() * 2);
     if ((rc = upload(h, raw, &h->d_c1h_bfrag))) return fail(rc);
   }
+  for (int br = 0; br < 2; ++br) {
+    std::vector<uint16_t> frag;
+    pack_branch(br ? 13 : 4, br ? o1w : n1w, br ? o2w : n2w, br == 1, frag);
+    std::vector<float> raw(frag.size() / 2), f32(42, 0.f);
+    std::memcpy(raw.data(), frag.data(), frag.size() * 2);
+    const Tensor* b1 = br ? o1b : n1b;
+    for (int i = 0; i < 32; ++i) f32[i] = b1->data[i];
+    if (br)
+      for (int i = 0; i < 9; ++i) f32[32 + i] = o2w->data[i];  // onset2 taps of concat channel 0 (the note map)
+    f32[41] = br ? o2b->data[0] : n2b->data[0];
+    if ((rc = upload(h, raw, br ? &h->d_onset_wfrag : &h->d_note_wfrag)) ||
+        (rc = upload(h, f32, br ? &h->d_onset_wf32 : &h->d_note_wf32)))
+      return fail(rc);
+  }
   pack_contour1(c1w, c1f);
   pack_onset1(o1w, o1f);
   pack_note1(n1w, n1f);
@@ -519,7 +608,7 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       (rc = alloc(h, &h->lp, cap * kFrames * kBins)) || (rc = alloc(h, &h->c1, cap * 8 * kPlaneC)) ||
       (rc = alloc(h, &h->contour, cap * kPlaneC)) || (rc = alloc(h, &h->n1, cap * 32 * kPlaneN)) ||
       (rc = alloc(h, &h->note, cap * kPlaneN)) || (rc = alloc(h, &h->o1, cap * 32 * kPlaneN)) ||
-      (rc = alloc(h, &h->onset, cap * kPlaneN)))
+      (rc = alloc(h, &h->onset, cap * kPlaneN)) || (rc = alloc(h, &h->zp, cap * kFrames * kZRow)))
     return fail(rc);
   {
     hipError_t e = hipMalloc(&h->mm, cap * 2 * sizeof(int));
@@ -710,10 +799,10 @@ int bp_get_stage_ms(bp_handle h, float* ms, int n) {
   const int64_t cnt = h->timed_chunks < bp_context::kTimedRing ? h->timed_chunks : bp_context::kTimedRing;
   double acc[BP_N_STAGES] = {0};
   for (int64_t c = 0; c < cnt; ++c) {
-    for (int i = 0; i < BP_N_STAGES; ++i) {
+    for (int i = 0; i < h->n_seq; ++i) {
       float t = 0.f;
       BP_HIP(hipEventElapsedTime(&t, h->ev[c][i], h->ev[c][i + 1]));
-      acc[i] += t;
+      acc[h->seq[i]] += t;
     }
   }
   for (int i = 0; i < BP_N_STAGES; ++i) ms[i] = (float)(acc[i] / (double)cnt);
@@ -773,6 +862,17 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
     case BP_STAGE_ONSET2:
       if ((ok = need(bf->note) && need(bf->o1) && need(bf->onset)))
         launch_onset2(bf->note, bf->o1, h->d_w_onset2, h->b_onset2, bf->onset, n, s);
+      break;
+    case BP_STAGE_ZPACK:
+      if ((ok = need(bf->lp) && need(bf->mm) && need(bf->zp))) launch_zpack(bf->lp, bf->mm, bf->zp, n, h->kc, s);
+      break;
+    case BP_STAGE_NOTE:
+      if ((ok = need(bf->contour) && need(bf->note)))
+        launch_note_branch(bf->contour, h->d_note_wfrag, h->d_note_wf32, bf->note, n, h->n_cu, s);
+      break;
+    case BP_STAGE_ONSET:
+      if ((ok = need(bf->zp) && need(bf->note) && need(bf->onset)))
+        launch_onset_branch(bf->zp, bf->note, h->d_onset_wfrag, h->d_onset_wf32, bf->onset, n, h->n_cu, s);
       break;
     default:
       h->err = "bp_run_stage: unknown stage";

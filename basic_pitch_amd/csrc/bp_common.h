@@ -17,6 +17,7 @@ constexpr int kTaps = 256;       // n_fft of the top-octave kernels / lowpass le
 constexpr int kPlaneC = kFrames * kFreqC;  // 45408
 constexpr int kPlaneN = kFrames * kFreqN;  // 15136
 constexpr int kPyrStride = 43712;
+constexpr int kZRow = 312;      // row stride (words) of the pre-split z tensor `zp` (309 bins + 3 zero words)
 
 // pyramid level k (1..8) lives at kPyrOff[k] inside a window's pyr row; level 0 is the audio itself
 __host__ __device__ constexpr int level_len(int k) {

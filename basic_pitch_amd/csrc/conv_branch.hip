@@ -1,0 +1,374 @@
+// Fused note branch and fused onset branch — split-precision matrix-core kernels (default path).
+//
+//   note  branch (basic_pitch/models.py:266-290): Conv2D 1->32, 7x7, strides (1,3), "same", ReLU on the
+//                sigmoid contour map, then Conv2D 32->1, (7,3), "same", sigmoid           -> note
+//   onset branch (basic_pitch/models.py:295-318): Conv2D 8->32, 5x5, strides (1,3), "same", folded BN,
+//                ReLU on the harmonic stack (nn.py:69-88), Concatenate([note, features]) (305),
+//                Conv2D 33->1, 3x3, "same", sigmoid                                      -> onset
+//
+// Both branches are "conv (many taps) -> 32 channels -> conv (few taps) -> 1 channel".  The 32-channel
+// intermediate (1.9 MB / window each way in the unfused kernels, conv_stride3.hip + conv_heads.hip) never
+// leaves the CU here:
+//
+//   1. conv1 runs as an implicit GEMM in TRANSPOSED form on v_mfma_f32_32x32x16_f16:
+//          C1[channel (32 rows)][pixel (32 cols)] = W1[channel][k] x patch[k][pixel]
+//      A = weights (resident in VGPRs for the whole kernel), B = one ds_read_b128 per lane from an LDS
+//      "image" whose 16-byte slots hold the 8 k-values a lane needs (note: 8 adjacent contour bins of one
+//      frame; onset: the 8 harmonic-stack channels of one bin).  Operands are split x = hi + lo (two
+//      f16), products hi*hi + lo*hi + hi*lo accumulate in fp32: fp32-class accuracy (see
+//      conv_contour1_f16.hip) at the f16 matrix rate.
+//   2. The C layout of a 32x32 MFMA (col = lane & 31, row = (r&3) + 8(r>>2) + 4(lane>>5)) is, up to a
+//      permutation of K that is folded into the packed conv2 weights, exactly the B-operand layout of the
+//      next MFMA.  So bias + ReLU + hi/lo split happen in registers and feed the "tap projection"
+//          P[tap (rows)][pixel] = W2[tap][channel] x relu(C1)[channel][pixel]          (K = 32 channels)
+//      with no data movement at all.
+//   3. conv2's spatial part is then only a shifted sum of P: per pixel KH2*3 adds instead of
+//      32*KH2*3 FMAs.  P goes through a per-wave LDS scratch; Q[row][dt][w] = sum_dw P[row][w+dw-1][dt,dw]
+//      is kept in a ring of rows, and out[t][w] = sigmoid(b + sum_dt Q[t+dt-PH2][dt][w]).
+//   4. A workgroup walks a time chunk of one window 4 conv1-rows at a time with ring buffers for the
+//      image and for Q: no halo recompute inside a chunk (two chunks per window -> 512 work items at
+//      B = 256; 2 workgroups per CU overlap one's staging with the other's MFMAs).
+//
+// Roofline: bound = f16 MFMA issue.  Algorithmic work per window: note 47.5 + 20.3 MFLOP, onset
+// 193.7 + 9.0 MFLOP.  HBM bytes per window: note 181,632 read + 60,544
+// written; onset 214,656 (zp) + 60,544 (note) read + 60,544 written.
+#include "bp_common.h"
+
+namespace bp {
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+constexpr int kBrThreads = 256;
+constexpr int kBrRows = 4;                               // conv1 rows per phase
+constexpr int kBrChunks = 2;                             // time chunks per window
+constexpr int kBrChunkFrames = kFrames / kBrChunks;      // 86
+constexpr int kBrTilesPerRow = 3;                        // 32-pixel tiles, 30 inner pixels each
+constexpr int kScrStride = 33;
+static_assert(kFrames % kBrChunks == 0, "chunks tile the window");
+static_assert(kBrTilesPerRow * 30 >= kFreqN, "tiles cover a row");
+
+struct BranchParams {
+  const uint4* wfrag;  // [A1 hi: KS1*64][A1 lo: KS1*64][A2 hi: 2*64][A2 lo: 2*64] x (8 x f16)
+  const float* wf32;   // bias1[32], extra[9] (onset: taps of the note channel), bias2
+  const void* src;     // note: contour f32 [n][172][264]; onset: zp u32 [n][172][kZRow]
+  const float* note;   // onset only: note posteriorgram [n][172][88]
+  float* out;          // [n][172][88]
+  int n_windows;
+};
+
+// ---- branch descriptions ----------------------------------------------------------------------
+struct NoteBr {
+  static constexpr bool kOnset = false;
+  static constexpr int KS1 = 4;             // conv1 k-steps: (frame-tap pair) x 8 adjacent bins (7 + 1 zero)
+  static constexpr int PH1 = 3;             // conv1 frame padding (ONNX pads [3,2,3,2])
+  static constexpr int ND = 8;              // frame offsets touched (dt = 7 is a zero-weight dummy)
+  static constexpr int KH2 = 7, PH2 = 3;    // conv2 frames
+  static constexpr int NT2 = KH2 * 3;       // conv2 taps
+  static constexpr int SLOTS = kFreqN;      // slot (row, w) = contour bins 3w-2 .. 3w+5
+  static constexpr int RING = kBrRows + 2 * PH1;
+  static constexpr int QRING = kBrRows + 2 * PH2;
+  static __device__ constexpr int d_of(int s, int h) { return 2 * s + h; }
+  static __device__ constexpr int x_of(int, int) { return 0; }
+  static __device__ __forceinline__ int lane_slot(int wc) { return wc; }
+};
+
+struct OnsetBr {
+  static constexpr bool kOnset = true;
+  static constexpr int KS1 = 13;            // conv1 k-steps: (tap pair of the 5x5 window) x 8 channels
+  static constexpr int PH1 = 2;             // ONNX pads [2,1,2,1]
+  static constexpr int ND = 6;              // tap 25 (dt = 5, dw = 0) is a zero-weight dummy
+  static constexpr int KH2 = 3, PH2 = 1;
+  static constexpr int NT2 = KH2 * 3;
+  static constexpr int SLOTS = kFreqC + 2;  // slot (row, s) = stack bin s-1, 8 channels; bins -1 and 264 zero
+  static constexpr int RING = kBrRows + 2 * PH1;
+  static constexpr int QRING = kBrRows + 2 * PH2;
+  static __device__ constexpr int d_of(int s, int h) { return (2 * s + h) / 5; }
+  static __device__ constexpr int x_of(int s, int h) { return (2 * s + h) % 5; }
+  static __device__ __forceinline__ int lane_slot(int wc) { return 3 * wc; }  // bin 3w+dw-1 -> slot 3w+dw
+};
+
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)(v - (float)hi);
+}
+
+// ---- image staging: `nrows` rows starting at `row_first` (absolute frame index, may be outside the window)
+template <class Br>
+__device__ __forceinline__ void stage_rows(const BranchParams& p, int b, int row_first, int nrows,
+                                           uint4* __restrict__ img_hi, uint4* __restrict__ img_lo, int wave,
+                                           int lane) {
+  for (int rr = wave; rr < nrows; rr += kBrThreads / 64) {
+    const int row = row_first + rr;
+    const bool rvalid = row >= 0 && row < kFrames;
+    const int ring = ((row + 64 * Br::RING) % Br::RING) * Br::SLOTS;
+    if constexpr (!Br::kOnset) {
+      const float* src = static_cast<const float*>(p.src) + ((int64_t)b * kFrames + (rvalid ? row : 0)) * kFreqC;
+      for (int w = lane; w < Br::SLOTS; w += 64) {
+        f16x8 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int bin = 3 * w + e - 2;
+          const bool ok = rvalid && bin >= 0 && bin < kFreqC;
+          const float v = ok ? src[ok ? bin : 0] : 0.0f;
+          _Float16 hi, lo;
+          split_f16(v, hi, lo);
+          vh[e] = hi;
+          vl[e] = lo;
+        }
+        img_hi[ring + w] = __builtin_bit_cast(uint4, vh);
+        img_lo[ring + w] = __builtin_bit_cast(uint4, vl);
+      }
+    } else {
+      const uint32_t* src =
+          static_cast<const uint32_t*>(p.src) + ((int64_t)b * kFrames + (rvalid ? row : 0)) * kZRow;
+      for (int sl = lane; sl < Br::SLOTS; sl += 64) {
+        const int f = sl - 1;
+        const bool inside = rvalid && f >= 0 && f < kFreqC;  // crop to 264 bins before "same" padding (nn.py:87)
+        uint32_t u[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int g = f + harm_shift(c);
+          const bool ok = inside && g >= 0 && g < kBins;
+          u[c] = ok ? src[ok ? g : 0] : 0u;
+        }
+        uint4 vh, vl;
+        vh.x = (u[0] & 0xffffu) | (u[1] << 16);
+        vh.y = (u[2] & 0xffffu) | (u[3] << 16);
+        vh.z = (u[4] & 0xffffu) | (u[5] << 16);
+        vh.w = (u[6] & 0xffffu) | (u[7] << 16);
+        vl.x = (u[0] >> 16) | (u[1] & 0xffff0000u);
+        vl.y = (u[2] >> 16) | (u[3] & 0xffff0000u);
+        vl.z = (u[4] >> 16) | (u[5] & 0xffff0000u);
+        vl.w = (u[6] >> 16) | (u[7] & 0xffff0000u);
+        img_hi[ring + sl] = vh;
+        img_lo[ring + sl] = vl;
+      }
+    }
+  }
+}
+
+template <class Br>
+__global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
+  constexpr int KS1 = Br::KS1, KH2 = Br::KH2, PH1 = Br::PH1, PH2 = Br::PH2, NT2 = Br::NT2;
+  __shared__ __attribute__((aligned(16))) uint4 img_hi[Br::RING * Br::SLOTS];
+  __shared__ __attribute__((aligned(16))) uint4 img_lo[Br::RING * Br::SLOTS];
+  __shared__ float qring[Br::QRING * KH2 * kFreqN];
+  __shared__ float scr_all[4 * NT2 * kScrStride];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  const int h = lane >> 5, li = lane & 31;
+  float* scr = scr_all + wave * (NT2 * kScrStride);
+
+  // resident A operands (weights) and biases
+  uint4 a1h[KS1], a1l[KS1], a2h[2], a2l[2];
+#pragma unroll
+  for (int s = 0; s < KS1; ++s) {
+    a1h[s] = p.wfrag[s * 64 + lane];
+    a1l[s] = p.wfrag[(KS1 + s) * 64 + lane];
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    a2h[s] = p.wfrag[(2 * KS1 + s) * 64 + lane];
+    a2l[s] = p.wfrag[(2 * KS1 + 2 + s) * 64 + lane];
+  }
+  float bias1[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bias1[r] = p.wf32[(r & 3) + 8 * (r >> 2) + 4 * h];
+  float extra[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) extra[i] = p.wf32[32 + i];
+  const float bias2 = p.wf32[41];
+
+  const int n_items = p.n_windows * kBrChunks;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int b = item / kBrChunks;
+    const int T0 = (item - b * kBrChunks) * kBrChunkFrames;
+    const int T1 = T0 + kBrChunkFrames;
+    const int n_phase = (T1 - T0 + 2 * PH2 + kBrRows - 1) / kBrRows;
+
+    __syncthreads();  // previous item finished with the rings
+    stage_rows<Br>(p, b, T0 - PH2 - PH1, Br::RING, img_hi, img_lo, wave, lane);
+    __syncthreads();
+
+    for (int ph = 0; ph < n_phase; ++ph) {
+      const int r0 = T0 - PH2 + kBrRows * ph;  // first conv1 row of this phase
+
+      // ---- conv1 + projection, 12 tiles: 4 rows x 3 overlapping 32-pixel tiles (30 inner pixels each)
+#pragma unroll 1
+      for (int j = 0; j < kBrTilesPerRow; ++j) {
+        const int tile = wave + 4 * j;
+        const int row = r0 + tile / kBrTilesPerRow;
+        const int wbase = (tile % kBrTilesPerRow) * 30 - 1;
+        const int w = wbase + li;
+        const bool wvalid = w >= 0 && w < kFreqN;
+        const int wc = w < 0 ? 0 : (w >= kFreqN ? kFreqN - 1 : w);
+        const bool rvalid = row >= 0 && row < kFrames;  // wave-uniform
+        float* qrow = qring + ((row + 64 * Br::QRING) % Br::QRING) * (KH2 * kFreqN);
+
+        if (rvalid) {
+          int rb[Br::ND];
+#pragma unroll
+          for (int d = 0; d < Br::ND; ++d) rb[d] = ((row - PH1 + d + 64 * Br::RING) % Br::RING) * Br::SLOTS;
+          const int lane_off = Br::lane_slot(wc);
+
+          f32x16 acc, accc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            acc[r] = 0.0f;
+            accc[r] = 0.0f;
+          }
+#pragma unroll
+          for (int s = 0; s < KS1; ++s) {
+            const int o0 = rb[Br::d_of(s, 0)] + Br::x_of(s, 0);
+            const int o1 = rb[Br::d_of(s, 1)] + Br::x_of(s, 1);
+            const int slot = lane_off + (h ? o1 : o0);
+            const f16x8 bh = __builtin_bit_cast(f16x8, img_hi[slot]);
+            const f16x8 bl = __builtin_bit_cast(f16x8, img_lo[slot]);
+            const f16x8 ah = __builtin_bit_cast(f16x8, a1h[s]);
+            const f16x8 al = __builtin_bit_cast(f16x8, a1l[s]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+            accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accc, 0, 0, 0);
+            accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accc, 0, 0, 0);
+          }
+
+          // bias + ReLU (+ zero padding of conv2 outside the row), split, and the tap projection
+          f16x8 b2h[2], b2l[2];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = fmaxf((acc[r] + accc[r]) + bias1[r], 0.0f);
+            v = wvalid ? v : 0.0f;
+            _Float16 hi, lo;
+            split_f16(v, hi, lo);
+            b2h[r >> 3][r & 7] = hi;
+            b2l[r >> 3][r & 7] = lo;
+          }
+          f32x16 pp, ppc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            pp[r] = 0.0f;
+            ppc[r] = 0.0f;
+          }
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, a2h[s]);
+            const f16x8 al = __builtin_bit_cast(f16x8, a2l[s]);
+            pp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b2h[s], pp, 0, 0, 0);
+            ppc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b2h[s], ppc, 0, 0, 0);
+            ppc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b2l[s], ppc, 0, 0, 0);
+          }
+          // P[tap][pixel] -> per-wave scratch (tap = C row)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int t0 = (r & 3) + 8 * (r >> 2);  // tap for h = 0; h = 1 adds 4
+            if (t0 >= NT2) continue;
+            const float v = pp[r] + ppc[r];
+            if (t0 + 4 < NT2) {
+              scr[(t0 + 4 * h) * kScrStride + li] = v;
+            } else if (h == 0) {
+              scr[t0 * kScrStride + li] = v;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          // Q[row][dt][w] = sum_dw P[w+dw-1][(dt,dw)]  (+ the note channel of the concat for the onset head)
+          const float* note_row = Br::kOnset ? p.note + ((int64_t)b * kFrames + row) * kFreqN : nullptr;
+          for (int idx = lane; idx < 30 * KH2; idx += 64) {
+            const int dt = idx / 30;
+            const int l2 = 1 + idx - 30 * dt;
+            const int wq = wbase + l2;
+            const float* sp = scr + (dt * 3) * kScrStride + l2;
+            float q = (sp[-1] + sp[kScrStride]) + sp[2 * kScrStride + 1];
+            if (wq < kFreqN) {
+              if constexpr (Br::kOnset) {
+                const float nl = wq > 0 ? note_row[wq - 1] : 0.0f;
+                const float nc = note_row[wq];
+                const float nr = wq + 1 < kFreqN ? note_row[wq + 1] : 0.0f;
+                q += (nl * extra[dt * 3] + nc * extra[dt * 3 + 1]) + nr * extra[dt * 3 + 2];
+              }
+              qrow[dt * kFreqN + wq] = q;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        } else {
+          // conv1 row outside the window: conv2 sees zeros there
+          for (int idx = lane; idx < 30 * KH2; idx += 64) {
+            const int dt = idx / 30;
+            const int wq = wbase + 1 + idx - 30 * dt;
+            if (wq < kFreqN) qrow[dt * kFreqN + wq] = 0.0f;
+          }
+        }
+      }
+      __syncthreads();
+
+      // ---- output rows r0-PH2 .. r0-PH2+3 (one per wave), then the next 4 image rows
+      {
+        const int t = r0 - PH2 + wave;
+        if (t >= T0 && t < T1) {
+          int qb[KH2];
+#pragma unroll
+          for (int dt = 0; dt < KH2; ++dt)
+            qb[dt] = (((t + dt - PH2 + 64 * Br::QRING) % Br::QRING) * KH2 + dt) * kFreqN;
+          float* orow = p.out + ((int64_t)b * kFrames + t) * kFreqN;
+          for (int w = lane; w < kFreqN; w += 64) {
+            float s = 0.0f;
+#pragma unroll
+            for (int dt = 0; dt < KH2; ++dt) s += qring[qb[dt] + w];
+            orow[w] = sigmoidf_exact(s + bias2);
+          }
+        }
+      }
+      if (ph + 1 < n_phase)
+        stage_rows<Br>(p, b, r0 + kBrRows + PH1, kBrRows, img_hi, img_lo, wave, lane);
+      __syncthreads();
+    }
+  }
+}
+
+// ---- z pack: NormalizedLog tail + BatchNorm affine, stored pre-split as (f16 hi | f16 lo << 16) ----
+// (signal.py:177-183, models.py:187-189).  One pass over lp; consumers gather these words straight
+// into MFMA operand slots with no further arithmetic.
+__global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ lp, const int* __restrict__ mm,
+                                                    uint32_t* __restrict__ zp, LogConsts kc) {
+  const int b = blockIdx.y;
+  const float mn = ord2f(mm[2 * b]);
+  const float range = ord2f(mm[2 * b + 1]) - mn;
+  const float* lpb = lp + (int64_t)b * kFrames * kBins;
+  uint32_t* zb = zp + (int64_t)b * kFrames * kZRow;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < kFrames * kZRow; i += gridDim.x * 256) {
+    const int t = i / kZRow, g = i - t * kZRow;
+    uint32_t u = 0;
+    if (g < kBins) {
+      const float z = norm_bn(lpb[t * kBins + g], mn, range, kc);
+      _Float16 hi, lo;
+      split_f16(z, hi, lo);
+      u = (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
+    }
+    zb[i] = u;
+  }
+}
+
+void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc,
+                  hipStream_t stream) {
+  hipLaunchKernelGGL(zpack_kernel, dim3(16, n_windows), dim3(256), 0, stream, lp, mm, zp, kc);
+}
+
+template <class Br>
+static void launch_branch(const BranchParams& p, int n_cu, hipStream_t stream) {
+  const int items = p.n_windows * kBrChunks;
+  const int grid = items < 2 * n_cu ? items : 2 * n_cu;
+  hipLaunchKernelGGL(branch_kernel<Br>, dim3(grid), dim3(kBrThreads), 0, stream, p);
+}
+
+void launch_note_branch(const float* contour, const void* wfrag, const float* wf32, float* note,
+                        int n_windows, int n_cu, hipStream_t stream) {
+  BranchParams p{static_cast<const uint4*>(wfrag), wf32, contour, nullptr, note, n_windows};
+  launch_branch<NoteBr>(p, n_cu, stream);
+}
+
+void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32,
+                         float* onset, int n_windows, int n_cu, hipStream_t stream) {
+  BranchParams p{static_cast<const uint4*>(wfrag), wf32, zp, note, onset, n_windows};
+  launch_branch<OnsetBr>(p, n_cu, stream);
+}
+
+}  // namespace bp

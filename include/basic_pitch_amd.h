@@ -60,8 +60,11 @@ typedef enum bp_mem_kind {
 
 /* bp_create flags */
 #define BP_FLAG_STAGE_TIMING 1u /* record HIP events around every stage; read with bp_get_stage_ms */
-#define BP_FLAG_F32_MFMA 2u     /* contour conv1 on the exact-f32 MFMA kernel instead of the default
-                                   f16 hi/lo split-operand kernel (fp32-class accuracy, ~4x faster) */
+#define BP_FLAG_F32_MFMA 2u     /* A/B reference path: the whole CNN on the exact-f32 kernels (f32 MFMA
+                                   32x32x2 for conv1 layers, f32 VALU heads, 32-channel intermediates in
+                                   HBM) instead of the default split-precision path (operands split into
+                                   f16 hi + lo, three f16 MFMAs per product, fp32 accumulate: fp32-class
+                                   accuracy at the f16 matrix rate; note / onset branches fused) */
 
 /*
  * Weights blob ("BPAMDW01", little endian) — produced by tools/extract_weights.py from the
@@ -137,19 +140,27 @@ enum {
   BP_STAGE_NOTE2 = 5,     /* conv 7x3 + sigmoid         n1 -> note            */
   BP_STAGE_ONSET1 = 6,    /* norm+BN+stack+conv 5x5 s3  lp,mm -> o1           */
   BP_STAGE_ONSET2 = 7,    /* concat + conv 3x3 + sigm.  note,o1 -> onset      */
-  BP_N_STAGES = 8
+  BP_STAGE_ZPACK = 8,     /* norm + BN, f16 hi|lo words  lp,mm -> zp          */
+  BP_STAGE_NOTE = 9,      /* fused note branch           contour -> note      */
+  BP_STAGE_ONSET = 10,    /* fused onset branch          zp,note -> onset     */
+  BP_N_STAGES = 11
 };
+/* Default (split-precision) path runs: PYRAMID, FILTERBANK, ZPACK, CONTOUR1, CONTOUR2, NOTE, ONSET.
+ * BP_FLAG_F32_MFMA runs:               PYRAMID, FILTERBANK, CONTOUR1, CONTOUR2, NOTE1, NOTE2, ONSET1, ONSET2. */
 
 /* With BP_FLAG_STAGE_TIMING: mean milliseconds per stage over the chunks (<= 128 most recent) run
- * since the previous call; synchronises the stream and resets the accumulation. */
+ * since the previous call (0 for stages the handle's path does not run); n >= BP_N_STAGES;
+ * synchronises the stream and resets the accumulation. */
 int bp_get_stage_ms(bp_handle h, float* ms, int n);
 
 /*
  * Test hook: run ONE stage on caller-supplied DEVICE buffers (layouts in DESIGN.md "HBM layout"):
  *   audio [n,43844]  pyr [n,BP_PYR_STRIDE]  lp [n,172,309]  mm int32 [n,2] (ordered-int min,max)
  *   c1 [n,8,172,264]  contour [n,172,264]  n1 [n,32,172,88]  note [n,172,88]  o1 [n,32,172,88]
- *   onset [n,172,88].  Unused pointers for a stage may be NULL.  Synchronous.
+ *   onset [n,172,88]  zp uint32 [n,172,BP_Z_ROW] (f16 hi | f16 lo << 16 of the normalised, BatchNorm-ed
+ *   CQT; words 309..311 of a row are zero).  Unused pointers for a stage may be NULL.  Synchronous.
  */
+#define BP_Z_ROW 312
 #define BP_PYR_STRIDE 43712
 typedef struct bp_stage_buffers {
   const float* audio;
@@ -162,6 +173,7 @@ typedef struct bp_stage_buffers {
   float* note;
   float* o1;
   float* onset;
+  uint32_t* zp;
 } bp_stage_buffers;
 int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* buf, int64_t n_windows);
 

@@ -28,6 +28,25 @@ def ord_decode(i: np.ndarray) -> np.ndarray:
     return np.where(i >= 0, i, i ^ np.int32(0x7FFFFFFF)).astype(np.int32).view(np.float32)
 
 
+def zp_pack(z: np.ndarray) -> np.ndarray:
+    """z (n,172,309) fp32 -> the library's pre-split words (n,172,312): f16 hi | f16 lo << 16."""
+    z = np.ascontiguousarray(z, dtype=np.float32)
+    hi = z.astype(np.float16)
+    lo = (z - hi.astype(np.float32)).astype(np.float16)
+    u = hi.view(np.uint16).astype(np.uint32) | (lo.view(np.uint16).astype(np.uint32) << 16)
+    out = np.zeros(z.shape[:2] + (_native.BP_Z_ROW,), dtype=np.uint32)
+    out[:, :, : z.shape[2]] = u
+    return out
+
+
+def zp_unpack(zp: np.ndarray) -> np.ndarray:
+    """inverse of zp_pack (hi + lo in fp32), pad words dropped"""
+    zp = np.ascontiguousarray(zp).view(np.uint32)[:, :, :309]
+    hi = (zp & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float32)
+    lo = (zp >> 16).astype(np.uint16).view(np.float16).astype(np.float32)
+    return hi + lo
+
+
 def pyr_pack(levels, lib) -> np.ndarray:
     """Oracle pyramid levels [1..8] -> the library's pyr row layout."""
     n = levels[1].shape[0]

@@ -106,6 +106,38 @@ def test_stage_cnn(runner, cases, stage, ins, outs, key, tol):
     assert d <= tol * scale, (stage, d)
 
 
+def test_stage_zpack(runner, cases):
+    """norm + BN written as pre-split f16 hi|lo words: hi + lo reproduces z to ~2^-22 relative."""
+    from stage_harness import ord_encode, zp_unpack
+
+    x, r32, r64 = cases
+    n = x.shape[0]
+    out = runner.run("zpack", n, {"lp": r32["lp"], "mm": ord_encode(r32["minmax"])},
+                     {"zp": ((n, 172, 312), torch.int32)})
+    zp = out["zp"].view(np.uint32)
+    assert (zp[:, :, 309:] == 0).all()
+    z = zp_unpack(zp)
+    assert np.abs(z - r32["z"]).max() <= 2e-6  # fp32 rounding of the normalisation + 2^-22 split residue
+
+
+@pytest.mark.parametrize("branch", ["note", "onset"])
+def test_stage_fused_branch(runner, cases, branch):
+    """The fused split-precision branches (conv -> ReLU -> conv -> sigmoid in one kernel) against the
+    oracle's fp32 posteriorgrams, fed with the oracle's own inputs of that branch."""
+    from stage_harness import zp_pack
+
+    x, r32, r64 = cases
+    n = x.shape[0]
+    if branch == "note":
+        feed = {"contour": r32["contour"]}
+    else:
+        feed = {"zp": zp_pack(r32["z"]).view(np.int32), "note": r32["note"]}
+    got = runner.run(branch, n, feed, {branch: ((n, 172, 88), F32)})[branch]
+    assert np.isfinite(got).all()
+    d32 = np.abs(got - r32[branch]).max()
+    assert d32 <= 5e-6, (branch, d32)
+
+
 def test_contour1_exact_f32_variant(cases):
     """The exact-f32 MFMA kernel (BP_FLAG_F32_MFMA) and the default f16 hi/lo split-operand kernel
     compute the same operator: both within 5e-5 of the fp32 oracle on c1 (values up to ~4.6), and the
