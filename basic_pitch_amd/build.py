@@ -20,6 +20,7 @@ SOURCES = [
     "bp_api.hip",
     "cqt_pyramid.hip",
     "cqt_filterbank.hip",
+    "cqt_mfma.hip",
     "conv_contour1.hip",
     "conv_contour1_f16.hip",
     "conv_stride3.hip",

@@ -39,6 +39,10 @@ void launch_note2(const float* n1, const float* wgt, float bias, float* note, in
                   hipStream_t s);
 void launch_onset2(const float* note, const float* o1, const float* wgt, float bias, float* onset,
                    int n_windows, hipStream_t s);
+void launch_pyramid_mfma(const float* audio, float* pyr, const void* hfrag, int n_windows, hipStream_t s);
+void launch_filterbank_mfma(const float* audio, const float* pyr, const void* bfrag, const float* sqrt_len,
+                            float* lp, int* mm, float* scratch, int n_windows, LogConsts kc, int n_cu,
+                            hipStream_t s);
 void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc, hipStream_t s);
 void launch_note_branch(const float* contour, const void* wfrag, const float* wf32, float* note,
                         int n_windows, int n_cu, hipStream_t s);
@@ -144,6 +148,7 @@ struct bp_context {
   // fused branches (conv_branch.hip): f16 hi/lo A fragments (raw bytes) + {bias1[32], extra[9], bias2}
   float *d_note_wfrag = nullptr, *d_note_wf32 = nullptr, *d_onset_wfrag = nullptr, *d_onset_wf32 = nullptr;
   float* zp = nullptr;  // uint32 [cap][172][kZRow] pre-split z
+  float *d_dec_hfrag = nullptr, *d_fbh_bfrag = nullptr;  // cqt_mfma.hip f16 hi/lo fragments (raw bytes)
   float *d_c1_bfrag = nullptr, *d_c1_bias = nullptr, *d_o1_bfrag = nullptr, *d_o1_bias = nullptr;
   float *d_n1_bfrag = nullptr, *d_n1_bias = nullptr, *d_w_contour2 = nullptr, *d_w_note2 = nullptr,
         *d_w_onset2 = nullptr;
@@ -353,10 +358,12 @@ void pack_note1(const Tensor* w, std::vector<float>& out) {
 }
 
 
-void put_split(std::vector<uint16_t>& out, size_t hi_base, size_t lo_base, size_t idx, float v) {
+// x = hi + lo / lo_scale: lo_scale > 1 keeps the residual inside f16's normal range (cqt_mfma.hip)
+void put_split(std::vector<uint16_t>& out, size_t hi_base, size_t lo_base, size_t idx, float v,
+               float lo_scale = 1.0f) {
   const uint16_t hi = f32_to_f16(v);
   out[hi_base + idx] = hi;
-  out[lo_base + idx] = f32_to_f16(v - f16_to_f32(hi));
+  out[lo_base + idx] = f32_to_f16((v - f16_to_f32(hi)) * lo_scale);
 }
 
 // Fused branch A fragments (conv_branch.hip): [A1 hi: KS1*64][A1 lo: KS1*64][A2 hi: 2*64][A2 lo: 2*64] x 8 f16.
@@ -396,8 +403,53 @@ void pack_branch(int ks1, const Tensor* w1, const Tensor* w2, bool onset, std::v
       }
 }
 
+// cqt_mfma.hip decimator: B[i][u] = h[i - 2u] band, [hi: 9 steps][lo: 9 steps] x 64 lanes x 8 f16;
+// lane (u = lane & 15, kg = lane >> 4), element e: i = 32 s + 8 kg + e.
+void pack_decimator_f16(const Tensor* lowp, std::vector<uint16_t>& out) {
+  const size_t lo_base = (size_t)9 * 64 * 8;
+  out.assign(2 * lo_base, 0);
+  for (int s = 0; s < 9; ++s)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int e = 0; e < 8; ++e) {
+        const int u = lane & 15, kg = lane >> 4;
+        const int j = 32 * s + 8 * kg + e - 2 * u;
+        // taps pre-scaled by 2^10, residuals by a further 2^11 (kDmTapScale / kLoScale in cqt_mfma.hip)
+        put_split(out, 0, lo_base, ((size_t)s * 64 + lane) * 8 + e,
+                  (j >= 0 && j < 256) ? lowp->data[j] * 1024.0f : 0.f, 2048.0f);
+      }
+}
+
+// cqt_mfma.hip filterbank: [4 roles][7 steps][hi|lo][64 lanes][8] f16; lane (n = lane & 15, kg), element e:
+// tap = base + 32 s' + 8 kg + e of the role's segment (FmRole in cqt_mfma.hip).
+void pack_filterbank_f16(const Tensor* re, const Tensor* im, std::vector<uint16_t>& out) {
+  out.assign((size_t)4 * 7 * 2 * 64 * 8, 0);
+  for (int role = 0; role < 4; ++role)
+    for (int s = 0; s < 7; ++s)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const int n = lane & 15, kg = lane >> 4;
+          float v = 0.f;
+          if (role < 2) {
+            const int tap = 16 + 32 * s + 8 * kg + e;
+            v = (role == 0 ? re : im)->data[n * 256 + tap];
+          } else if (s < 5) {
+            const int tap = 48 + 32 * s + 8 * kg + e;
+            v = (role == 2 ? re : im)->data[(16 + n) * 256 + tap];
+          } else {
+            const int tap = (role == 2 ? 64 : 128) + 32 * (s - 5) + 8 * kg + e;
+            if (n < 4)
+              v = re->data[(32 + n) * 256 + tap];
+            else if (n < 8)
+              v = im->data[(32 + n - 4) * 256 + tap];
+          }
+          const size_t base = (((size_t)role * 7 + s) * 2) * 64 * 8;
+          // taps pre-scaled by 2^12, residuals by a further 2^11 (kFmTapScale / kLoScale in cqt_mfma.hip)
+          put_split(out, base, base + 64 * 8, (size_t)lane * 8 + e, v * 4096.0f, 2048.0f);
+        }
+}
+
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->zp, h->d_c1h_bfrag, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->zp, h->d_c1h_bfrag, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->fb_scratch};
@@ -437,11 +489,19 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
       BP_HIP(hipEventRecord(ev[++e], s));          \
     }                                              \
   } while (0)
-  launch_pyramid(audio_dev, h->pyr, h->d_lowpass, n, s);
-  BP_MARK(BP_STAGE_PYRAMID);
-  launch_filterbank(audio_dev, h->pyr, h->d_fb_bfrag, h->d_sqrt_len, h->lp, h->mm, h->fb_scratch, n, h->kc,
-                    h->n_cu, s);
-  BP_MARK(BP_STAGE_FILTERBANK);
+  if (h->flags & BP_FLAG_F32_MFMA) {
+    launch_pyramid(audio_dev, h->pyr, h->d_lowpass, n, s);
+    BP_MARK(BP_STAGE_PYRAMID);
+    launch_filterbank(audio_dev, h->pyr, h->d_fb_bfrag, h->d_sqrt_len, h->lp, h->mm, h->fb_scratch, n, h->kc,
+                      h->n_cu, s);
+    BP_MARK(BP_STAGE_FILTERBANK);
+  } else {
+    launch_pyramid_mfma(audio_dev, h->pyr, h->d_dec_hfrag, n, s);
+    BP_MARK(BP_STAGE_PYRAMID);
+    launch_filterbank_mfma(audio_dev, h->pyr, h->d_fbh_bfrag, h->d_sqrt_len, h->lp, h->mm, h->fb_scratch, n,
+                           h->kc, h->n_cu, s);
+    BP_MARK(BP_STAGE_FILTERBANK);
+  }
   if (h->flags & BP_FLAG_F32_MFMA) {
     launch_contour1(h->lp, h->mm, h->d_c1_bfrag, h->d_c1_bias, h->c1, n, h->kc, h->n_cu, s);
     BP_MARK(BP_STAGE_CONTOUR1);
@@ -577,6 +637,17 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     std::vector<float> raw(c1h.size() / 2);
     std::memcpy(raw.data(), c1h.data(), c1h.size() * 2);
     if ((rc = upload(h, raw, &h->d_c1h_bfrag))) return fail(rc);
+  }
+  {
+    std::vector<uint16_t> frag;
+    pack_decimator_f16(lowp, frag);
+    std::vector<float> raw(frag.size() / 2);
+    std::memcpy(raw.data(), frag.data(), frag.size() * 2);
+    if ((rc = upload(h, raw, &h->d_dec_hfrag))) return fail(rc);
+    pack_filterbank_f16(re, im, frag);
+    raw.assign(frag.size() / 2, 0.f);
+    std::memcpy(raw.data(), frag.data(), frag.size() * 2);
+    if ((rc = upload(h, raw, &h->d_fbh_bfrag))) return fail(rc);
   }
   for (int br = 0; br < 2; ++br) {
     std::vector<uint16_t> frag;
@@ -826,14 +897,23 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
   bool ok = true;
   switch (stage) {
     case BP_STAGE_PYRAMID:
-      if ((ok = need(bf->audio) && need(bf->pyr))) launch_pyramid(bf->audio, bf->pyr, h->d_lowpass, n, s);
+      if ((ok = need(bf->audio) && need(bf->pyr))) {
+        if (h->flags & BP_FLAG_F32_MFMA)
+          launch_pyramid(bf->audio, bf->pyr, h->d_lowpass, n, s);
+        else
+          launch_pyramid_mfma(bf->audio, bf->pyr, h->d_dec_hfrag, n, s);
+      }
       break;
     case BP_STAGE_FILTERBANK:
       if ((ok = need(bf->audio) && need(bf->pyr) && need(bf->lp) && need(bf->mm))) {
         int rc = ensure_fb_scratch(h, n);
         if (rc) return rc;
-        launch_filterbank(bf->audio, bf->pyr, h->d_fb_bfrag, h->d_sqrt_len, bf->lp, bf->mm, h->fb_scratch, n,
-                          h->kc, h->n_cu, s);
+        if (h->flags & BP_FLAG_F32_MFMA)
+          launch_filterbank(bf->audio, bf->pyr, h->d_fb_bfrag, h->d_sqrt_len, bf->lp, bf->mm, h->fb_scratch, n,
+                            h->kc, h->n_cu, s);
+        else
+          launch_filterbank_mfma(bf->audio, bf->pyr, h->d_fbh_bfrag, h->d_sqrt_len, bf->lp, bf->mm,
+                                 h->fb_scratch, n, h->kc, h->n_cu, s);
       }
       break;
     case BP_STAGE_CONTOUR1:

@@ -212,6 +212,11 @@ static void launch_fb_level(const float* audio, const float* pyr, const float* b
                      bfrag, sqrt_len, lp, mmp, n_windows, kc);
 }
 
+void launch_mm_reduce(const float* scratch, int* mm, int n_windows, hipStream_t stream) {
+  hipLaunchKernelGGL(mm_reduce_kernel, dim3(n_windows), dim3(64), 0, stream,
+                     reinterpret_cast<const float2*>(scratch), mm);
+}
+
 size_t filterbank_scratch_floats(int n_windows) { return (size_t)n_windows * kMmPartials * 2; }
 
 void launch_filterbank(const float* audio, const float* pyr, const float* bfrag,

@@ -1,0 +1,373 @@
+// CQT front end on the f16 matrix cores with split operands (default path): the 8 x decimate-by-2
+// pyramid and the 9-level complex filterbank.  Same operators as cqt_pyramid.hip / cqt_filterbank.hip
+// (the exact-f32 A/B reference kernels), same reference lines:
+//   basic_pitch/layers/nnaudio.py:259-284, 636-638   downsampling_by_n: zero-pad 127, 256-tap FIR, stride 2
+//   basic_pitch/layers/nnaudio.py:216-256, 640-661   get_cqt_complex per level, * sqrt(lengths), magnitude
+//   basic_pitch/layers/signal.py:171-178             power, 10*log10(power + 1e-10), per-example min / max
+//
+// Every operand x is carried as x = hi + lo (two f16, 22 significand bits) and every product as
+// hi*hi + lo*hi + hi*lo on v_mfma_f32_16x16x32_f16 with fp32 accumulation: fp32-class accuracy
+// (dropped term <= 2^-22 |ab|) at 16x the f32 matrix rate.  The signal is split ONCE while it is staged
+// into LDS; the filters are split on the host.
+//
+// Decimator.  y[n] = sum_j h[j] xz[2n + j - 127] has ONE filter, so the GEMM is built from the band
+// structure instead: a tile is 16 row-blocks x 16 outputs, A[m][i] = xp[32 m + i] (Hankel, 32-sample row
+// stride, 16-byte aligned reads), B[i][u] = h[i - 2u] (Toeplitz band, 256 of the 288 k-slots non-zero:
+// 89 % dense), 9 k-steps.  The 9 B fragments are the same for all 8 levels and stay in VGPRs.
+//
+// Filterbank.  Per (window, level, 16-frame tile): [16 frames x K] x [K x 72 filter columns] with the
+// Hankel A[t][i] = xp[t*hop + i].  K is clipped to the kernels' support (61 % of 256 taps) in 32-tap
+// steps, the four waves own (re 0-15 | im 0-15 | re 16-31 + half of {re,im} 32-35 | im 16-31 + other half):
+// 7 k-steps each, B fragments resident.  Aligned 16-byte A reads need t*hop = 0 (mod 8): levels with
+// hop < 8 stage 8/hop shifted copies of their (short) signal.  All 9 levels run in ONE launch (the
+// filters are level-independent), items = (window, level, tile).
+//
+// LDS rows are skewed so every ds_read_b128 of a fragment is bank-conflict free (row stride = 2 or 6
+// sixteen-byte units mod 16).
+//
+// Roofline: f16 MFMA issue.  Algorithmic work per window: pyramid 22.4 MFLOP, filterbank 57.1 MFLOP
+// (SURVEY.md §8a row a8).  Bytes per window: pyramid 175,376 + 174,764 read, 174,764 written;
+// filterbank 350,140 read + 212,592 written.
+#include "bp_common.h"
+
+namespace bp {
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+// f16 has 5 exponent bits: the residual of a sample (<= 2^-12 |x|) and the small taps of the filters
+// (1e-3 .. 1e-8) would land in its subnormal range and lose their low bits — measured 8.7e-6 instead of
+// 2.4e-6 on the CQT magnitudes.  So residuals are stored multiplied by 2^11 and the taps pre-scaled by a
+// power of two; the three product classes have their own accumulators and are recombined with exact
+// power-of-two factors:  result = (hh + (lh + hl) * 2^-11) * 2^-tapshift.
+constexpr float kLoScale = 2048.0f, kLoUnscale = 1.0f / 2048.0f;
+constexpr float kDmTapUnscale = 1.0f / 1024.0f;   // decimator taps are packed * 2^10 (bp_api.hip)
+constexpr float kFmTapUnscale = 1.0f / 4096.0f;   // CQT kernels are packed * 2^12
+
+__device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo) {
+  f16x8 vh, vl;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const _Float16 h = (_Float16)v[e];
+    vh[e] = h;
+    vl[e] = (_Float16)((v[e] - (float)h) * kLoScale);
+  }
+  hi = __builtin_bit_cast(uint4, vh);
+  lo = __builtin_bit_cast(uint4, vl);
+}
+
+#define BP_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0)
+
+// ================================================================================================
+// decimate by 2
+constexpr int kDmThreads = 256;
+constexpr int kDmTiles = 8;                           // MFMA tiles (256 outputs each) per workgroup
+constexpr int kDmOutPerWg = 256 * kDmTiles;           // 2048
+constexpr int kDmPos = 2 * kDmOutPerWg + 256;         // 4352 staged input positions
+constexpr int kDmUnits = (kDmPos / 32) * 6;           // 16-byte units, 32-sample rows skewed to 6 units
+constexpr int kDmSteps = 9;                           // 288 k-slots (286 used)
+
+__global__ __launch_bounds__(kDmThreads) void decimate2_mfma_kernel(const float* __restrict__ src,
+                                                                    int64_t src_stride, int len_in,
+                                                                    float* __restrict__ dst,
+                                                                    int64_t dst_stride, int len_out,
+                                                                    const uint4* __restrict__ hfrag) {
+  __shared__ __attribute__((aligned(16))) uint4 s_hi[kDmUnits];
+  __shared__ __attribute__((aligned(16))) uint4 s_lo[kDmUnits];
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  const int b = blockIdx.y;
+  const int o0 = blockIdx.x * kDmOutPerWg;
+  const float* x = src + (int64_t)b * src_stride;
+  const int in0 = 2 * o0 - 127;  // xp[p] = xz[in0 + p]
+
+  uint4 hh[kDmSteps], hl[kDmSteps];
+#pragma unroll
+  for (int s = 0; s < kDmSteps; ++s) {
+    hh[s] = hfrag[s * 64 + lane];
+    hl[s] = hfrag[(kDmSteps + s) * 64 + lane];
+  }
+
+  for (int q = threadIdx.x; q < kDmPos / 8; q += kDmThreads) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = in0 + 8 * q + e;
+      const bool ok = g >= 0 && g < len_in;
+      v[e] = ok ? x[ok ? g : 0] : 0.0f;
+    }
+    uint4 hi, lo;
+    split8(v, hi, lo);
+    const int unit = q + 2 * (q >> 2);
+    s_hi[unit] = hi;
+    s_lo[unit] = lo;
+  }
+  __syncthreads();
+
+  const int m = lane & 15, kg = lane >> 4;
+  float* y = dst + (int64_t)b * dst_stride;
+  for (int tile = wave; tile < kDmTiles; tile += kDmThreads / 64) {
+    const int mb = tile * 16;
+    if (o0 + 16 * mb >= len_out) break;
+    f32x4 a_hh = {0.f, 0.f, 0.f, 0.f}, a_lh = a_hh, a_hl = a_hh;
+    const int base = 6 * (mb + m) + kg;
+#pragma unroll
+    for (int s = 0; s < kDmSteps; ++s) {
+      const uint4 ah = s_hi[base + 6 * s];
+      const uint4 al = s_lo[base + 6 * s];
+      a_hh = BP_MFMA16(ah, hh[s], a_hh);
+      a_lh = BP_MFMA16(al, hh[s], a_lh);
+      a_hl = BP_MFMA16(ah, hl[s], a_hl);
+    }
+    // C: col u = lane & 15, row (row-block) = 4*kg + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = o0 + 16 * (mb + 4 * kg + r) + m;
+      if (n < len_out) y[n] = (a_hh[r] + (a_lh[r] + a_hl[r]) * kLoUnscale) * kDmTapUnscale;
+    }
+  }
+}
+
+void launch_pyramid_mfma(const float* audio, float* pyr, const void* hfrag, int n_windows,
+                         hipStream_t stream) {
+  for (int k = 1; k < kOctaves; ++k) {
+    const float* src = (k == 1) ? audio : pyr + pyr_off(k - 1);
+    const int64_t sstride = (k == 1) ? kAudioN : kPyrStride;
+    const int lin = level_len(k - 1), lout = level_len(k);
+    dim3 grid((lout + kDmOutPerWg - 1) / kDmOutPerWg, n_windows);
+    hipLaunchKernelGGL(decimate2_mfma_kernel, grid, dim3(kDmThreads), 0, stream, src, sstride, lin,
+                       pyr + pyr_off(k), (int64_t)kPyrStride, lout, static_cast<const uint4*>(hfrag));
+  }
+}
+
+// ================================================================================================
+// filterbank
+constexpr int kFmThreads = 256;
+constexpr int kFmTileFrames = 16;
+constexpr int kFmTilesPerLevel = (kFrames + kFmTileFrames - 1) / kFmTileFrames;  // 11
+constexpr int kFmSteps = 7;                       // k-steps (32 taps) per wave
+constexpr int kFmMaxUnits = (15 * 256 + 256 + 16 * 16) / 8;  // hop 256: 4096 samples + 16 skews
+constexpr int kFmExRow = 17;
+constexpr int kFmExTile = kFmTileFrames * kFmExRow;
+
+__host__ __device__ constexpr int fm_copies(int hop) { return hop >= 8 ? 1 : 8 / hop; }
+__host__ __device__ constexpr int fm_copy_units(int hop) { return hop == 4 ? 40 : 36; }  // per shifted copy
+
+// uint4 index of the 8 samples xp[t*HOP + off .. +7] of the tile (off a multiple of 8)
+template <int HOP>
+__device__ __forceinline__ int fm_unit(int t, int off) {
+  if constexpr (HOP >= 32) {
+    return (t * (HOP + 16) + off + 16 * (off / HOP)) >> 3;
+  } else if constexpr (HOP >= 8) {
+    return (t * HOP + off) >> 3;
+  } else {
+    constexpr int C = fm_copies(HOP);
+    return (t % C) * fm_copy_units(HOP) + (t / C) + (off >> 3);
+  }
+}
+
+template <int HOP>
+__device__ __forceinline__ void fm_stage(const float* __restrict__ x, int L, int t0, uint4* __restrict__ s_hi,
+                                         uint4* __restrict__ s_lo) {
+  // xp[p] = reflect(x)[t0*HOP + p - 128]    (nnaudio.py:229, 300-301)
+  auto sample = [&](int p) {
+    int g = t0 * HOP + p - 128;
+    g = g < 0 ? -g : g;
+    g = g >= L ? 2 * (L - 1) - g : g;
+    g = g < 0 ? 0 : (g >= L ? L - 1 : g);  // only reachable for the padding frames 172..175
+    return x[g];
+  };
+  if constexpr (HOP >= 8) {
+    constexpr int NBLK = (15 * HOP + 256) / 8;
+    for (int q = threadIdx.x; q < NBLK; q += kFmThreads) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = sample(8 * q + e);
+      uint4 hi, lo;
+      split8(v, hi, lo);
+      const int unit = (HOP >= 32) ? q + 2 * ((8 * q) / HOP) : q;
+      s_hi[unit] = hi;
+      s_lo[unit] = lo;
+    }
+  } else {
+    constexpr int C = fm_copies(HOP);
+    constexpr int NBLK = 16 / C + 32;  // 8-sample blocks a copy must hold
+    for (int i = threadIdx.x; i < C * NBLK; i += kFmThreads) {
+      const int c = i / NBLK, q = i - c * NBLK;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = sample(8 * q + c * HOP + e);
+      uint4 hi, lo;
+      split8(v, hi, lo);
+      s_hi[c * fm_copy_units(HOP) + q] = hi;
+      s_lo[c * fm_copy_units(HOP) + q] = lo;
+    }
+  }
+}
+
+// segment A: NA steps from tap BASE_A into exchange slot SLOT_A; segment B (roles 2, 3): 2 steps of the
+// {re,im} 32..35 columns starting at tap BASE_B into slot SLOT_B
+template <int ROLE>
+struct FmRole;
+template <> struct FmRole<0> { static constexpr int NA = 7, BASE_A = 16, NB = 0, BASE_B = 0, SLOT_A = 0, SLOT_B = 0; };
+template <> struct FmRole<1> { static constexpr int NA = 7, BASE_A = 16, NB = 0, BASE_B = 0, SLOT_A = 1, SLOT_B = 0; };
+template <> struct FmRole<2> { static constexpr int NA = 5, BASE_A = 48, NB = 2, BASE_B = 64, SLOT_A = 2, SLOT_B = 4; };
+template <> struct FmRole<3> { static constexpr int NA = 5, BASE_A = 48, NB = 2, BASE_B = 128, SLOT_A = 3, SLOT_B = 5; };
+
+template <int ROLE, int HOP>
+__device__ __forceinline__ void fm_role_compute(const uint4* __restrict__ s_hi, const uint4* __restrict__ s_lo,
+                                                const uint4 (&bh)[kFmSteps], const uint4 (&bl)[kFmSteps],
+                                                float* __restrict__ exch, int lane) {
+  using R = FmRole<ROLE>;
+  const int t = lane & 15, kg = lane >> 4;
+  f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 a_hh = z4, a_lh = z4, a_hl = z4;
+#pragma unroll
+  for (int s = 0; s < R::NA; ++s) {
+    const int u = fm_unit<HOP>(t, R::BASE_A + 32 * s + 8 * kg);
+    const uint4 ah = s_hi[u], al = s_lo[u];
+    a_hh = BP_MFMA16(ah, bh[s], a_hh);
+    a_lh = BP_MFMA16(al, bh[s], a_lh);
+    a_hl = BP_MFMA16(ah, bl[s], a_hl);
+  }
+  // C: col = lane & 15 (filter), row = 4*kg + r (frame)
+  float* ea = exch + R::SLOT_A * kFmExTile + (kg * 4) * kFmExRow + t;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ea[r * kFmExRow] = (a_hh[r] + (a_lh[r] + a_hl[r]) * kLoUnscale) * kFmTapUnscale;
+  if constexpr (R::NB > 0) {
+    f32x4 b_hh = z4, b_lh = z4, b_hl = z4;
+#pragma unroll
+    for (int s = 0; s < R::NB; ++s) {
+      const int u = fm_unit<HOP>(t, R::BASE_B + 32 * s + 8 * kg);
+      const uint4 ah = s_hi[u], al = s_lo[u];
+      b_hh = BP_MFMA16(ah, bh[R::NA + s], b_hh);
+      b_lh = BP_MFMA16(al, bh[R::NA + s], b_lh);
+      b_hl = BP_MFMA16(ah, bl[R::NA + s], b_hl);
+    }
+    float* eb = exch + R::SLOT_B * kFmExTile + (kg * 4) * kFmExRow + t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) eb[r * kFmExRow] = (b_hh[r] + (b_lh[r] + b_hl[r]) * kLoUnscale) * kFmTapUnscale;
+  }
+}
+
+template <int LEVEL>
+__device__ __forceinline__ void fm_item(const float* __restrict__ audio, const float* __restrict__ pyr, int b,
+                                        int tile, const uint4 (&bh)[kFmSteps], const uint4 (&bl)[kFmSteps],
+                                        const float* __restrict__ sqrt_len, float* __restrict__ lp,
+                                        float2* __restrict__ mmp, const LogConsts& kc, uint4* s_hi, uint4* s_lo,
+                                        float* exch, int role, int lane) {
+  constexpr int HOP = 256 >> LEVEL;
+  constexpr int L = level_len(LEVEL);
+  const float* x = (LEVEL == 0) ? audio + (int64_t)b * kAudioN : pyr + (int64_t)b * kPyrStride + pyr_off(LEVEL);
+  const int t0 = tile * kFmTileFrames;
+  // keep the per-level LDS address arithmetic inside the item (hoisting all 36 level x role variants
+  // out of the persistent loop costs > 100 VGPRs)
+  asm volatile("" : "+v"(lane));
+
+  __syncthreads();  // previous item's epilogue is done with exch, its MFMAs with s_hi / s_lo
+  fm_stage<HOP>(x, L, t0, s_hi, s_lo);
+  __syncthreads();
+  switch (role) {
+    case 0: fm_role_compute<0, HOP>(s_hi, s_lo, bh, bl, exch, lane); break;
+    case 1: fm_role_compute<1, HOP>(s_hi, s_lo, bh, bl, exch, lane); break;
+    case 2: fm_role_compute<2, HOP>(s_hi, s_lo, bh, bl, exch, lane); break;
+    default: fm_role_compute<3, HOP>(s_hi, s_lo, bh, bl, exch, lane); break;
+  }
+  __syncthreads();
+
+  // epilogue: 16 frames x 36 filters -> * sqrt(len), magnitude, log-power, tile extrema
+  float vmin = __int_as_float(0x7f800000), vmax = -__int_as_float(0x7f800000);
+  for (int idx = threadIdx.x; idx < kFmTileFrames * kBpo; idx += kFmThreads) {
+    const int fr = idx / kBpo, k = idx - fr * kBpo;
+    const int t = t0 + fr;
+    const int bin = (kOctaves - 1 - LEVEL) * kBpo + k - 15;  // nnaudio.py:640-642
+    if (t >= kFrames || bin < 0) continue;
+    float re, im;
+    const float* e = exch + fr * kFmExRow;
+    if (k < 16) {
+      re = e[0 * kFmExTile + k];
+      im = e[1 * kFmExTile + k];
+    } else if (k < 32) {
+      re = e[2 * kFmExTile + k - 16];
+      im = e[3 * kFmExTile + k - 16];
+    } else {
+      re = e[4 * kFmExTile + k - 32] + e[5 * kFmExTile + k - 32];
+      im = e[4 * kFmExTile + k - 28] + e[5 * kFmExTile + k - 28];
+    }
+    const float sl = sqrt_len[bin];
+    re = __fmul_rn(re, sl);  // nnaudio.py:650: scale before squaring
+    im = __fmul_rn(im, sl);
+    const float mag = sqrtf(__fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)));  // nnaudio.py:661
+    const float pw = __fmul_rn(mag, mag);                                      // signal.py:174
+    const float v = __fmul_rn(__fmul_rn(logf(__fadd_rn(pw, kc.eps)), kc.s0), kc.s1);
+    lp[((int64_t)b * kFrames + t) * kBins + bin] = v;
+    vmin = fminf(vmin, v);
+    vmax = fmaxf(vmax, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    vmin = fminf(vmin, __shfl_xor(vmin, o));
+    vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+  }
+  if (lane == 0)
+    mmp[(((int64_t)b * kOctaves + LEVEL) * kFmTilesPerLevel + tile) * 4 + role] = make_float2(vmin, vmax);
+}
+
+__global__ __launch_bounds__(kFmThreads, 4) void cqt_filterbank_mfma_kernel(
+    const float* __restrict__ audio, const float* __restrict__ pyr, const uint4* __restrict__ bfrag,
+    const float* __restrict__ sqrt_len, float* __restrict__ lp, float2* __restrict__ mmp, int n_windows,
+    LogConsts kc) {
+  __shared__ __attribute__((aligned(16))) uint4 s_hi[kFmMaxUnits];
+  __shared__ __attribute__((aligned(16))) uint4 s_lo[kFmMaxUnits];
+  __shared__ float exch[6 * kFmExTile];
+  const int lane = threadIdx.x & 63;
+  const int role = wave_id();
+
+  uint4 bh[kFmSteps], bl[kFmSteps];
+  {
+    const uint4* bp_ = bfrag + (size_t)role * kFmSteps * 2 * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < kFmSteps; ++s) {
+      bh[s] = bp_[(2 * s) * 64];
+      bl[s] = bp_[(2 * s + 1) * 64];
+    }
+  }
+  const int per_window = kOctaves * kFmTilesPerLevel;
+  const int n_items = n_windows * per_window;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int b = item / per_window;
+    const int rem = item - b * per_window;
+    const int level = rem / kFmTilesPerLevel;
+    const int tile = rem - level * kFmTilesPerLevel;
+#define BP_FM_CASE(LV)                                                                                          \
+  case LV:                                                                                                      \
+    fm_item<LV>(audio, pyr, b, tile, bh, bl, sqrt_len, lp, mmp, kc, s_hi, s_lo, exch, role, lane);              \
+    break;
+    switch (level) {
+      BP_FM_CASE(0)
+      BP_FM_CASE(1)
+      BP_FM_CASE(2)
+      BP_FM_CASE(3)
+      BP_FM_CASE(4)
+      BP_FM_CASE(5)
+      BP_FM_CASE(6)
+      BP_FM_CASE(7)
+      default: fm_item<8>(audio, pyr, b, tile, bh, bl, sqrt_len, lp, mmp, kc, s_hi, s_lo, exch, role, lane); break;
+    }
+#undef BP_FM_CASE
+  }
+}
+
+void launch_mm_reduce(const float* scratch, int* mm, int n_windows, hipStream_t stream);
+
+void launch_filterbank_mfma(const float* audio, const float* pyr, const void* bfrag, const float* sqrt_len,
+                            float* lp, int* mm, float* scratch, int n_windows, LogConsts kc, int n_cu,
+                            hipStream_t stream) {
+  float2* mmp = reinterpret_cast<float2*>(scratch);
+  const int items = n_windows * kOctaves * kFmTilesPerLevel;
+  const int grid = items < 4 * n_cu ? items : 4 * n_cu;
+  hipLaunchKernelGGL(cqt_filterbank_mfma_kernel, dim3(grid), dim3(kFmThreads), 0, stream, audio, pyr,
+                     static_cast<const uint4*>(bfrag), sqrt_len, lp, mmp, n_windows, kc);
+  launch_mm_reduce(scratch, mm, n_windows, stream);
+}
+
+}  // namespace bp
