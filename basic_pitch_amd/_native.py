@@ -16,13 +16,13 @@ BP_MEM_HOST = 0
 BP_MEM_DEVICE = 1
 BP_FLAG_STAGE_TIMING = 1
 BP_FLAG_F32_MFMA = 2
-BP_N_STAGES = 11
+BP_N_STAGES = 12
 BP_Z_ROW = 312
 BP_PYR_STRIDE = 43712
 
 STAGE_NAMES = [
     "pyramid", "filterbank", "contour1", "contour2", "note1", "note2", "onset1", "onset2",
-    "zpack", "note", "onset",
+    "zpack", "note", "onset", "contour",
 ]
 
 _ERR_NAMES = {

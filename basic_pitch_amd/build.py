@@ -22,7 +22,7 @@ SOURCES = [
     "cqt_filterbank.hip",
     "cqt_mfma.hip",
     "conv_contour1.hip",
-    "conv_contour1_f16.hip",
+    "conv_contour.hip",
     "conv_stride3.hip",
     "conv_heads.hip",
     "conv_branch.hip",

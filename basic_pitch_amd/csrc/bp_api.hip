@@ -27,8 +27,8 @@ void launch_filterbank(const float* audio, const float* pyr, const float* bfrag,
                        hipStream_t s);
 void launch_contour1(const float* lp, const int* mm, const float* bfrag, const float* bias, float* c1,
                      int n_windows, LogConsts kc, int n_cu, hipStream_t s);
-void launch_contour1_f16(const float* lp, const int* mm, const void* bfrag, const float* bias, float* c1,
-                         int n_windows, LogConsts kc, int n_cu, hipStream_t s);
+void launch_contour_branch(const uint32_t* zp, const void* wfrag, const float* wf32, float* contour,
+                           int n_windows, int n_cu, hipStream_t s);
 void launch_onset1(const float* lp, const int* mm, const float* bfrag, const float* bias, float* o1,
                    int n_windows, LogConsts kc, int n_cu, hipStream_t s);
 void launch_note1(const float* contour, const float* bfrag, const float* bias, float* n1, int n_windows,
@@ -144,7 +144,7 @@ struct bp_context {
   float b_contour2 = 0, b_note2 = 0, b_onset2 = 0;
   // device constants
   float *d_lowpass = nullptr, *d_sqrt_len = nullptr, *d_fb_bfrag = nullptr;
-  float* d_c1h_bfrag = nullptr;  // f16 hi/lo B fragments of the split-precision contour1 (raw bytes)
+  float *d_cb_wfrag = nullptr, *d_cb_wf32 = nullptr;  // fused contour branch (conv_contour.hip)
   // fused branches (conv_branch.hip): f16 hi/lo A fragments (raw bytes) + {bias1[32], extra[9], bias2}
   float *d_note_wfrag = nullptr, *d_note_wf32 = nullptr, *d_onset_wfrag = nullptr, *d_onset_wf32 = nullptr;
   float* zp = nullptr;  // uint32 [cap][172][kZRow] pre-split z
@@ -294,11 +294,24 @@ float f16_to_f32(uint16_t hv) {
   return f;
 }
 
-// split-precision contour conv1 B fragments (conv_contour1_f16.hip):
-// [4 waves][16 k-steps][hi|lo][64 lanes][8 channels] f16; k-step = (frame dt, tap pair ep), lane ->
-// (tap parity h = lane>>5, column n = lane&31 = out channel o*4 + bin j); value W[o][c][dt][2ep+h-j].
-void pack_contour1_f16(const Tensor* w, std::vector<uint16_t>& out) {
-  out.assign((size_t)4 * 16 * 2 * 64 * 8, 0);
+// x = hi + lo / lo_scale: lo_scale > 1 keeps the residual inside f16's normal range (cqt_mfma.hip)
+void put_split(std::vector<uint16_t>& out, size_t hi_base, size_t lo_base, size_t idx, float v,
+               float lo_scale = 1.0f) {
+  const uint16_t hi = f32_to_f16(v);
+  out[hi_base + idx] = hi;
+  out[lo_base + idx] = f32_to_f16((v - f16_to_f32(hi)) * lo_scale);
+}
+
+// Fused contour branch (conv_contour.hip).
+//   conv1 A fragments [4 waves][16 k-steps][hi|lo][64 lanes][8 channels] f16; k-step = (frame dt, tap pair
+//   ep), lane -> (tap parity h = lane >> 5, row i = lane & 31 = out channel o*4 + bin offset j); value
+//   W1[o][c][dt][2ep + h - j] (Toeplitz over 4 adjacent bins).
+//   conv2 A fragments [2][64 lanes][8]: lane -> (tap = lane & 31 (25 used), h); k-slot e < 4 is channel
+//   2e + h of the hi part, e >= 4 channel 2(e-4) + h of the scaled lo part of relu(c1):
+//     fragment 0 = [hi(w) | 0], fragment 1 = [lo(w) * 2^11 | hi(w)].
+void pack_contour_branch(const Tensor* w1, const Tensor* w2, std::vector<uint16_t>& out) {
+  const size_t n1 = (size_t)4 * 16 * 2 * 64 * 8;
+  out.assign(n1 + 2 * 64 * 8, 0);
   for (int wave = 0; wave < 4; ++wave)
     for (int s = 0; s < 16; ++s) {
       const int step = wave * 16 + s;
@@ -307,16 +320,25 @@ void pack_contour1_f16(const Tensor* w, std::vector<uint16_t>& out) {
       for (int lane = 0; lane < 64; ++lane) {
         const int hh = lane >> 5, n = lane & 31, o = n >> 2, jj = n & 3;
         const int df = 2 * ep + hh - jj;
+        const size_t base = ((((size_t)wave * 16 + s) * 2 + 0) * 64 + lane) * 8;
         for (int c = 0; c < 8; ++c) {
           float v = 0.f;
-          if (df >= 0 && df < 39) v = w->data[((o * 8 + c) * 3 + dt) * 39 + df];
-          const uint16_t hi = f32_to_f16(v);
-          const uint16_t lo = f32_to_f16(v - f16_to_f32(hi));
-          out[((((size_t)wave * 16 + s) * 2 + 0) * 64 + lane) * 8 + c] = hi;
-          out[((((size_t)wave * 16 + s) * 2 + 1) * 64 + lane) * 8 + c] = lo;
+          if (df >= 0 && df < 39) v = w1->data[((o * 8 + c) * 3 + dt) * 39 + df];
+          put_split(out, base, base + 64 * 8, c, v, 2048.0f);
         }
       }
     }
+  for (int lane = 0; lane < 64; ++lane) {
+    const int tap = lane & 31, hh = lane >> 5;
+    for (int e = 0; e < 4; ++e) {
+      const float v = tap < 25 ? w2->data[(2 * e + hh) * 25 + tap] : 0.f;
+      const uint16_t hi = f32_to_f16(v);
+      const uint16_t lo = f32_to_f16((v - f16_to_f32(hi)) * 2048.0f);
+      out[n1 + (size_t)lane * 8 + e] = hi;                 // fragment 0: hi(w) x hi(c)
+      out[n1 + 64 * 8 + (size_t)lane * 8 + e] = lo;        // fragment 1: lo(w) x hi(c)
+      out[n1 + 64 * 8 + (size_t)lane * 8 + 4 + e] = hi;    //             hi(w) x lo(c)
+    }
+  }
 }
 
 // contour conv1 Toeplitz B fragments [4 waves][126][64] (conv_contour1.hip).
@@ -358,13 +380,6 @@ void pack_note1(const Tensor* w, std::vector<float>& out) {
 }
 
 
-// x = hi + lo / lo_scale: lo_scale > 1 keeps the residual inside f16's normal range (cqt_mfma.hip)
-void put_split(std::vector<uint16_t>& out, size_t hi_base, size_t lo_base, size_t idx, float v,
-               float lo_scale = 1.0f) {
-  const uint16_t hi = f32_to_f16(v);
-  out[hi_base + idx] = hi;
-  out[lo_base + idx] = f32_to_f16((v - f16_to_f32(hi)) * lo_scale);
-}
 
 // Fused branch A fragments (conv_branch.hip): [A1 hi: KS1*64][A1 lo: KS1*64][A2 hi: 2*64][A2 lo: 2*64] x 8 f16.
 // A1 lane (i = out channel = lane & 31, h = lane >> 5), element e: conv1 weight of k = 8h + e of step s.
@@ -386,7 +401,7 @@ void pack_branch(int ks1, const Tensor* w1, const Tensor* w2, bool onset, std::v
           const int dt = 2 * s + hh;
           if (dt < 7 && e < 7) v = w1->data[(i * 7 + dt) * 7 + e];
         }
-        put_split(out, a1h, a1l, ((size_t)s * 64 + lane) * 8 + e, v);
+        put_split(out, a1h, a1l, ((size_t)s * 64 + lane) * 8 + e, v, 2048.0f);
       }
   for (int s2 = 0; s2 < 2; ++s2)
     for (int lane = 0; lane < 64; ++lane)
@@ -399,7 +414,7 @@ void pack_branch(int ks1, const Tensor* w1, const Tensor* w2, bool onset, std::v
           v = onset ? w2->data[((1 + ch) * 3 + dt) * 3 + dw]   // channel 0 of the concat is the note map
                     : w2->data[(ch * 7 + dt) * 3 + dw];
         }
-        put_split(out, a2h, a2l, ((size_t)s2 * 64 + lane) * 8 + e, v);
+        put_split(out, a2h, a2l, ((size_t)s2 * 64 + lane) * 8 + e, v, 2048.0f);
       }
 }
 
@@ -449,7 +464,7 @@ void pack_filterbank_f16(const Tensor* re, const Tensor* im, std::vector<uint16_
 }
 
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->zp, h->d_c1h_bfrag, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->zp, h->d_cb_wfrag, h->d_cb_wf32, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->fb_scratch};
@@ -518,10 +533,9 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
   } else {
     launch_zpack(h->lp, h->mm, reinterpret_cast<uint32_t*>(h->zp), n, h->kc, s);
     BP_MARK(BP_STAGE_ZPACK);
-    launch_contour1_f16(h->lp, h->mm, h->d_c1h_bfrag, h->d_c1_bias, h->c1, n, h->kc, h->n_cu, s);
-    BP_MARK(BP_STAGE_CONTOUR1);
-    launch_contour2(h->c1, h->d_w_contour2, h->b_contour2, contour_dev, n, s);
-    BP_MARK(BP_STAGE_CONTOUR2);
+    launch_contour_branch(reinterpret_cast<const uint32_t*>(h->zp), h->d_cb_wfrag, h->d_cb_wf32, contour_dev, n,
+                          h->n_cu, s);
+    BP_MARK(BP_STAGE_CONTOUR);
     launch_note_branch(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, h->n_cu, s);
     BP_MARK(BP_STAGE_NOTE);
     launch_onset_branch(reinterpret_cast<const uint32_t*>(h->zp), note_dev, h->d_onset_wfrag, h->d_onset_wf32,
@@ -631,37 +645,34 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     h->stream = h->own_stream;
   }
   std::vector<float> c1f, o1f, n1f;
-  {
-    std::vector<uint16_t> c1h;
-    pack_contour1_f16(c1w, c1h);
-    std::vector<float> raw(c1h.size() / 2);
-    std::memcpy(raw.data(), c1h.data(), c1h.size() * 2);
-    if ((rc = upload(h, raw, &h->d_c1h_bfrag))) return fail(rc);
-  }
-  {
+  {  // split-precision path: f16 hi | scaled-lo operand fragments (raw bytes) + fp32 side tables
+    auto raw_of = [](const std::vector<uint16_t>& f) {
+      std::vector<float> raw(f.size() / 2);
+      std::memcpy(raw.data(), f.data(), f.size() * 2);
+      return raw;
+    };
     std::vector<uint16_t> frag;
     pack_decimator_f16(lowp, frag);
-    std::vector<float> raw(frag.size() / 2);
-    std::memcpy(raw.data(), frag.data(), frag.size() * 2);
-    if ((rc = upload(h, raw, &h->d_dec_hfrag))) return fail(rc);
+    if ((rc = upload(h, raw_of(frag), &h->d_dec_hfrag))) return fail(rc);
     pack_filterbank_f16(re, im, frag);
-    raw.assign(frag.size() / 2, 0.f);
-    std::memcpy(raw.data(), frag.data(), frag.size() * 2);
-    if ((rc = upload(h, raw, &h->d_fbh_bfrag))) return fail(rc);
-  }
-  for (int br = 0; br < 2; ++br) {
-    std::vector<uint16_t> frag;
-    pack_branch(br ? 13 : 4, br ? o1w : n1w, br ? o2w : n2w, br == 1, frag);
-    std::vector<float> raw(frag.size() / 2), f32(42, 0.f);
-    std::memcpy(raw.data(), frag.data(), frag.size() * 2);
-    const Tensor* b1 = br ? o1b : n1b;
-    for (int i = 0; i < 32; ++i) f32[i] = b1->data[i];
-    if (br)
-      for (int i = 0; i < 9; ++i) f32[32 + i] = o2w->data[i];  // onset2 taps of concat channel 0 (the note map)
-    f32[41] = br ? o2b->data[0] : n2b->data[0];
-    if ((rc = upload(h, raw, br ? &h->d_onset_wfrag : &h->d_note_wfrag)) ||
-        (rc = upload(h, f32, br ? &h->d_onset_wf32 : &h->d_note_wf32)))
-      return fail(rc);
+    if ((rc = upload(h, raw_of(frag), &h->d_fbh_bfrag))) return fail(rc);
+    pack_contour_branch(c1w, c2w, frag);
+    std::vector<float> cb32(9, 0.f);
+    for (int i = 0; i < 8; ++i) cb32[i] = c1b->data[i];
+    cb32[8] = c2b->data[0];
+    if ((rc = upload(h, raw_of(frag), &h->d_cb_wfrag)) || (rc = upload(h, cb32, &h->d_cb_wf32))) return fail(rc);
+    for (int br = 0; br < 2; ++br) {
+      pack_branch(br ? 13 : 4, br ? o1w : n1w, br ? o2w : n2w, br == 1, frag);
+      std::vector<float> f32(42, 0.f);
+      const Tensor* b1 = br ? o1b : n1b;
+      for (int i = 0; i < 32; ++i) f32[i] = b1->data[i];
+      if (br)
+        for (int i = 0; i < 9; ++i) f32[32 + i] = o2w->data[i];  // onset2 taps of concat channel 0 (the note map)
+      f32[41] = br ? o2b->data[0] : n2b->data[0];
+      if ((rc = upload(h, raw_of(frag), br ? &h->d_onset_wfrag : &h->d_note_wfrag)) ||
+          (rc = upload(h, f32, br ? &h->d_onset_wf32 : &h->d_note_wf32)))
+        return fail(rc);
+    }
   }
   pack_contour1(c1w, c1f);
   pack_onset1(o1w, o1f);
@@ -917,12 +928,8 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
       }
       break;
     case BP_STAGE_CONTOUR1:
-      if ((ok = need(bf->lp) && need(bf->mm) && need(bf->c1))) {
-        if (h->flags & BP_FLAG_F32_MFMA)
-          launch_contour1(bf->lp, bf->mm, h->d_c1_bfrag, h->d_c1_bias, bf->c1, n, h->kc, h->n_cu, s);
-        else
-          launch_contour1_f16(bf->lp, bf->mm, h->d_c1h_bfrag, h->d_c1_bias, bf->c1, n, h->kc, h->n_cu, s);
-      }
+      if ((ok = need(bf->lp) && need(bf->mm) && need(bf->c1)))
+        launch_contour1(bf->lp, bf->mm, h->d_c1_bfrag, h->d_c1_bias, bf->c1, n, h->kc, h->n_cu, s);
       break;
     case BP_STAGE_CONTOUR2:
       if ((ok = need(bf->c1) && need(bf->contour)))
@@ -945,6 +952,10 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
       break;
     case BP_STAGE_ZPACK:
       if ((ok = need(bf->lp) && need(bf->mm) && need(bf->zp))) launch_zpack(bf->lp, bf->mm, bf->zp, n, h->kc, s);
+      break;
+    case BP_STAGE_CONTOUR:
+      if ((ok = need(bf->zp) && need(bf->contour)))
+        launch_contour_branch(bf->zp, h->d_cb_wfrag, h->d_cb_wf32, bf->contour, n, h->n_cu, s);
       break;
     case BP_STAGE_NOTE:
       if ((ok = need(bf->contour) && need(bf->note)))

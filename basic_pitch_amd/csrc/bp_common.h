@@ -39,6 +39,11 @@ __host__ __device__ constexpr int harm_shift(int c) {
   return s[c];
 }
 
+// Split-precision operands: x = hi + lo / kLoScale with hi = rn_f16(x), lo = rn_f16((x - hi) * kLoScale).
+// The scale keeps the residual (<= 2^-12 |x|) inside f16's normal exponent range; products are
+// hi*hi + (lo*hi + hi*lo) * kLoUnscale, accumulated in fp32 (separate accumulators per scale).
+constexpr float kLoScale = 2048.0f, kLoUnscale = 1.0f / 2048.0f;
+
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 

@@ -15,8 +15,8 @@
 //      A = weights (resident in VGPRs for the whole kernel), B = one ds_read_b128 per lane from an LDS
 //      "image" whose 16-byte slots hold the 8 k-values a lane needs (note: 8 adjacent contour bins of one
 //      frame; onset: the 8 harmonic-stack channels of one bin).  Operands are split x = hi + lo (two
-//      f16), products hi*hi + lo*hi + hi*lo accumulate in fp32: fp32-class accuracy (see
-//      conv_contour1_f16.hip) at the f16 matrix rate.
+//      f16, lo stored * 2^11 — bp_common.h), products hi*hi + (lo*hi + hi*lo) * 2^-11 accumulate in fp32:
+//      fp32-class accuracy at the f16 matrix rate.
 //   2. The C layout of a 32x32 MFMA (col = lane & 31, row = (r&3) + 8(r>>2) + 4(lane>>5)) is, up to a
 //      permutation of K that is folded into the packed conv2 weights, exactly the B-operand layout of the
 //      next MFMA.  So bias + ReLU + hi/lo split happen in registers and feed the "tap projection"
@@ -89,7 +89,7 @@ struct OnsetBr {
 
 __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
   hi = (_Float16)v;
-  lo = (_Float16)(v - (float)hi);
+  lo = (_Float16)((v - (float)hi) * kLoScale);
 }
 
 // ---- image staging: `nrows` rows starting at `row_first` (absolute frame index, may be outside the window)
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
           f16x8 b2h[2], b2l[2];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            float v = fmaxf((acc[r] + accc[r]) + bias1[r], 0.0f);
+            float v = fmaxf((acc[r] + accc[r] * kLoUnscale) + bias1[r], 0.0f);
             v = wvalid ? v : 0.0f;
             _Float16 hi, lo;
             split_f16(v, hi, lo);
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
           for (int r = 0; r < 16; ++r) {
             const int t0 = (r & 3) + 8 * (r >> 2);  // tap for h = 0; h = 1 adds 4
             if (t0 >= NT2) continue;
-            const float v = pp[r] + ppc[r];
+            const float v = pp[r] + ppc[r] * kLoUnscale;
             if (t0 + 4 < NT2) {
               scr[(t0 + 4 * h) * kScrStride + li] = v;
             } else if (h == 0) {

@@ -1,0 +1,341 @@
+// Fused contour branch — split-precision matrix-core kernel (default path).
+//
+//   Conv2D 8->8, (3 frames x 39 bins), "same", folded BN, ReLU on the harmonic stack   (models.py:241-250,
+//   nn.py:69-88), then Conv2D 8->1, 5x5, "same", sigmoid (models.py:254-263), FlattenFreqCh (nn.py:105-119)
+//                                                                                       -> contour
+// 65 % of the whole path's FLOPs are the first convolution.  Mapping:
+//
+//   * conv1 is an implicit GEMM in transposed form on v_mfma_f32_32x32x16_f16:
+//         C1[(out channel o, bin offset j) (32 rows)][position (32 cols)] = Wt[(o,j)][k] x S[k][position]
+//     position = (frame, group of 4 adjacent bins); the rows carry a 4-bin Toeplitz expansion of the 39-tap
+//     kernel (42/39 extra taps); one k-step = 2 adjacent taps x 8 stack channels = one ds_read_b128 of the
+//     LDS image of the harmonic stack (channel-last, pre-split f16 hi | scaled lo, 4 phase planes so the
+//     32 lanes of a read are consecutive 16-byte slots).  K = 3 frames x 21 tap pairs = 63 k-steps.
+//   * the 63 A fragments (hi + lo = 126 x 16 B per lane) exceed one wave's registers, so K is split over
+//     the 4 waves (16 steps = 128 VGPRs each, resident for the whole kernel).  The partial sums are
+//     combined by a REDUCE-SCATTER through LDS: wave g ends up with the complete sums of bin offset j = g
+//     (12 values out, 12 in per lane instead of 16 + 16 for a gather to one owner).
+//   * what wave g then holds per lane — 4 channels of one position/bin — is exactly the B operand of the
+//     tap projection of the second convolution:  P[tap (25)][position] = W2t[tap][c] x relu(C1)[c][position]
+//     (K = 8 channels; hi and scaled lo share the 16 k-slots, 2 MFMAs).  conv2's 5x5 spatial sum is then
+//     25 adds per pixel: P goes through an LDS scratch and is accumulated into a ring of output rows.
+//   * a workgroup walks a time chunk of one window linearly, 32 positions at a time, with a 5-row ring of
+//     the stack image (next row prefetched from HBM while the MFMAs of the current tile run): no halo
+//     restaging, no c1 / stack tensor in HBM.  2 chunks per window, 2 workgroups per CU.
+//
+// Numerics: operands are x = hi + lo, lo stored * 2^11 (f16 exponent range, see cqt_mfma.hip); products
+// hi*hi + (lo*hi + hi*lo) * 2^-11 accumulate in fp32.  Deterministic: fixed reduction orders everywhere.
+//
+// Roofline: f16 MFMA issue.  Algorithmic work 680.0 + 18.2 MFLOP per window;
+// bytes per window: 214,656 (zp) read, 181,632 written.
+#include "bp_common.h"
+
+namespace bp {
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+constexpr int kCbThreads = 256;
+constexpr int kCbChunks = 2;
+constexpr int kCbChunkFrames = kFrames / kCbChunks;   // 86 output frames per chunk
+constexpr int kCbRows = kCbChunkFrames + 4;            // conv1 rows a chunk needs (conv2 pads 2 + 2)
+constexpr int kCbGroups = kFreqC / 4;                  // 66 four-bin groups per row
+constexpr int kCbPos = kCbRows * kCbGroups;            // 5940 positions
+constexpr int kCbTiles = (kCbPos + 31) / 32;           // 186
+constexpr int kCbQ = 76;                               // slots per phase plane
+constexpr int kCbSlots = 4 * kCbQ;                     // 304 slots per image row
+constexpr int kCbRing = 5;                             // image rows resident
+constexpr int kCbORing = 6;                            // output rows accumulating
+constexpr int kCbScrT = 136;                           // scratch floats per tap (132 pixels + skew)
+constexpr int kCbStepsTotal = 63, kCbStepsWave = 16;
+static_assert(kFrames % kCbChunks == 0, "chunks tile the window");
+static_assert(kCbTiles * 32 - kCbPos >= 1, "the 2 deferred pixels of the last tile must be padding");
+
+struct ContourParams {
+  const uint32_t* zp;   // [n][172][kZRow] pre-split z (zpack_kernel)
+  const uint4* wfrag;   // [4 waves][16 steps][hi|lo][64] conv1 A fragments, then [2][64] conv2 A fragments
+  const float* wf32;    // bias1[8], bias2
+  float* contour;       // [n][172][264]
+  int n_windows;
+};
+
+// gather one image slot (8 stack channels of bin f of frame `row`) from zp; zero outside the cropped stack
+__device__ __forceinline__ void cb_gather(const uint32_t* __restrict__ zpb, int row, int slot, uint32_t (&u)[8]) {
+  const int pl = slot / kCbQ, q = slot - pl * kCbQ;
+  const int f = 4 * q + pl - 20;
+  const bool inside = row >= 0 && row < kFrames && f >= 0 && f < kFreqC;  // crop before padding (nn.py:87)
+  const uint32_t* src = zpb + (int64_t)(inside ? row : 0) * kZRow;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int g = f + harm_shift(c);
+    const bool ok = inside && g >= 0 && g < kBins;
+    u[c] = ok ? src[ok ? g : 0] : 0u;
+  }
+}
+
+__device__ __forceinline__ void cb_put(const uint32_t (&u)[8], uint4* __restrict__ img_hi,
+                                       uint4* __restrict__ img_lo, int idx) {
+  uint4 vh, vl;
+  vh.x = (u[0] & 0xffffu) | (u[1] << 16);
+  vh.y = (u[2] & 0xffffu) | (u[3] << 16);
+  vh.z = (u[4] & 0xffffu) | (u[5] << 16);
+  vh.w = (u[6] & 0xffffu) | (u[7] << 16);
+  vl.x = (u[0] >> 16) | (u[1] & 0xffff0000u);
+  vl.y = (u[2] >> 16) | (u[3] & 0xffff0000u);
+  vl.z = (u[4] >> 16) | (u[5] & 0xffff0000u);
+  vl.w = (u[6] >> 16) | (u[7] & 0xffff0000u);
+  img_hi[idx] = vh;
+  img_lo[idx] = vl;
+}
+
+// conv1 partial sums of one wave's K slice
+template <int WAVE>
+__device__ __forceinline__ void cb_mfma(const uint4* __restrict__ img_hi, const uint4* __restrict__ img_lo,
+                                        const int (&rowslot)[3], int lo_off, int hi_off,
+                                        const uint4 (&wh)[kCbStepsWave], const uint4 (&wl)[kCbStepsWave],
+                                        f32x16& a_hh, f32x16& a_x) {
+#pragma unroll
+  for (int s = 0; s < kCbStepsWave; ++s) {
+    const int step = WAVE * kCbStepsWave + s;
+    if (step >= kCbStepsTotal) continue;
+    const int dt = step / 21, ep = step - 21 * dt;
+    const int r0 = (2 * ep + 1) & 3, q0 = (2 * ep + 1) >> 2;
+    const int slot = rowslot[dt] + ((r0 == 1) ? lo_off : hi_off) + r0 * kCbQ + q0;
+    const f16x8 bh = __builtin_bit_cast(f16x8, img_hi[slot]);
+    const f16x8 bl = __builtin_bit_cast(f16x8, img_lo[slot]);
+    const f16x8 ah = __builtin_bit_cast(f16x8, wh[s]);
+    const f16x8 al = __builtin_bit_cast(f16x8, wl[s]);
+    a_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, a_hh, 0, 0, 0);
+    a_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a_x, 0, 0, 0);
+    a_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a_x, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(kCbThreads, 2) void contour_branch_kernel(ContourParams p) {
+  __shared__ __attribute__((aligned(16))) uint4 img_hi[kCbRing * kCbSlots];
+  __shared__ __attribute__((aligned(16))) uint4 img_lo[kCbRing * kCbSlots];
+  __shared__ float xbuf[4 * 3 * 4 * 64];      // [dst wave][src slot][q][lane]
+  __shared__ float scr[25 * kCbScrT];         // P[tap][pixel + 4 (+ skew)] of the current tile
+  __shared__ float oring[kCbORing * kFreqC];  // output rows being accumulated
+  __shared__ float tailb[2 * 100];            // P of the last position of the previous tile, [tap][j]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int g = wave_id();
+  const int h = lane >> 5, li = lane & 31;
+
+  // resident conv1 A fragments of this wave's K slice, conv2 A fragments, biases
+  uint4 wh[kCbStepsWave], wl[kCbStepsWave];
+  {
+    const uint4* wp = p.wfrag + (size_t)g * kCbStepsWave * 2 * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < kCbStepsWave; ++s) {
+      wh[s] = wp[(2 * s) * 64];
+      wl[s] = wp[(2 * s + 1) * 64];
+    }
+  }
+  const uint4 a2m = p.wfrag[(size_t)4 * kCbStepsWave * 2 * 64 + lane];
+  const uint4 a2x = p.wfrag[(size_t)4 * kCbStepsWave * 2 * 64 + 64 + lane];
+  float bias1[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bias1[q] = p.wf32[2 * q + h];
+  const float bias2 = p.wf32[8];
+
+  const int n_items = p.n_windows * kCbChunks;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int b = item / kCbChunks;
+    const int T0 = (item - b * kCbChunks) * kCbChunkFrames;
+    const int T1 = T0 + kCbChunkFrames;
+    const int R0 = T0 - 2;  // first conv1 row of the chunk
+    const uint32_t* zpb = p.zp + (int64_t)b * kFrames * kZRow;
+    float* outb = p.contour + (int64_t)b * kPlaneC;
+
+    __syncthreads();  // previous item is done with LDS
+    for (int i = tid; i < kCbORing * kFreqC; i += kCbThreads) oring[i] = 0.0f;
+    for (int i = tid; i < kCbRing * kCbSlots; i += kCbThreads) {
+      const int rr = i / kCbSlots, slot = i - rr * kCbSlots;
+      const int row = R0 - 1 + rr;
+      uint32_t u[8];
+      cb_gather(zpb, row, slot, u);
+      cb_put(u, img_hi, img_lo, ((row + 5 * 8) % kCbRing) * kCbSlots + slot);
+    }
+    int next_emit = T0;
+    __syncthreads();
+
+    for (int n = 0; n <= kCbTiles; ++n) {
+      const bool compute = n < kCbTiles;  // iteration kCbTiles only flushes the last rows
+
+      // ---- prefetch the image row that becomes visible 3 rows ahead when the walk enters a new row
+      uint32_t pf0[8];
+      int stage_row = -1000;
+      if (compute && n > 0) {
+        const int rl = (32 * n) / kCbGroups;
+        if (rl != (32 * (n - 1)) / kCbGroups && rl + 3 <= kCbRows) stage_row = R0 + rl + 3;
+      }
+      const bool staging = stage_row != -1000;  // wave-uniform
+      if (staging) {
+        cb_gather(zpb, stage_row, tid, pf0);  // slots 0..255 in flight during the MFMAs; 256..303 after them
+      }
+
+      float own[4] = {0.f, 0.f, 0.f, 0.f};  // this wave's partial sums for bin offset j = g
+      bool cvalid = false;
+      if (compute) {
+        // ---- conv1: this wave's K slice of tile n
+        const int pos = 32 * n + li;
+        const int posc = pos < kCbPos ? pos : kCbPos - 1;
+        const int rr = posc / kCbGroups;
+        const int mf = posc - rr * kCbGroups;
+        const int row = R0 + rr;
+        cvalid = pos < kCbPos && row >= 0 && row < kFrames;  // conv2 zero-pads outside the window
+        int rowslot[3];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) rowslot[dt] = ((row - 1 + dt + 5 * 8) % kCbRing) * kCbSlots;
+        const int lo_off = mf + h * kCbQ;                  // tap plane 1 -> 2 (same group)
+        const int hi_off = mf + h * (1 - 3 * kCbQ);        // tap plane 3 -> 0 of the next group
+        f32x16 a_hh, a_x;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          a_hh[r] = 0.0f;
+          a_x[r] = 0.0f;
+        }
+        switch (g) {
+          case 0: cb_mfma<0>(img_hi, img_lo, rowslot, lo_off, hi_off, wh, wl, a_hh, a_x); break;
+          case 1: cb_mfma<1>(img_hi, img_lo, rowslot, lo_off, hi_off, wh, wl, a_hh, a_x); break;
+          case 2: cb_mfma<2>(img_hi, img_lo, rowslot, lo_off, hi_off, wh, wl, a_hh, a_x); break;
+          default: cb_mfma<3>(img_hi, img_lo, rowslot, lo_off, hi_off, wh, wl, a_hh, a_x); break;
+        }
+        // reduce-scatter: register r holds (o = 2(r>>2) + h, j = r & 3); bin offset j goes to wave j
+        // (g is wave-uniform: the own-partial selects are scalar-condition moves, no register indexing)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float pv = a_hh[4 * q + j] + a_x[4 * q + j] * kLoUnscale;
+            if (j == g) {
+              own[q] = pv;
+            } else {
+              const int sidx = g < j ? g : g - 1;
+              xbuf[((j * 3 + sidx) * 4 + q) * 64 + lane] = pv;
+            }
+          }
+        }
+      }
+      if (staging) {
+        const int base = ((stage_row + 5 * 8) % kCbRing) * kCbSlots;
+        cb_put(pf0, img_hi, img_lo, base + tid);
+        if (tid < kCbSlots - kCbThreads) {
+          cb_gather(zpb, stage_row, tid + kCbThreads, pf0);
+          cb_put(pf0, img_hi, img_lo, base + tid + kCbThreads);
+        }
+      }
+      __syncthreads();  // B1: partials exchanged; previous tile's accumulation into oring is complete
+
+      // ---- emit the output rows completed by the previous tile (conv1 rows <= done are fully accumulated)
+      {
+        const int done = n == 0 ? -1 : (128 * (n - 1) + 126) / kFreqC - 1;  // chunk-relative conv1 row
+        int last = R0 + done - 2;
+        last = last < T1 - 1 ? last : T1 - 1;
+        for (; next_emit <= last; ++next_emit) {
+          float* orow = oring + (next_emit % kCbORing) * kFreqC;
+          for (int f = tid; f < kFreqC; f += kCbThreads) {
+            outb[next_emit * kFreqC + f] = sigmoidf_exact(orow[f] + bias2);
+            orow[f] = 0.0f;
+          }
+        }
+      }
+      if (!compute) break;
+
+      // ---- finish conv1 for bin offset j = g, ReLU, and project onto the 25 taps of conv2
+      {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float* xp = xbuf + ((g * 3) * 4 + q) * 64 + lane;
+          const float e0 = xp[0], e1 = xp[4 * 64], e2 = xp[8 * 64];
+          // fixed summation order: source waves 0, 1, 2, 3 with the own partial in its place
+          const float x0 = g == 0 ? own[q] : e0;
+          const float x1 = g == 1 ? own[q] : (g < 1 ? e0 : e1);
+          const float x2 = g == 2 ? own[q] : (g < 2 ? e1 : e2);
+          const float x3 = g == 3 ? own[q] : e2;
+          const float s = fmaxf((((x0 + x1) + x2) + x3) + bias1[q], 0.0f);
+          v[q] = cvalid ? s : 0.0f;
+        }
+        f16x8 b2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const _Float16 hi = (_Float16)v[q];
+          b2[q] = hi;
+          b2[4 + q] = (_Float16)((v[q] - (float)hi) * kLoScale);
+        }
+        f32x16 pm, px;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pm[r] = 0.0f;
+          px[r] = 0.0f;
+        }
+        pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a2m), b2, pm, 0, 0, 0);
+        px = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a2x), b2, px, 0, 0, 0);
+        // P[tap][position li, bin g] -> scratch (pixel y = 4 li + g at index y + 4 + skew), tail copy
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t0 = (r & 3) + 8 * (r >> 2);  // tap of half h = 0; h = 1 adds 4
+          if (t0 >= 25) continue;
+          const float pv = pm[r] + px[r] * kLoUnscale;
+          const int tap = t0 + 4 * h;
+          if (t0 + 4 < 25 || h == 0) {
+            scr[tap * kCbScrT + 4 * (li + 1) + g + ((li + 1) >> 3)] = pv;
+            if (li == 31) tailb[(n & 1) * 100 + tap * 4 + g] = pv;
+          }
+        }
+        if (lane < 25) scr[lane * kCbScrT + g] = tailb[((n + 1) & 1) * 100 + lane * 4 + g];
+      }
+      __syncthreads();  // B2: P of the tile (and the previous tile's last position) is in scr
+
+      // ---- conv2 spatial sum: pixel x of the tile, x in [-2, 126) (the last 2 wait for their neighbours)
+      {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));  // keep this block's address arithmetic out of the loop-invariant set
+        const int x = (tv & 127) - 2;
+        const int part2 = tv >> 7;  // 0: frame taps 0..2, 1: frame taps 3..4
+        const int G = 128 * n + x;
+        if (G >= 0 && G < 4 * kCbPos) {
+          const int rr = G / kFreqC;
+          const int f = G - rr * kFreqC;
+          const int row = R0 + rr;
+          // physical scratch index of pixel x + dw - 2 and whether it is inside the row (zero padding)
+          int phys[5];
+          bool okw[5];
+#pragma unroll
+          for (int dw = 0; dw < 5; ++dw) {
+            const int y4 = x + dw + 2;  // (x + dw - 2) + 4, always inside the scratch row
+            phys[dw] = y4 + (y4 >> 5);
+            okw[dw] = (unsigned)(f + dw - 2) < (unsigned)kFreqC;
+          }
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const int dt = part2 ? 3 + d : d;
+            if (d == 2 && part2) continue;
+            const int t = row - dt + 2;
+            const float* sp = scr + dt * 5 * kCbScrT;
+            float s = 0.0f;
+#pragma unroll
+            for (int dw = 0; dw < 5; ++dw) {
+              const float pv = sp[dw * kCbScrT + phys[dw]];
+              s += okw[dw] ? pv : 0.0f;
+            }
+            if (t >= T0 && t < T1) oring[(t % kCbORing) * kFreqC + f] += s;
+          }
+        }
+      }
+    }
+  }
+}
+
+void launch_contour_branch(const uint32_t* zp, const void* wfrag, const float* wf32, float* contour,
+                           int n_windows, int n_cu, hipStream_t stream) {
+  ContourParams p{zp, static_cast<const uint4*>(wfrag), wf32, contour, n_windows};
+  const int items = n_windows * kCbChunks;
+  const int grid = items < 2 * n_cu ? items : 2 * n_cu;
+  hipLaunchKernelGGL(contour_branch_kernel, dim3(grid), dim3(kCbThreads), 0, stream, p);
+}
+
+}  // namespace bp

@@ -39,7 +39,6 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 // 2.4e-6 on the CQT magnitudes.  So residuals are stored multiplied by 2^11 and the taps pre-scaled by a
 // power of two; the three product classes have their own accumulators and are recombined with exact
 // power-of-two factors:  result = (hh + (lh + hl) * 2^-11) * 2^-tapshift.
-constexpr float kLoScale = 2048.0f, kLoUnscale = 1.0f / 2048.0f;
 constexpr float kDmTapUnscale = 1.0f / 1024.0f;   // decimator taps are packed * 2^10 (bp_api.hip)
 constexpr float kFmTapUnscale = 1.0f / 4096.0f;   // CQT kernels are packed * 2^12
 

@@ -29,10 +29,10 @@ def ord_decode(i: np.ndarray) -> np.ndarray:
 
 
 def zp_pack(z: np.ndarray) -> np.ndarray:
-    """z (n,172,309) fp32 -> the library's pre-split words (n,172,312): f16 hi | f16 lo << 16."""
+    """z (n,172,309) fp32 -> the library's pre-split words (n,172,312): f16 hi | f16 lo << 16, lo = (z - hi) * 2^11."""
     z = np.ascontiguousarray(z, dtype=np.float32)
     hi = z.astype(np.float16)
-    lo = (z - hi.astype(np.float32)).astype(np.float16)
+    lo = ((z - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)  # kLoScale (bp_common.h)
     u = hi.view(np.uint16).astype(np.uint32) | (lo.view(np.uint16).astype(np.uint32) << 16)
     out = np.zeros(z.shape[:2] + (_native.BP_Z_ROW,), dtype=np.uint32)
     out[:, :, : z.shape[2]] = u
@@ -44,7 +44,7 @@ def zp_unpack(zp: np.ndarray) -> np.ndarray:
     zp = np.ascontiguousarray(zp).view(np.uint32)[:, :, :309]
     hi = (zp & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float32)
     lo = (zp >> 16).astype(np.uint16).view(np.float16).astype(np.float32)
-    return hi + lo
+    return hi + lo / np.float32(2048.0)
 
 
 def pyr_pack(levels, lib) -> np.ndarray:

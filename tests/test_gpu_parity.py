@@ -120,7 +120,7 @@ def test_stage_zpack(runner, cases):
     assert np.abs(z - r32["z"]).max() <= 2e-6  # fp32 rounding of the normalisation + 2^-22 split residue
 
 
-@pytest.mark.parametrize("branch", ["note", "onset"])
+@pytest.mark.parametrize("branch", ["contour", "note", "onset"])
 def test_stage_fused_branch(runner, cases, branch):
     """The fused split-precision branches (conv -> ReLU -> conv -> sigmoid in one kernel) against the
     oracle's fp32 posteriorgrams, fed with the oracle's own inputs of that branch."""
@@ -130,34 +130,34 @@ def test_stage_fused_branch(runner, cases, branch):
     n = x.shape[0]
     if branch == "note":
         feed = {"contour": r32["contour"]}
+    elif branch == "contour":
+        feed = {"zp": zp_pack(r32["z"]).view(np.int32)}
     else:
         feed = {"zp": zp_pack(r32["z"]).view(np.int32), "note": r32["note"]}
-    got = runner.run(branch, n, feed, {branch: ((n, 172, 88), F32)})[branch]
+    width = 264 if branch == "contour" else 88
+    got = runner.run(branch, n, feed, {branch: ((n, 172, width), F32)})[branch]
     assert np.isfinite(got).all()
     d32 = np.abs(got - r32[branch]).max()
     assert d32 <= 5e-6, (branch, d32)
 
 
-def test_contour1_exact_f32_variant(cases):
-    """The exact-f32 MFMA kernel (BP_FLAG_F32_MFMA) and the default f16 hi/lo split-operand kernel
-    compute the same operator: both within 5e-5 of the fp32 oracle on c1 (values up to ~4.6), and the
-    split kernel is not further from the fp64 oracle than the f32 one by more than 2e-5."""
+def test_exact_f32_reference_path(cases):
+    """BP_FLAG_F32_MFMA runs the whole CNN on the exact-f32 kernels (f32 MFMA / VALU, intermediates in
+    HBM).  It is the A/B reference of the default split-precision path: both must sit within the same
+    distance of the fp64 oracle on the noise-like windows."""
     from basic_pitch_amd import Model
-    from stage_harness import StageRunner, ord_encode
 
     x, r32, r64 = cases
-    n = x.shape[0]
-    feed = {"lp": r32["lp"], "mm": ord_encode(r32["minmax"])}
     outs = {}
     for name, exact in (("split", False), ("f32", True)):
         m = Model(max_windows=8, exact_f32_mfma=exact)
-        outs[name] = StageRunner(m).run("contour1", n, feed, {"c1": ((n, 8, 172, 264), F32)})["c1"]
+        outs[name] = m.predict(x)
         m.close()
-    for name, got in outs.items():
-        assert np.abs(got - r32["c1"]).max() <= 5e-5 * float(np.abs(r32["c1"]).max()), name
-    e_split = np.abs(outs["split"] - r64["c1"]).max()
-    e_f32 = np.abs(outs["f32"] - r64["c1"]).max()
-    assert e_split <= e_f32 + 2e-5, (e_split, e_f32)
+    for k in ("note", "onset", "contour"):
+        e_split = np.abs(outs["split"][k][:3] - r64[k][:3]).max()
+        e_f32 = np.abs(outs["f32"][k][:3] - r64[k][:3]).max()
+        assert e_f32 <= 1e-4 and e_split <= 1e-4, (k, e_split, e_f32)
+        assert e_split <= e_f32 + 3e-5, (k, e_split, e_f32)
 
 
 def _noise_aware(got, r32, r64, floor=1e-4, factor=4.0):
