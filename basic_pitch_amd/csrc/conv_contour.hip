@@ -58,18 +58,35 @@ struct ContourParams {
   int n_windows;
 };
 
-// gather one image slot (8 stack channels of bin f of frame `row`) from zp; zero outside the cropped stack
-__device__ __forceinline__ void cb_gather(const uint32_t* __restrict__ zpb, int row, int slot, uint32_t (&u)[8]) {
+// Image slot `slot` of a row holds the 8 stack channels of bin f = 4 q + pl - 20 (pl = slot / 76, q = slot % 76).
+__device__ __forceinline__ int cb_slot_bin(int slot) {
   const int pl = slot / kCbQ, q = slot - pl * kCbQ;
-  const int f = 4 * q + pl - 20;
-  const bool inside = row >= 0 && row < kFrames && f >= 0 && f < kFreqC;  // crop before padding (nn.py:87)
-  const uint32_t* src = zpb + (int64_t)(inside ? row : 0) * kZRow;
+  return 4 * q + pl - 20;
+}
+// issue the 8 loads of one slot (addresses clamped into the row: no masking yet, so no dependent ALU and the
+// loads stay in flight together)
+__device__ __forceinline__ void cb_issue(const uint32_t* __restrict__ zrow, int f, uint32_t (&u)[8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    int g = f + harm_shift(c);
+    g = g < 0 ? 0 : (g > kZRow - 1 ? kZRow - 1 : g);
+    u[c] = zrow[g];
+  }
+}
+// zero what lies outside the cropped stack (nn.py:87: crop to 264 bins, then "same" padding) or the window
+__device__ __forceinline__ void cb_mask(int f, bool row_ok, uint32_t (&u)[8]) {
+  const bool inside = row_ok && f >= 0 && f < kFreqC;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int g = f + harm_shift(c);
-    const bool ok = inside && g >= 0 && g < kBins;
-    u[c] = ok ? src[ok ? g : 0] : 0u;
+    u[c] = (inside && g >= 0 && g < kBins) ? u[c] : 0u;
   }
+}
+__device__ __forceinline__ void cb_gather(const uint32_t* __restrict__ zpb, int row, int slot, uint32_t (&u)[8]) {
+  const bool row_ok = row >= 0 && row < kFrames;
+  const int f = cb_slot_bin(slot);
+  cb_issue(zpb + (int64_t)(row_ok ? row : 0) * kZRow, f, u);
+  cb_mask(f, row_ok, u);
 }
 
 __device__ __forceinline__ void cb_put(const uint32_t (&u)[8], uint4* __restrict__ img_hi,
@@ -92,7 +109,7 @@ template <int WAVE>
 __device__ __forceinline__ void cb_mfma(const uint4* __restrict__ img_hi, const uint4* __restrict__ img_lo,
                                         const int (&rowslot)[3], int lo_off, int hi_off,
                                         const uint4 (&wh)[kCbStepsWave], const uint4 (&wl)[kCbStepsWave],
-                                        f32x16& a_hh, f32x16& a_x) {
+                                        f32x16& a_hh, f32x16& a_lh, f32x16& a_hl) {
 #pragma unroll
   for (int s = 0; s < kCbStepsWave; ++s) {
     const int step = WAVE * kCbStepsWave + s;
@@ -104,9 +121,10 @@ __device__ __forceinline__ void cb_mfma(const uint4* __restrict__ img_hi, const 
     const f16x8 bl = __builtin_bit_cast(f16x8, img_lo[slot]);
     const f16x8 ah = __builtin_bit_cast(f16x8, wh[s]);
     const f16x8 al = __builtin_bit_cast(f16x8, wl[s]);
+    // three independent accumulation chains: no back-to-back dependent MFMAs
     a_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, a_hh, 0, 0, 0);
-    a_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a_x, 0, 0, 0);
-    a_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a_x, 0, 0, 0);
+    a_lh = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a_lh, 0, 0, 0);
+    a_hl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a_hl, 0, 0, 0);
   }
 }
 
@@ -137,8 +155,12 @@ __global__ __launch_bounds__(kCbThreads, 2) void contour_branch_kernel(ContourPa
   const uint4 a2x = p.wfrag[(size_t)4 * kCbStepsWave * 2 * 64 + 64 + lane];
   float bias1[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) bias1[q] = p.wf32[2 * q + h];
-  const float bias2 = p.wf32[8];
+  for (int q = 0; q < 4; ++q) {
+    bias1[q] = p.wf32[2 * q + h];
+    asm volatile("" : "+v"(bias1[q]));  // pin in a register: a reload inside the loop would serialise on vmcnt
+  }
+  float bias2 = p.wf32[8];
+  asm volatile("" : "+v"(bias2));
 
   const int n_items = p.n_windows * kCbChunks;
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -159,22 +181,31 @@ __global__ __launch_bounds__(kCbThreads, 2) void contour_branch_kernel(ContourPa
       cb_put(u, img_hi, img_lo, ((row + 5 * 8) % kCbRing) * kCbSlots + slot);
     }
     int next_emit = T0;
+    int pending_row = -1000;
     __syncthreads();
 
     for (int n = 0; n <= kCbTiles; ++n) {
       const bool compute = n < kCbTiles;  // iteration kCbTiles only flushes the last rows
 
-      // ---- prefetch the image row that becomes visible 3 rows ahead when the walk enters a new row
-      uint32_t pf0[8];
-      int stage_row = -1000;
-      if (compute && n > 0) {
+      // ---- image row that becomes visible 3 rows ahead when the walk enters a new row: slots 0..255 during
+      // this tile, slots 256..303 during the next one (the row is first read two tiles later at the earliest)
+      uint32_t pf[8];
+      int stage_row = -1000, stage_slot = 0;
+      if (pending_row != -1000) {
+        stage_row = pending_row;
+        stage_slot = tid + kCbThreads;
+        pending_row = -1000;
+      } else if (compute && n > 0) {
         const int rl = (32 * n) / kCbGroups;
-        if (rl != (32 * (n - 1)) / kCbGroups && rl + 3 <= kCbRows) stage_row = R0 + rl + 3;
+        if (rl != (32 * (n - 1)) / kCbGroups && rl + 3 <= kCbRows) {
+          stage_row = R0 + rl + 3;
+          stage_slot = tid;
+          pending_row = stage_row;
+        }
       }
-      const bool staging = stage_row != -1000;  // wave-uniform
-      if (staging) {
-        cb_gather(zpb, stage_row, tid, pf0);  // slots 0..255 in flight during the MFMAs; 256..303 after them
-      }
+      const bool staging = stage_row != -1000 && stage_slot < kCbSlots;
+      const bool stage_row_ok = stage_row >= 0 && stage_row < kFrames;
+      const int stage_f = cb_slot_bin(stage_slot);
 
       float own[4] = {0.f, 0.f, 0.f, 0.f};  // this wave's partial sums for bin offset j = g
       bool cvalid = false;
@@ -191,17 +222,18 @@ __global__ __launch_bounds__(kCbThreads, 2) void contour_branch_kernel(ContourPa
         for (int dt = 0; dt < 3; ++dt) rowslot[dt] = ((row - 1 + dt + 5 * 8) % kCbRing) * kCbSlots;
         const int lo_off = mf + h * kCbQ;                  // tap plane 1 -> 2 (same group)
         const int hi_off = mf + h * (1 - 3 * kCbQ);        // tap plane 3 -> 0 of the next group
-        f32x16 a_hh, a_x;
+        f32x16 a_hh, a_lh, a_hl;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           a_hh[r] = 0.0f;
-          a_x[r] = 0.0f;
+          a_lh[r] = 0.0f;
+          a_hl[r] = 0.0f;
         }
         switch (g) {
-          case 0: cb_mfma<0>(img_hi, img_lo, rowslot, lo_off, hi_off, wh, wl, a_hh, a_x); break;
-          case 1: cb_mfma<1>(img_hi, img_lo, rowslot, lo_off, hi_off, wh, wl, a_hh, a_x); break;
-          case 2: cb_mfma<2>(img_hi, img_lo, rowslot, lo_off, hi_off, wh, wl, a_hh, a_x); break;
-          default: cb_mfma<3>(img_hi, img_lo, rowslot, lo_off, hi_off, wh, wl, a_hh, a_x); break;
+          case 0: cb_mfma<0>(img_hi, img_lo, rowslot, lo_off, hi_off, wh, wl, a_hh, a_lh, a_hl); break;
+          case 1: cb_mfma<1>(img_hi, img_lo, rowslot, lo_off, hi_off, wh, wl, a_hh, a_lh, a_hl); break;
+          case 2: cb_mfma<2>(img_hi, img_lo, rowslot, lo_off, hi_off, wh, wl, a_hh, a_lh, a_hl); break;
+          default: cb_mfma<3>(img_hi, img_lo, rowslot, lo_off, hi_off, wh, wl, a_hh, a_lh, a_hl); break;
         }
         // reduce-scatter: register r holds (o = 2(r>>2) + h, j = r & 3); bin offset j goes to wave j
         // (g is wave-uniform: the own-partial selects are scalar-condition moves, no register indexing)
@@ -209,7 +241,7 @@ __global__ __launch_bounds__(kCbThreads, 2) void contour_branch_kernel(ContourPa
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float pv = a_hh[4 * q + j] + a_x[4 * q + j] * kLoUnscale;
+            const float pv = a_hh[4 * q + j] + (a_lh[4 * q + j] + a_hl[4 * q + j]) * kLoUnscale;
             if (j == g) {
               own[q] = pv;
             } else {
@@ -217,14 +249,6 @@ __global__ __launch_bounds__(kCbThreads, 2) void contour_branch_kernel(ContourPa
               xbuf[((j * 3 + sidx) * 4 + q) * 64 + lane] = pv;
             }
           }
-        }
-      }
-      if (staging) {
-        const int base = ((stage_row + 5 * 8) % kCbRing) * kCbSlots;
-        cb_put(pf0, img_hi, img_lo, base + tid);
-        if (tid < kCbSlots - kCbThreads) {
-          cb_gather(zpb, stage_row, tid + kCbThreads, pf0);
-          cb_put(pf0, img_hi, img_lo, base + tid + kCbThreads);
         }
       }
       __syncthreads();  // B1: partials exchanged; previous tile's accumulation into oring is complete
@@ -243,6 +267,9 @@ __global__ __launch_bounds__(kCbThreads, 2) void contour_branch_kernel(ContourPa
         }
       }
       if (!compute) break;
+      // loads of the image row to stage: issued here (the conv1 accumulators are dead, registers are free), in
+      // flight under the reduction, projection, barrier B2 and the spatial sum; written to LDS at the end
+      if (staging) cb_issue(zpb + (int64_t)(stage_row_ok ? stage_row : 0) * kZRow, stage_f, pf);
 
       // ---- finish conv1 for bin offset j = g, ReLU, and project onto the 25 taps of conv2
       {
@@ -325,6 +352,10 @@ __global__ __launch_bounds__(kCbThreads, 2) void contour_branch_kernel(ContourPa
             if (t >= T0 && t < T1) oring[(t % kCbORing) * kFreqC + f] += s;
           }
         }
+      }
+      if (staging) {
+        cb_mask(stage_f, stage_row_ok, pf);
+        cb_put(pf, img_hi, img_lo, ((stage_row + 5 * 8) % kCbRing) * kCbSlots + stage_slot);
       }
     }
   }
