@@ -65,6 +65,35 @@ class bp_stage_buffers(C.Structure):
     ]
 
 
+class bp_note_params(C.Structure):
+    _fields_ = [
+        ("onset_threshold", C.c_double),
+        ("frame_threshold", C.c_double),
+        ("min_freq_hz", C.c_double),
+        ("max_freq_hz", C.c_double),
+        ("min_note_len", C.c_int32),
+        ("infer_onsets", C.c_int32),
+        ("melodia_trick", C.c_int32),
+        ("include_pitch_bends", C.c_int32),
+        ("energy_tol", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class bp_note_event(C.Structure):
+    _fields_ = [
+        ("start_s", C.c_double),
+        ("end_s", C.c_double),
+        ("bend_offset", C.c_int64),
+        ("start_frame", C.c_int32),
+        ("end_frame", C.c_int32),
+        ("pitch_midi", C.c_int32),
+        ("n_bends", C.c_int32),
+        ("amplitude", C.c_float),
+        ("reserved", C.c_int32),
+    ]
+
+
 # every symbol include/basic_pitch_amd.h declares (tests check they are all exported)
 EXPORTED_SYMBOLS = [
     "bp_create",
@@ -82,6 +111,9 @@ EXPORTED_SYMBOLS = [
     "bp_run_stage",
     "bp_pyramid_layout",
     "bp_version",
+    "bp_note_params_default",
+    "bp_notes_decode",
+    "bp_notes_last_error",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -133,6 +165,14 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bp_pyramid_layout.restype = C.c_int
     lib.bp_version.argtypes = []
     lib.bp_version.restype = C.c_char_p
+    lib.bp_note_params_default.argtypes = [C.POINTER(bp_note_params)]
+    lib.bp_note_params_default.restype = None
+    lib.bp_notes_decode.argtypes = [
+        vp, vp, vp, i64, C.POINTER(bp_note_params), vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64)
+    ]
+    lib.bp_notes_decode.restype = C.c_int
+    lib.bp_notes_last_error.argtypes = []
+    lib.bp_notes_last_error.restype = C.c_char_p
     if path is None:
         _lib = lib
     return lib

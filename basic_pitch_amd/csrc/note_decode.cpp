@@ -1,0 +1,318 @@
+// Note decoding: posteriorgrams -> note events (host C++).
+//
+// Replaces, behind the C ABI entry point bp_notes_decode (include/basic_pitch_amd.h), the Python loops of
+// basic_pitch/note_creation.py (spotify/basic-pitch v0.4.0):
+//   constrain_frequency            note_creation.py:314-343
+//   get_infered_onsets             note_creation.py:289-311
+//   output_to_notes_polyphonic     note_creation.py:360-511   (melodia trick: 452-509)
+//   get_pitch_bends                note_creation.py:182-219
+//   model_frames_to_time           note_creation.py:346-357
+//   model_output_to_notes          note_creation.py:52-116    (without the PrettyMIDI object)
+//
+// The reference is single-threaded numpy/Python: 9.5 ms for the 9-second test clip, 2.07 s for a 3-minute
+// track and super-linear, because every melodia iteration rescans the whole matrix for its maximum
+// (np.max + np.argmax, note_creation.py:452-453).  Here the maximum comes from a tournament tree with the
+// same tie-break (lowest flat index), so an iteration costs O(log n) per cell it zeroes.
+//
+// Bit-exactness contract (tests/test_note_decode.py): same events, in the same order, as the numpy
+// restatement oracle/note_oracle.py — which reproduces the reference's golden note events — including the
+// float32 pairwise summation numpy uses for np.mean (amplitudes), float64 everywhere the reference is
+// float64, round-half-even where it calls np.round.
+#include "../../include/basic_pitch_amd.h"
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int kF = BP_N_FREQ_NOTE;      // 88
+constexpr int kFC = BP_N_FREQ_CONTOUR;  // 264
+constexpr int kMidiOffset = 21;         // note_creation.py:40
+constexpr int kMaxFreqIdx = 87;         // note_creation.py:43
+
+// numpy's pairwise summation for float32 (numpy/_core/src/umath/loops_utils.h.src, *_pairwise_sum):
+// the reduction np.mean / np.add.reduce run on a (strided) 1-D float32 view.
+float pairwise_sum_f32(const float* a, int64_t n, int64_t stride) {
+  if (n < 8) {
+    float res = 0.0f;
+    for (int64_t i = 0; i < n; ++i) res += a[i * stride];
+    return res;
+  }
+  if (n <= 128) {
+    float r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j * stride];
+    int64_t i;
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[(i + j) * stride];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i * stride];
+    return res;
+  }
+  int64_t n2 = n / 2;
+  n2 -= n2 % 8;
+  return pairwise_sum_f32(a, n2, stride) + pairwise_sum_f32(a + n2 * stride, n - n2, stride);
+}
+
+// np.mean of frames[a:b, f] for a float32 matrix: float32 accumulator, float32 division
+float mean_f32(const float* frames, int64_t a, int64_t b, int f) {
+  const int64_t n = b - a;
+  const float s = 0.0f + pairwise_sum_f32(frames + a * kF + f, n, kF);
+  return s / (float)n;
+}
+
+// np.round (round half to even) of a double, as an int
+int64_t round_half_even(double v) { return (int64_t)std::nearbyint(v); }
+
+// np.maximum: NaN if either operand is NaN
+inline double np_maximum(double a, double b) {
+  if (std::isnan(a) || std::isnan(b)) return std::nan("");
+  return a > b ? a : b;
+}
+
+// Tournament tree over a double array: index of the maximum, ties -> lowest index (np.argmax).
+class MaxTree {
+ public:
+  explicit MaxTree(std::vector<double>& v) : val_(v), n_((int64_t)v.size()) {
+    size_ = 1;
+    while (size_ < n_) size_ <<= 1;
+    node_.assign(2 * size_, -1);
+    for (int64_t i = 0; i < n_; ++i) node_[size_ + i] = (int32_t)i;
+    for (int64_t i = size_ - 1; i >= 1; --i) node_[i] = better(node_[2 * i], node_[2 * i + 1]);
+  }
+  int32_t argmax() const { return node_[1]; }
+  void set_zero(int64_t idx) {
+    if (val_[idx] == 0.0) return;
+    val_[idx] = 0.0;
+    for (int64_t i = (size_ + idx) >> 1; i >= 1; i >>= 1) node_[i] = better(node_[2 * i], node_[2 * i + 1]);
+  }
+
+ private:
+  int32_t better(int32_t a, int32_t b) const {
+    if (a < 0) return b;
+    if (b < 0) return a;
+    return (val_[b] > val_[a]) ? b : a;  // a < b always (left child first): ties keep the lower index
+  }
+  std::vector<double>& val_;
+  int64_t n_, size_;
+  std::vector<int32_t> node_;
+};
+
+thread_local std::string g_notes_error;
+
+}  // namespace
+
+extern "C" {
+
+const char* bp_notes_last_error(void) { return g_notes_error.c_str(); }
+
+void bp_note_params_default(bp_note_params* p) {
+  if (!p) return;
+  p->onset_threshold = 0.5;                                         // inference.py:434
+  p->frame_threshold = 0.3;                                         // inference.py:435
+  p->min_note_len = 11;                                             // note_creation.py:45 DEFAULT_MIN_NOTE_LEN
+  p->infer_onsets = 1;
+  p->melodia_trick = 1;
+  p->include_pitch_bends = 1;
+  p->energy_tol = 11;                                               // note_creation.py:46
+  p->min_freq_hz = 0.0;
+  p->max_freq_hz = 0.0;
+}
+
+int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_frames,
+                    const bp_note_params* prm, bp_note_event* events, int64_t max_events, int32_t* bends,
+                    int64_t max_bends, int64_t* n_events_out, int64_t* n_bends_out) {
+  if (!prm || !n_events_out || !n_bends_out || n_frames < 0 || (n_frames > 0 && (!note || !onset || !contour))) {
+    g_notes_error = "bp_notes_decode: null pointer or negative frame count";
+    return BP_ERR_INVALID_ARG;
+  }
+  if (n_frames > (int64_t)1 << 24) {
+    g_notes_error = "bp_notes_decode: more than 2^24 frames";
+    return BP_ERR_INVALID_ARG;
+  }
+  *n_events_out = 0;
+  *n_bends_out = 0;
+  const int64_t T = n_frames;
+  if (T == 0) return BP_OK;
+
+  // ---- constrain_frequency (in place, note_creation.py:338-341)
+  int64_t min_idx = 0, max_idx = kF;
+  if (prm->min_freq_hz > 0.0)
+    min_idx = round_half_even(12.0 * (std::log2(prm->min_freq_hz) - std::log2(440.0)) + 69.0 - kMidiOffset);
+  if (prm->max_freq_hz > 0.0)
+    max_idx = round_half_even(12.0 * (std::log2(prm->max_freq_hz) - std::log2(440.0)) + 69.0 - kMidiOffset);
+  {
+    // numpy slice semantics: [:a] and [b:] with negative / overshooting bounds
+    auto norm = [](int64_t i) { return i < 0 ? (i + kF < 0 ? 0 : i + kF) : (i > kF ? kF : i); };
+    const int64_t lo = norm(min_idx), hi = norm(max_idx);
+    for (int64_t t = 0; t < T; ++t) {
+      for (int64_t f = 0; f < lo; ++f) note[t * kF + f] = onset[t * kF + f] = 0.0f;
+      for (int64_t f = hi; f < kF; ++f) note[t * kF + f] = onset[t * kF + f] = 0.0f;
+    }
+  }
+
+  // ---- onsets (float64 from here on when inferred, note_creation.py:289-311)
+  std::vector<double> on((size_t)T * kF);
+  if (prm->infer_onsets) {
+    float max_on = onset[0];
+    for (int64_t i = 1; i < T * kF; ++i) max_on = (onset[i] > max_on || std::isnan(onset[i])) ? onset[i] : max_on;
+    std::vector<double> fd((size_t)T * kF, 0.0);
+    double max_fd = 0.0;  // rows 0, 1 are zero, every entry is >= 0
+    for (int64_t t = 2; t < T; ++t)
+      for (int f = 0; f < kF; ++f) {
+        const double d1 = (double)note[t * kF + f] - (double)note[(t - 1) * kF + f];
+        const double d2 = (double)note[t * kF + f] - (double)note[(t - 2) * kF + f];
+        double d = d1 < d2 ? d1 : d2;
+        if (d < 0) d = 0;
+        fd[t * kF + f] = d;
+        if (d > max_fd) max_fd = d;
+      }
+    for (int64_t i = 0; i < T * kF; ++i) {
+      const double scaled = ((double)max_on * fd[i]) / max_fd;  // 0/0 -> NaN when nothing rises, like numpy
+      on[i] = np_maximum((double)onset[i], scaled);
+    }
+  } else {
+    for (int64_t i = 0; i < T * kF; ++i) on[i] = (double)onset[i];
+  }
+
+  struct Raw {
+    int32_t start, end, pitch;
+    float amp;
+  };
+  std::vector<Raw> notes;
+
+  // ---- peak picking (scipy.signal.argrelmax, axis 0) + threshold, visited backwards in time
+  std::vector<double> energy((size_t)T * kF);
+  for (int64_t i = 0; i < T * kF; ++i) energy[i] = (double)note[i];
+  const int energy_tol = prm->energy_tol;
+  const double frame_thresh = prm->frame_threshold, onset_thresh = prm->onset_threshold;
+  for (int64_t t = T - 2; t >= 1; --t) {
+    for (int f = kF - 1; f >= 0; --f) {
+      const double v = on[t * kF + f];
+      if (!(v > on[(t - 1) * kF + f] && v > on[(t + 1) * kF + f])) continue;
+      if (!(v >= onset_thresh)) continue;
+      const int64_t start = t;
+      if (start >= T - 1) continue;
+      int64_t i = start + 1;
+      int k = 0;
+      while (i < T - 1 && k < energy_tol) {
+        if (energy[i * kF + f] < frame_thresh)
+          ++k;
+        else
+          k = 0;
+        ++i;
+      }
+      i -= k;
+      if (i - start <= prm->min_note_len) continue;
+      for (int64_t r = start; r < i; ++r) {
+        energy[r * kF + f] = 0;
+        if (f < kMaxFreqIdx) energy[r * kF + f + 1] = 0;
+        if (f > 0) energy[r * kF + f - 1] = 0;
+      }
+      notes.push_back({(int32_t)start, (int32_t)i, f + kMidiOffset, mean_f32(note, start, i, f)});
+    }
+  }
+
+  // ---- melodia trick (note_creation.py:449-509)
+  if (prm->melodia_trick) {
+    MaxTree tree(energy);
+    while (true) {
+      const int32_t am = tree.argmax();
+      if (!(energy[am] > frame_thresh)) break;
+      const int64_t i_mid = am / kF;
+      const int f = am % kF;
+      tree.set_zero(am);
+      auto wipe = [&](int64_t r) {
+        tree.set_zero(r * kF + f);
+        if (f < kMaxFreqIdx) tree.set_zero(r * kF + f + 1);
+        if (f > 0) tree.set_zero(r * kF + f - 1);
+      };
+      int64_t i = i_mid + 1;
+      int k = 0;
+      while (i < T - 1 && k < energy_tol) {
+        if (energy[i * kF + f] < frame_thresh)
+          ++k;
+        else
+          k = 0;
+        wipe(i);
+        ++i;
+      }
+      const int64_t i_end = i - 1 - k;
+      i = i_mid - 1;
+      k = 0;
+      while (i > 0 && k < energy_tol) {
+        if (energy[i * kF + f] < frame_thresh)
+          ++k;
+        else
+          k = 0;
+        wipe(i);
+        --i;
+      }
+      const int64_t i_start = i + 1 + k;
+      if (i_end - i_start <= prm->min_note_len) continue;
+      notes.push_back({(int32_t)i_start, (int32_t)i_end, f + kMidiOffset, mean_f32(note, i_start, i_end, f)});
+    }
+  }
+
+  // ---- pitch bends (note_creation.py:182-219) and frame times (346-357)
+  int64_t total_bends = 0;
+  if (prm->include_pitch_bends)
+    for (const Raw& r : notes) total_bends += r.end - r.start;
+  *n_events_out = (int64_t)notes.size();
+  *n_bends_out = total_bends;
+  if ((int64_t)notes.size() > max_events || total_bends > max_bends || (notes.size() && !events) ||
+      (total_bends && !bends)) {
+    g_notes_error = "bp_notes_decode: output buffers too small (required sizes returned)";
+    return BP_ERR_INVALID_ARG;
+  }
+  double gauss[51];
+  for (int i = 0; i < 51; ++i) {
+    const double n = (double)i - 25.0;
+    gauss[i] = std::exp(-(n * n) / (2.0 * 5.0 * 5.0));  // scipy.signal.windows.gaussian(51, std=5)
+  }
+  const double window_offset = (256.0 / 22050.0) * (172.0 - (43844.0 / 256.0)) + 0.0018;
+  auto frame_time = [&](int64_t fr) {
+    const double original = (double)(fr * 256) / 22050.0;
+    const double window_number = std::floor((double)fr / 172.0);
+    return original - (window_offset * window_number);
+  };
+  int64_t bo = 0;
+  for (size_t e = 0; e < notes.size(); ++e) {
+    const Raw& r = notes[e];
+    bp_note_event& ev = events[e];
+    ev.start_frame = r.start;
+    ev.end_frame = r.end;
+    ev.start_s = frame_time(r.start);
+    ev.end_s = frame_time(r.end);
+    ev.pitch_midi = r.pitch;
+    ev.amplitude = r.amp;
+    ev.bend_offset = bo;
+    ev.n_bends = 0;
+    if (!prm->include_pitch_bends) continue;
+    const double pitch_hz = 440.0 * std::pow(2.0, ((double)r.pitch - 69.0) / 12.0);
+    const int64_t freq_idx = round_half_even(12.0 * 3.0 * std::log2(pitch_hz / 27.5));
+    const int64_t tol = 25;
+    const int64_t f0 = freq_idx - tol > 0 ? freq_idx - tol : 0;
+    const int64_t f1 = freq_idx + tol + 1 < kFC ? freq_idx + tol + 1 : kFC;
+    const int64_t g0 = tol - freq_idx > 0 ? tol - freq_idx : 0;
+    const int64_t pb_shift = tol - g0;
+    for (int64_t t = r.start; t < r.end; ++t) {
+      int64_t best = 0;
+      double bestv = (double)contour[t * kFC + f0] * gauss[g0];
+      for (int64_t j = 1; j < f1 - f0; ++j) {
+        const double v = (double)contour[t * kFC + f0 + j] * gauss[g0 + j];
+        if (v > bestv || (std::isnan(v) && !std::isnan(bestv))) {  // np.argmax: first maximum, NaN wins
+          bestv = v;
+          best = j;
+        }
+      }
+      bends[bo++] = (int32_t)(best - pb_shift);
+    }
+    ev.n_bends = (int32_t)(r.end - r.start);
+  }
+  return BP_OK;
+}
+
+}  // extern "C"

@@ -13,9 +13,11 @@ Both produce the values the per-window loop would.
 """
 from __future__ import annotations
 
+import csv
 import ctypes as C
 import enum
 import json
+import os
 import pathlib
 from typing import Any, Dict, Iterable, List, Optional, Tuple, Union
 
@@ -23,6 +25,7 @@ import numpy as np
 
 from . import _native
 from . import audio as _audio
+from . import note_creation as infer
 from .constants import (
     ANNOTATIONS_FPS,
     AUDIO_N_SAMPLES,
@@ -302,3 +305,129 @@ def run_inference_windowed(
         k: unwrap_output(np.concatenate(output[k]), audio_original_length, n_overlapping_frames, hop_size)
         for k in output
     }
+
+
+class OutputExtensions(enum.Enum):
+    MIDI = "mid"
+    MODEL_OUTPUT_NPZ = "npz"
+    MIDI_SONIFICATION = "wav"
+    NOTE_EVENTS = "csv"
+
+
+def verify_input_path(audio_path: Union[pathlib.Path, str]) -> None:
+    """inference.py:340-354."""
+    if not os.path.isfile(audio_path):
+        raise ValueError(f"{audio_path} is not a file path.")
+
+
+def verify_output_dir(output_dir: Union[pathlib.Path, str]) -> None:
+    """inference.py:357-371."""
+    if not os.path.isdir(output_dir):
+        raise ValueError(f"{output_dir} is not a directory.")
+
+
+def build_output_path(
+    audio_path: Union[pathlib.Path, str], output_directory: Union[pathlib.Path, str], output_type: OutputExtensions
+) -> pathlib.Path:
+    """inference.py:374-406: <dir>/<stem>_basic_pitch.<ext>; IOError if it already exists."""
+    basename, _ = os.path.splitext(os.path.basename(str(audio_path)))
+    output_path = pathlib.Path(output_directory) / f"{basename}_basic_pitch.{output_type.value}"
+    if output_path.exists():
+        raise IOError(f"{output_path} already exists and would be overwritten. Skipping output files for {audio_path}.")
+    return output_path
+
+
+def save_note_events(note_events: List["infer.NoteEvent"], save_path: Union[pathlib.Path, str]) -> None:
+    """inference.py:409-428: CSV with start_time_s, end_time_s, pitch_midi, velocity, pitch_bend..."""
+    with open(save_path, "w") as fhandle:
+        writer = csv.writer(fhandle, delimiter=",")
+        writer.writerow(["start_time_s", "end_time_s", "pitch_midi", "velocity", "pitch_bend"])
+        for start_time, end_time, note_number, amplitude, pitch_bend in note_events:
+            row = [start_time, end_time, note_number, int(np.round(DEFAULT_MIDI_VELOCITY_SCALE * amplitude))]
+            if pitch_bend:
+                row.extend(pitch_bend)
+            writer.writerow(row)
+
+
+def predict(
+    audio_path: Union[pathlib.Path, str],
+    model_or_model_path: Union[Model, pathlib.Path, str] = ICASSP_2022_MODEL_PATH,
+    onset_threshold: float = DEFAULT_ONSET_THRESHOLD,
+    frame_threshold: float = DEFAULT_FRAME_THRESHOLD,
+    minimum_note_length: float = DEFAULT_MINIMUM_NOTE_LENGTH_MS,
+    minimum_frequency: Optional[float] = None,
+    maximum_frequency: Optional[float] = None,
+    multiple_pitch_bends: bool = False,
+    melodia_trick: bool = True,
+    debug_file: Optional[pathlib.Path] = None,
+    midi_tempo: float = DEFAULT_MINIMUM_MIDI_TEMPO,
+) -> Tuple[Dict[str, np.ndarray], "infer.pretty_midi.PrettyMIDI", List["infer.NoteEvent"]]:
+    """Run a single prediction (inference.py:431-506): (model_output, midi_data, note_events)."""
+    model_output = run_inference(audio_path, model_or_model_path, debug_file)
+    min_note_len = int(np.round(minimum_note_length / 1000 * (AUDIO_SAMPLE_RATE / FFT_HOP)))
+    midi_data, note_events = infer.model_output_to_notes(
+        model_output,
+        onset_thresh=onset_threshold,
+        frame_thresh=frame_threshold,
+        min_note_len=min_note_len,
+        min_freq=minimum_frequency,
+        max_freq=maximum_frequency,
+        multiple_pitch_bends=multiple_pitch_bends,
+        melodia_trick=melodia_trick,
+        midi_tempo=midi_tempo,
+    )
+    if debug_file:
+        with open(debug_file) as f:
+            debug_data = json.load(f)
+        with open(debug_file, "w") as f:
+            json.dump(
+                {
+                    **debug_data,
+                    "min_note_length": min_note_len,
+                    "onset_thresh": onset_threshold,
+                    "frame_thresh": frame_threshold,
+                    "estimated_notes": [
+                        (float(s0), float(s1), int(pitch), float(amp), [int(b) for b in pb] if pb else None)
+                        for s0, s1, pitch, amp, pb in note_events
+                    ],
+                },
+                f,
+            )
+    return model_output, midi_data, note_events
+
+
+def predict_and_save(
+    audio_path_list,
+    output_directory: Union[pathlib.Path, str],
+    save_midi: bool,
+    sonify_midi: bool,
+    save_model_outputs: bool,
+    save_notes: bool,
+    model_or_model_path: Union[Model, str, pathlib.Path] = ICASSP_2022_MODEL_PATH,
+    onset_threshold: float = DEFAULT_ONSET_THRESHOLD,
+    frame_threshold: float = DEFAULT_FRAME_THRESHOLD,
+    minimum_note_length: float = DEFAULT_MINIMUM_NOTE_LENGTH_MS,
+    minimum_frequency: Optional[float] = None,
+    maximum_frequency: Optional[float] = None,
+    multiple_pitch_bends: bool = False,
+    melodia_trick: bool = True,
+    debug_file: Optional[pathlib.Path] = None,
+    sonification_samplerate: int = DEFAULT_SONIFICATION_SAMPLERATE,
+    midi_tempo: float = DEFAULT_MINIMUM_MIDI_TEMPO,
+) -> None:
+    """inference.py:509-618 (MIDI sonification — pretty_midi.synthesize — is out of scope and raises)."""
+    if sonify_midi:
+        raise NotImplementedError("MIDI sonification (pretty_midi.synthesize) is not part of this backend")
+    model = model_or_model_path if isinstance(model_or_model_path, Model) else Model(model_or_model_path)
+    for audio_path in audio_path_list:
+        model_output, midi_data, note_events = predict(
+            pathlib.Path(audio_path), model, onset_threshold, frame_threshold, minimum_note_length,
+            minimum_frequency, maximum_frequency, multiple_pitch_bends, melodia_trick, debug_file, midi_tempo,
+        )
+        if save_model_outputs:
+            np.savez(build_output_path(audio_path, output_directory, OutputExtensions.MODEL_OUTPUT_NPZ),
+                     basic_pitch_model_output=model_output)
+        if save_midi:
+            midi_data.write(str(build_output_path(audio_path, output_directory, OutputExtensions.MIDI)))
+        if save_notes:
+            save_note_events(note_events, build_output_path(audio_path, output_directory, OutputExtensions.NOTE_EVENTS))

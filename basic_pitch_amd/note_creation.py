@@ -1,0 +1,153 @@
+"""Host-side mirror of `basic_pitch/note_creation.py` (spotify/basic-pitch v0.4.0) for the consumer of the
+hot path: posteriorgrams -> note events -> MIDI.  Same names, arguments and return values; the loops run in
+libbasicpitch_amd.so (`bp_notes_decode`, csrc/note_decode.cpp) instead of Python — 2 s of single-core Python
+per 3-minute track in the reference.
+
+The PrettyMIDI object is the stand-in of `basic_pitch_amd.midi` (pretty_midi is not installable here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import defaultdict
+from typing import DefaultDict, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _native
+from . import midi as pretty_midi
+from .constants import (
+    ANNOT_N_FRAMES,
+    AUDIO_N_SAMPLES,
+    AUDIO_SAMPLE_RATE,
+    CONTOURS_BINS_PER_SEMITONE,
+    FFT_HOP,
+    N_FREQ_BINS_CONTOURS,
+    N_FREQ_BINS_NOTES,
+)
+
+MIDI_OFFSET = 21
+N_PITCH_BEND_TICKS = 8192
+MAX_FREQ_IDX = 87
+DEFAULT_MIN_NOTE_LEN = 11
+ENERGY_TOLERANCE = 11
+MAGIC_ALIGNMENT_OFFSET = 0.0018
+MIDI_VELOCITY_SCALE = 127
+PITCH_BEND_SCALE = 4096
+
+NoteEvent = Tuple[float, float, int, float, Optional[List[int]]]
+
+
+def _decode(
+    frames: np.ndarray, onsets: np.ndarray, contours: np.ndarray, onset_thresh: float, frame_thresh: float,
+    min_note_len: int, infer_onsets: bool, max_freq: Optional[float], min_freq: Optional[float],
+    melodia_trick: bool, energy_tol: int, include_pitch_bends: bool,
+):
+    """One call into bp_notes_decode; returns the filled event / bend arrays."""
+    lib = _native.load_library()
+    for name, a, w in (("note", frames, N_FREQ_BINS_NOTES), ("onset", onsets, N_FREQ_BINS_NOTES), ("contour", contours, N_FREQ_BINS_CONTOURS)):
+        if not (isinstance(a, np.ndarray) and a.ndim == 2 and a.shape[1] == w and a.dtype == np.float32 and a.flags.c_contiguous):
+            raise ValueError(f"{name}: expected a C-contiguous float32 array of shape (T, {w})")
+    if not (frames.flags.writeable and onsets.flags.writeable):
+        raise ValueError("note / onset arrays must be writable (constrain_frequency zeroes them in place)")
+    T = frames.shape[0]
+    if onsets.shape[0] != T or contours.shape[0] != T:
+        raise ValueError("note, onset and contour must have the same number of frames")
+    prm = _native.bp_note_params()
+    lib.bp_note_params_default(C.byref(prm))
+    prm.onset_threshold, prm.frame_threshold = float(onset_thresh), float(frame_thresh)
+    prm.min_note_len, prm.energy_tol = int(min_note_len), int(energy_tol)
+    prm.infer_onsets, prm.melodia_trick = int(bool(infer_onsets)), int(bool(melodia_trick))
+    prm.include_pitch_bends = int(bool(include_pitch_bends))
+    prm.min_freq_hz = float(min_freq) if min_freq is not None else 0.0
+    prm.max_freq_hz = float(max_freq) if max_freq is not None else 0.0
+    n_ev, n_b = C.c_int64(0), C.c_int64(0)
+    cap_ev, cap_b = max(256, T // 4), max(4096, 4 * T)
+    while True:
+        events = (_native.bp_note_event * cap_ev)()
+        bends = np.empty(cap_b, dtype=np.int32)
+        rc = lib.bp_notes_decode(
+            frames.ctypes.data, onsets.ctypes.data, contours.ctypes.data, T, C.byref(prm), C.addressof(events),
+            cap_ev, bends.ctypes.data, cap_b, C.byref(n_ev), C.byref(n_b),
+        )
+        if rc == _native.BP_OK:
+            return events, bends, n_ev.value
+        if n_ev.value > cap_ev or n_b.value > cap_b:  # buffers too small: sizes were returned
+            cap_ev, cap_b = max(cap_ev, n_ev.value), max(cap_b, n_b.value)
+            continue
+        raise ValueError(f"bp_notes_decode: {lib.bp_notes_last_error().decode(errors='replace')}")
+
+
+def output_to_notes_polyphonic(
+    frames: np.ndarray, onsets: np.ndarray, onset_thresh: float, frame_thresh: float, min_note_len: int,
+    infer_onsets: bool, max_freq: Optional[float], min_freq: Optional[float], melodia_trick: bool = True,
+    energy_tol: int = ENERGY_TOLERANCE,
+) -> List[Tuple[int, int, int, float]]:
+    """note_creation.py:360-511 -> [(start_frame, end_frame, pitch_midi, amplitude)]."""
+    dummy = np.zeros((frames.shape[0], N_FREQ_BINS_CONTOURS), dtype=np.float32)
+    ev, _, n = _decode(frames, onsets, dummy, onset_thresh, frame_thresh, min_note_len, infer_onsets, max_freq,
+                       min_freq, melodia_trick, energy_tol, include_pitch_bends=False)
+    return [(ev[i].start_frame, ev[i].end_frame, ev[i].pitch_midi, np.float32(ev[i].amplitude)) for i in range(n)]
+
+
+def model_frames_to_time(n_frames: int) -> np.ndarray:
+    """note_creation.py:346-357."""
+    original_times = (np.arange(n_frames) * FFT_HOP).astype(int) / float(AUDIO_SAMPLE_RATE)
+    window_numbers = np.floor(np.arange(n_frames) / ANNOT_N_FRAMES)
+    window_offset = (FFT_HOP / AUDIO_SAMPLE_RATE) * (ANNOT_N_FRAMES - (AUDIO_N_SAMPLES / FFT_HOP)) + MAGIC_ALIGNMENT_OFFSET
+    return original_times - (window_offset * window_numbers)
+
+
+def drop_overlapping_pitch_bends(note_events_with_pitch_bends: List[NoteEvent]) -> List[NoteEvent]:
+    """note_creation.py:270-286: drop pitch bends from any notes that overlap in time with another note."""
+    note_events = sorted(note_events_with_pitch_bends)
+    for i in range(len(note_events) - 1):
+        for j in range(i + 1, len(note_events)):
+            if note_events[j][0] >= note_events[i][1]:
+                break
+            note_events[i] = note_events[i][:-1] + (None,)
+            note_events[j] = note_events[j][:-1] + (None,)
+    return note_events
+
+
+def note_events_to_midi(
+    note_events_with_pitch_bends: List[NoteEvent], multiple_pitch_bends: bool = False, midi_tempo: float = 120
+) -> pretty_midi.PrettyMIDI:
+    """note_creation.py:222-267."""
+    mid = pretty_midi.PrettyMIDI(initial_tempo=midi_tempo)
+    if not multiple_pitch_bends:
+        note_events_with_pitch_bends = drop_overlapping_pitch_bends(note_events_with_pitch_bends)
+    piano_program = pretty_midi.instrument_name_to_program("Electric Piano 1")
+    instruments: DefaultDict[int, pretty_midi.Instrument] = defaultdict(lambda: pretty_midi.Instrument(program=piano_program))
+    for start_time, end_time, note_number, amplitude, pitch_bend in note_events_with_pitch_bends:
+        instrument = instruments[note_number] if multiple_pitch_bends else instruments[0]
+        instrument.notes.append(
+            pretty_midi.Note(velocity=int(np.round(MIDI_VELOCITY_SCALE * amplitude)), pitch=note_number, start=start_time, end=end_time)
+        )
+        if not pitch_bend:
+            continue
+        pitch_bend_times = np.linspace(start_time, end_time, len(pitch_bend))
+        ticks = np.round(np.array(pitch_bend) * PITCH_BEND_SCALE / CONTOURS_BINS_PER_SEMITONE).astype(int)
+        ticks[ticks > N_PITCH_BEND_TICKS - 1] = N_PITCH_BEND_TICKS - 1
+        ticks[ticks < -N_PITCH_BEND_TICKS] = -N_PITCH_BEND_TICKS
+        for pb_time, pb_midi in zip(pitch_bend_times, ticks):
+            instrument.pitch_bends.append(pretty_midi.PitchBend(int(pb_midi), pb_time))
+    mid.instruments.extend(instruments.values())
+    return mid
+
+
+def model_output_to_notes(
+    output: Dict[str, np.ndarray], onset_thresh: float, frame_thresh: float, infer_onsets: bool = True,
+    min_note_len: int = DEFAULT_MIN_NOTE_LEN, min_freq: Optional[float] = None, max_freq: Optional[float] = None,
+    include_pitch_bends: bool = True, multiple_pitch_bends: bool = False, melodia_trick: bool = True,
+    midi_tempo: float = 120,
+) -> Tuple[pretty_midi.PrettyMIDI, List[NoteEvent]]:
+    """note_creation.py:52-116: model output -> (midi, [(start_s, end_s, pitch_midi, amplitude, bends)])."""
+    frames, onsets, contours = output["note"], output["onset"], output["contour"]
+    ev, bends, n = _decode(frames, onsets, contours, onset_thresh, frame_thresh, min_note_len, infer_onsets,
+                           max_freq, min_freq, melodia_trick, ENERGY_TOLERANCE, include_pitch_bends)
+    events: List[NoteEvent] = []
+    for i in range(n):
+        e = ev[i]
+        b = [int(v) for v in bends[e.bend_offset : e.bend_offset + e.n_bends]] if include_pitch_bends else None
+        events.append((float(e.start_s), float(e.end_s), int(e.pitch_midi), np.float32(e.amplitude), b))
+    return note_events_to_midi(events, multiple_pitch_bends, midi_tempo), events

@@ -183,6 +183,46 @@ int bp_pyramid_layout(int level /*1..8*/, int64_t* offset, int64_t* length);
 
 const char* bp_version(void);
 
+/* ---- note decoding: posteriorgrams -> note events (host C++, no GPU needed) -------------------------
+ * Replaces the Python loops of basic_pitch/note_creation.py: output_to_notes_polyphonic (360-511, with
+ * constrain_frequency 314-343, get_infered_onsets 289-311 and the melodia trick 452-509), get_pitch_bends
+ * (182-219) and model_frames_to_time (346-357), i.e. model_output_to_notes (52-116) without the PrettyMIDI
+ * object.  Events come back in the reference's order with the reference's values (bit-exact vs the numpy
+ * restatement in oracle/note_oracle.py, which reproduces the reference's golden events). */
+typedef struct bp_note_params {
+  double onset_threshold;      /* predict(onset_threshold=0.5)                          inference.py:434 */
+  double frame_threshold;      /* predict(frame_threshold=0.3)                          inference.py:435 */
+  double min_freq_hz;          /* <= 0: None                                            inference.py:437 */
+  double max_freq_hz;          /* <= 0: None                                            inference.py:438 */
+  int32_t min_note_len;        /* frames: int(round(ms / 1000 * (22050 / 256)))         inference.py:469 */
+  int32_t infer_onsets;        /* 1                                                     note_creation.py:56 */
+  int32_t melodia_trick;       /* 1                                                     inference.py:440 */
+  int32_t include_pitch_bends; /* 1                                                     note_creation.py:60 */
+  int32_t energy_tol;          /* 11                                                    note_creation.py:370 */
+  int32_t reserved;
+} bp_note_params;
+
+typedef struct bp_note_event {
+  double start_s, end_s;       /* model_frames_to_time()[start_frame / end_frame] */
+  int64_t bend_offset;         /* first pitch bend of this note in `bends` */
+  int32_t start_frame, end_frame;
+  int32_t pitch_midi;          /* 21 + note bin */
+  int32_t n_bends;             /* end_frame - start_frame, or 0 without pitch bends */
+  float amplitude;             /* np.mean(frames[start:end, bin]) in float32 */
+  int32_t reserved;
+} bp_note_event;
+
+void bp_note_params_default(bp_note_params* p);
+
+/* note / onset [n_frames, 88] are MODIFIED in place when min/max frequency is set, exactly like the
+ * reference's constrain_frequency (note_creation.py:338-341); contour [n_frames, 264] is read only.
+ * On return *n_events / *n_bends hold the required counts; if they exceed max_events / max_bends the call
+ * fails with BP_ERR_INVALID_ARG and can be repeated with larger buffers.  bends are in 1/3 semitones. */
+int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_frames,
+                    const bp_note_params* params, bp_note_event* events, int64_t max_events, int32_t* bends,
+                    int64_t max_bends, int64_t* n_events, int64_t* n_bends);
+const char* bp_notes_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -273,3 +273,30 @@ def test_track_path_equals_windowed_path_and_golden(weights, clip_22k):
     r32 = O.run_track(clip_22k, weights, np.float32, batch=6)
     _noise_aware(a, r32, r64)
     m.close()
+
+
+def test_predict_note_events_match_reference_golden(tmp_path):
+    """BASELINE.json north star: MIDI note events identical to the reference's on its test clip.
+    `predict()` end to end (decode + resample on the host, CQT + CNN on the MI355X, note decoding in C++)
+    against the reference's golden `note_events.npz`: all 28 events, every discrete field exact (start / end
+    time, pitch, pitch-bend list), amplitude within the reference's own tolerance (tests/test_inference.py:
+    73-76, atol 1e-4)."""
+    from basic_pitch_amd import inference as inf
+
+    wav = os.path.join(GOLDEN, "vocadito_10.wav")
+    model_output, midi, events = inf.predict(wav)
+    g = np.load(os.path.join(GOLDEN, "vocadito_10_note_events.npz"))
+    assert len(events) == len(g["pitch"]) == 28
+    for i, e in enumerate(events):
+        assert e[0] == g["start_s"][i] and e[1] == g["end_s"][i] and e[2] == g["pitch"][i], i
+        assert abs(float(e[3]) - float(g["amplitude"][i])) <= 1e-4, i
+        assert list(e[4]) == list(g["bend_values"][g["bend_offsets"][i] : g["bend_offsets"][i + 1]]), i
+    assert set(model_output) == {"note", "onset", "contour"}
+    assert len(midi.instruments) == 1 and len(midi.instruments[0].notes) == 28
+    # predict_and_save writes the reference's three artefacts (inference.py:565-602)
+    inf.predict_and_save([wav], tmp_path, True, False, True, True)
+    stem = tmp_path / "vocadito_10_basic_pitch"
+    assert stem.with_suffix(".mid").read_bytes()[:4] == b"MThd"
+    saved = np.load(stem.with_suffix(".npz"), allow_pickle=True)["basic_pitch_model_output"].item()
+    assert saved["note"].shape == (787, 88)
+    assert len(stem.with_suffix(".csv").read_text().strip().splitlines()) == 29
