@@ -47,6 +47,22 @@ CB_EXECUTED_FLOP_PER_WINDOW = 2 * 186 * (63 * 3 + 4 * 2) * (2 * 32 * 32 * 16)
 HBM_PEAK_GBS = 8000.0
 
 
+def pmc_traffic(kernel_key: str, batch: int):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes, gfx950 x2 correction on the read side — profiles/r01_c_pmc.md).  PMC
+    counters cannot be collected from inside the timed run, so this is the per-launch figure of the same
+    command at the same batch, or None when no profile for this batch is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_c_pmc.json")
+    if batch != 256 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        prof = json.load(f)
+    for k, v in prof.items():
+        if kernel_key in k:
+            return v["hbm_read_bytes"] + v["hbm_write_bytes"]
+    return None
+
+
 def cpu_baseline(seconds_budget: float = 12.0) -> dict:
     """Oracle fp32 on the host cores, bounded sample (checker code, timed as the CPU baseline)."""
     import torch
@@ -186,7 +202,9 @@ def main() -> None:
                 "peak": c1_peak,
                 "unit": "TFLOP/s",
                 "frac": achieved / c1_peak,
-                "traffic": None,
+                "traffic": None if args.exact_f32 else pmc_traffic("contour_branch_kernel", B),
+                "traffic_unit": "bytes per launch (PMC, profiles/r01_c_pmc.md)",
+                "algorithmic_bytes_per_launch": (214_656 + 181_632) * B,  # zp read + contour written
                 "executed_mfma_tflops": c1_exec,  # incl. the 3-product split and Toeplitz padding
                 "executed_frac": c1_exec / c1_peak,
                 "launch_ms": c1_ms,
