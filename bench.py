@@ -17,8 +17,8 @@ Extra objects on the JSON line:
                 timed steps, against the dense f16 MFMA peak (2.5 PFLOP/s; the kernel spends 3 f16 MFMAs per
                 product to keep fp32-class accuracy, so frac <= 1/3 by construction — executed_frac is the
                 matrix-pipe occupancy)
-  cpu_baseline  the oracle (CPU restatement of the frozen graph, torch-CPU fp32, all host threads)
-                timed on rank 0 on a bounded sample of the same synthetic windows ("port": the
+  cpu_baseline  the oracle's C restatement of the frozen graph (fp32, AVX2, OpenMP over windows, all host
+                cores) timed on rank 0 on a bounded sample of the same synthetic windows ("port": the
                 reference's own ONNX/TF runtimes are not installable here)
 """
 from __future__ import annotations
@@ -64,31 +64,43 @@ def pmc_traffic(kernel_key: str, batch: int):
 
 
 def cpu_baseline(seconds_budget: float = 12.0) -> dict:
-    """Oracle fp32 on the host cores, bounded sample (checker code, timed as the CPU baseline)."""
-    import torch
-
+    """The oracle's C restatement of the frozen graph (oracle/bp_oracle.c: fp32, AVX2, OpenMP over windows)
+    on all host cores, bounded sample (checker code, timed as the CPU baseline).  Falls back to the torch-CPU
+    oracle when the C library has not been built."""
     from oracle import bp_oracle as O
 
-    W = O.load_weights()
-    threads = torch.get_num_threads()
     rng = np.random.default_rng(0)
-    chunk = 8
-    x = rng.uniform(-1, 1, (chunk, O.AUDIO_N_SAMPLES)).astype(np.float32)
-    O.forward(x[:2], W, np.float32)  # warm-up (thread pools, allocator)
+    threads = os.cpu_count() or 1
+    try:
+        O.c_library()
+        chunk = 2 * threads
+        x = rng.uniform(-1, 1, (chunk, O.AUDIO_N_SAMPLES)).astype(np.float32)
+        run = lambda: O.forward_c(x, threads)  # noqa: E731
+        what = "C/OpenMP fp32 oracle (oracle/bp_oracle.c)"
+    except OSError:
+        import torch
+
+        W = O.load_weights()
+        threads = torch.get_num_threads()
+        chunk = 8
+        x = rng.uniform(-1, 1, (chunk, O.AUDIO_N_SAMPLES)).astype(np.float32)
+        run = lambda: O.forward(x, W, np.float32)  # noqa: E731
+        what = "torch-CPU fp32 oracle"
+    run()  # warm-up (thread pool, page faults)
     done = 0
     t0 = time.perf_counter()
     while True:
-        O.forward(x, W, np.float32)
+        run()
         done += chunk
         el = time.perf_counter() - t0
-        if el >= seconds_budget or done >= 4096:
+        if el >= seconds_budget or done >= 65536:
             break
     return {
         "value": done / el,
         "unit": "windows/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{done} uniform[-1,1) windows in batches of {chunk}, {el:.1f} s, torch-CPU fp32 oracle",
+        "sample": f"{done} uniform[-1,1) windows in batches of {chunk}, {el:.1f} s, {what}",
     }
 
 

@@ -225,3 +225,37 @@ def run_track(samples: np.ndarray, W=None, dtype=np.float64, batch: int = 8) -> 
         for k in outs:
             outs[k].append(r[k])
     return {k: unwrap_output(np.concatenate(v), n) for k, v in outs.items()}
+
+
+# ---- the C restatement (oracle/bp_oracle.c), used as a cross-check and as bench.py's CPU baseline -----------
+def c_library():
+    """ctypes handle of oracle/_build/libbp_oracle.so (built by `make -C oracle`, i.e. __graft_entry__.build())."""
+    import ctypes as C
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libbp_oracle.so")
+    lib = C.CDLL(path)
+    lib.bpo_forward.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.bpo_forward.restype = C.c_int
+    return lib
+
+
+def forward_c(audio: np.ndarray, n_threads: int = 0, weights_path: str = DEFAULT_WEIGHTS) -> Dict[str, np.ndarray]:
+    """audio (B, 43844) -> {"note","onset","contour"} through the C restatement (fp32, OpenMP over windows)."""
+    x = np.ascontiguousarray(audio, dtype=np.float32)
+    if x.ndim == 3:
+        x = np.ascontiguousarray(x[:, :, 0])
+    n = x.shape[0]
+    with open(weights_path, "rb") as f:
+        blob = f.read()
+    out = {
+        "note": np.empty((n, ANNOT_N_FRAMES, N_FREQ_NOTE), np.float32),
+        "onset": np.empty((n, ANNOT_N_FRAMES, N_FREQ_NOTE), np.float32),
+        "contour": np.empty((n, ANNOT_N_FRAMES, N_FREQ_CONTOUR), np.float32),
+    }
+    rc = c_library().bpo_forward(
+        blob, len(blob), x.ctypes.data, n, out["note"].ctypes.data, out["onset"].ctypes.data,
+        out["contour"].ctypes.data, n_threads or (os.cpu_count() or 1),
+    )
+    if rc != 0:
+        raise RuntimeError(f"bpo_forward failed: {rc}")
+    return out

@@ -93,3 +93,21 @@ def test_harmonic_stack_shifts():
         for f in (0, 1, 40, 200, 263):
             expect = f + sh + 1.0 if 0 <= f + sh < 309 else 0.0
             assert s[c, f].item() == expect
+
+
+def test_c_restatement_agrees_with_torch_oracle(weights):
+    """oracle/bp_oracle.c (the CPU baseline bench.py times) is an independent restatement of the same graph:
+    it must agree with the torch fp32 oracle to summation-order noise, and be as close to fp64 as it is."""
+    import subprocess
+
+    from conftest import make_windows
+
+    subprocess.run(["make", "-s", "-C", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")], check=True)
+    x = np.concatenate([make_windows("uniform", 2, 0), make_windows("normal", 1, 1)])
+    r32 = O.forward(x, weights, np.float32)
+    r64 = O.forward(x, weights, np.float64)
+    rc = O.forward_c(x, 4)
+    for k in ("note", "onset", "contour"):
+        assert rc[k].shape == r32[k].shape
+        assert np.abs(rc[k] - r32[k]).max() <= 5e-5, k
+        assert np.abs(rc[k] - r64[k]).max() <= 2 * np.abs(r32[k] - r64[k]).max() + 2e-5, k
