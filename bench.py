@@ -70,7 +70,13 @@ def cpu_baseline(seconds_budget: float = 12.0) -> dict:
     from oracle import bp_oracle as O
 
     rng = np.random.default_rng(0)
-    threads = os.cpu_count() or 1
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # a cgroup CPU quota (the GPU box: 16 of 256 hardware threads) is the number of cores we really have
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            threads = max(1, min(threads, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
     try:
         O.c_library()
         chunk = 2 * threads
