@@ -23,6 +23,7 @@ SOURCES = [
     "cqt_mfma.hip",
     "conv_contour1.hip",
     "conv_contour.hip",
+    "conv_contour_direct.hip",
     "conv_stride3.hip",
     "conv_heads.hip",
     "conv_branch.hip",
@@ -63,6 +64,9 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         "-shared",
         "-Wall",
         "-Wno-unused-function",
+        # the fully unrolled 63-k-step MFMA loops exceed clang's default size limit for `#pragma unroll`
+        "-mllvm",
+        "-pragma-unroll-threshold=400000",
         "-o",
         LIB_PATH + ".tmp",
     ] + _sources()

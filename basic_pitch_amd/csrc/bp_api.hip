@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -44,6 +45,10 @@ void launch_filterbank_mfma(const float* audio, const float* pyr, const void* bf
                             float* lp, int* mm, float* scratch, int n_windows, LogConsts kc, int n_cu,
                             hipStream_t s);
 void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc, hipStream_t s);
+void launch_contour_conv1(const uint32_t* zp, const void* wlds, const float* bias, float* c1, int n_windows,
+                          int n_cu, hipStream_t stream);
+void launch_contour_conv2(const float* c1, const float* w2, float bias, float* contour, int n_windows, int n_cu,
+                          hipStream_t stream);
 void launch_note_branch(const float* contour, const void* wfrag, const float* wf32, float* note,
                         int n_windows, int n_cu, hipStream_t s);
 void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32,
@@ -147,7 +152,11 @@ struct bp_context {
   float *d_cb_wfrag = nullptr, *d_cb_wf32 = nullptr;  // fused contour branch (conv_contour.hip)
   // fused branches (conv_branch.hip): f16 hi/lo A fragments (raw bytes) + {bias1[32], extra[9], bias2}
   float *d_note_wfrag = nullptr, *d_note_wf32 = nullptr, *d_onset_wfrag = nullptr, *d_onset_wf32 = nullptr;
-  float* zp = nullptr;  // uint32 [cap][172][kZRow] pre-split z
+  float* zp = nullptr;  // uint32 [cap][kZRowsP][kZRow] pre-split z, zero padded (bp_common.h)
+  // contour branch, two-kernel form (conv_contour_direct.hip): LDS weight image, bias[8], conv2 taps [5][5][8]
+  float *d_d1_wlds = nullptr, *d_d1_bias = nullptr, *d_d2_w = nullptr;
+  float* c1s = nullptr;  // [cap][172][kC1Row][8] relu(conv1); pad bins zeroed once at allocation
+  bool fused_contour = false;  // BP_CONTOUR_PATH=fused: the single-kernel contour branch (A/B comparisons)
   float *d_dec_hfrag = nullptr, *d_fbh_bfrag = nullptr;  // cqt_mfma.hip f16 hi/lo fragments (raw bytes)
   float *d_c1_bfrag = nullptr, *d_c1_bias = nullptr, *d_o1_bfrag = nullptr, *d_o1_bias = nullptr;
   float *d_n1_bfrag = nullptr, *d_n1_bias = nullptr, *d_w_contour2 = nullptr, *d_w_note2 = nullptr,
@@ -341,6 +350,20 @@ void pack_contour_branch(const Tensor* w1, const Tensor* w2, std::vector<uint16_
   }
 }
 
+// Two-kernel contour branch (conv_contour_direct.hip): LDS weight image [hi | lo][3 dt][45 taps][8 o] x (8 c) f16,
+// tap slot = df + 3 (three zero taps either side: the Toeplitz expansion is done by addressing).
+void pack_contour_direct(const Tensor* w1, std::vector<uint16_t>& out) {
+  const size_t half = (size_t)3 * 45 * 8 * 8;
+  out.assign(2 * half, 0);
+  for (int dt = 0; dt < 3; ++dt)
+    for (int df = 0; df < 39; ++df)
+      for (int o = 0; o < 8; ++o)
+        for (int c = 0; c < 8; ++c) {
+          const float v = w1->data[((o * 8 + c) * 3 + dt) * 39 + df];
+          put_split(out, 0, half, (((size_t)dt * 45 + df + 3) * 8 + o) * 8 + c, v, 2048.0f);
+        }
+}
+
 // contour conv1 Toeplitz B fragments [4 waves][126][64] (conv_contour1.hip).
 void pack_contour1(const Tensor* w, std::vector<float>& out) {
   static const int chan[4][2] = {{0, 1}, {2, 4}, {5, 3}, {6, 7}};
@@ -464,7 +487,7 @@ void pack_filterbank_f16(const Tensor* re, const Tensor* im, std::vector<uint16_
 }
 
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->zp, h->d_cb_wfrag, h->d_cb_wf32, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_bias, h->d_d2_w, h->d_cb_wfrag, h->d_cb_wf32, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->fb_scratch};
@@ -533,9 +556,17 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
   } else {
     launch_zpack(h->lp, h->mm, reinterpret_cast<uint32_t*>(h->zp), n, h->kc, s);
     BP_MARK(BP_STAGE_ZPACK);
-    launch_contour_branch(reinterpret_cast<const uint32_t*>(h->zp), h->d_cb_wfrag, h->d_cb_wf32, contour_dev, n,
-                          h->n_cu, s);
-    BP_MARK(BP_STAGE_CONTOUR);
+    if (h->fused_contour) {
+      launch_contour_branch(reinterpret_cast<const uint32_t*>(h->zp), h->d_cb_wfrag, h->d_cb_wf32, contour_dev, n,
+                            h->n_cu, s);
+      BP_MARK(BP_STAGE_CONTOUR);
+    } else {
+      launch_contour_conv1(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wlds, h->d_d1_bias, h->c1s, n,
+                           h->n_cu, s);
+      BP_MARK(BP_STAGE_CONTOUR_CONV1);
+      launch_contour_conv2(h->c1s, h->d_d2_w, h->b_contour2, contour_dev, n, h->n_cu, s);
+      BP_MARK(BP_STAGE_CONTOUR_CONV2);
+    }
     launch_note_branch(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, h->n_cu, s);
     BP_MARK(BP_STAGE_NOTE);
     launch_onset_branch(reinterpret_cast<const uint32_t*>(h->zp), note_dev, h->d_onset_wfrag, h->d_onset_wf32,
@@ -661,6 +692,18 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     for (int i = 0; i < 8; ++i) cb32[i] = c1b->data[i];
     cb32[8] = c2b->data[0];
     if ((rc = upload(h, raw_of(frag), &h->d_cb_wfrag)) || (rc = upload(h, cb32, &h->d_cb_wf32))) return fail(rc);
+    pack_contour_direct(c1w, frag);
+    std::vector<float> w2t(200);
+    for (int dt = 0; dt < 5; ++dt)
+      for (int dw = 0; dw < 5; ++dw)
+        for (int c = 0; c < 8; ++c) w2t[(dt * 5 + dw) * 8 + c] = c2w->data[(c * 5 + dt) * 5 + dw];
+    if ((rc = upload(h, raw_of(frag), &h->d_d1_wlds)) || (rc = upload(h, vec(c1b), &h->d_d1_bias)) ||
+        (rc = upload(h, w2t, &h->d_d2_w)))
+      return fail(rc);
+    {
+      const char* e = std::getenv("BP_CONTOUR_PATH");
+      h->fused_contour = e && std::strcmp(e, "fused") == 0;
+    }
     for (int br = 0; br < 2; ++br) {
       pack_branch(br ? 13 : 4, br ? o1w : n1w, br ? o2w : n2w, br == 1, frag);
       std::vector<float> f32(42, 0.f);
@@ -690,8 +733,16 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       (rc = alloc(h, &h->lp, cap * kFrames * kBins)) || (rc = alloc(h, &h->c1, cap * 8 * kPlaneC)) ||
       (rc = alloc(h, &h->contour, cap * kPlaneC)) || (rc = alloc(h, &h->n1, cap * 32 * kPlaneN)) ||
       (rc = alloc(h, &h->note, cap * kPlaneN)) || (rc = alloc(h, &h->o1, cap * 32 * kPlaneN)) ||
-      (rc = alloc(h, &h->onset, cap * kPlaneN)) || (rc = alloc(h, &h->zp, cap * kFrames * kZRow)))
+      (rc = alloc(h, &h->onset, cap * kPlaneN)) || (rc = alloc(h, &h->zp, cap * (int64_t)kZWin)) ||
+      (rc = alloc(h, &h->c1s, cap * (int64_t)kC1Win)))
     return fail(rc);
+  {
+    hipError_t e = hipMemset(h->c1s, 0, (size_t)cap * kC1Win * sizeof(float));  // pad bins stay zero
+    if (e != hipSuccess) {
+      h->err = std::string("hipMemset(c1s) failed: ") + hipGetErrorString(e);
+      return fail(BP_ERR_HIP);
+    }
+  }
   {
     hipError_t e = hipMalloc(&h->mm, cap * 2 * sizeof(int));
     if (e != hipSuccess) {
@@ -954,8 +1005,17 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
       if ((ok = need(bf->lp) && need(bf->mm) && need(bf->zp))) launch_zpack(bf->lp, bf->mm, bf->zp, n, h->kc, s);
       break;
     case BP_STAGE_CONTOUR:
-      if ((ok = need(bf->zp) && need(bf->contour)))
-        launch_contour_branch(bf->zp, h->d_cb_wfrag, h->d_cb_wf32, bf->contour, n, h->n_cu, s);
+      if ((ok = need(bf->zp) && need(bf->contour))) {
+        if (h->fused_contour) {
+          launch_contour_branch(bf->zp, h->d_cb_wfrag, h->d_cb_wf32, bf->contour, n, h->n_cu, s);
+        } else if (n > h->cap) {
+          h->err = "bp_run_stage: contour needs n_windows <= max_windows (internal c1 buffer)";
+          return BP_ERR_INVALID_ARG;
+        } else {
+          launch_contour_conv1(bf->zp, h->d_d1_wlds, h->d_d1_bias, h->c1s, n, h->n_cu, s);
+          launch_contour_conv2(h->c1s, h->d_d2_w, h->b_contour2, bf->contour, n, h->n_cu, s);
+        }
+      }
       break;
     case BP_STAGE_NOTE:
       if ((ok = need(bf->contour) && need(bf->note)))

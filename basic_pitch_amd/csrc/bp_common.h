@@ -17,7 +17,17 @@ constexpr int kTaps = 256;       // n_fft of the top-octave kernels / lowpass le
 constexpr int kPlaneC = kFrames * kFreqC;  // 45408
 constexpr int kPlaneN = kFrames * kFreqN;  // 15136
 constexpr int kPyrStride = 43712;
-constexpr int kZRow = 312;      // row stride (words) of the pre-split z tensor `zp` (309 bins + 3 zero words)
+// Pre-split z tensor `zp` (normalised + BatchNorm-ed CQT as f16 hi | f16 lo << 16), zero padded so that the
+// harmonic-stack gathers (bin f - 20 .. f + 283 shifted by -36 .. +101) and the frame halo need no masks:
+// [kZRowsP = 1 + 172 + 1 frames][kZRow = 56 + 309 + 83 words]; frame t, bin g lives at (t + 1) * kZRow + kZPadL + g.
+constexpr int kZRow = 448;
+constexpr int kZPadL = 56;
+constexpr int kZRowsP = kFrames + 2;
+constexpr int kZWin = kZRowsP * kZRow;   // words per window
+// relu(conv1) of the contour branch: [172][kC1Row = 2 + 264 + 2 bins][8 channels] fp32, pad bins zero
+constexpr int kC1Pad = 2;
+constexpr int kC1Row = kFreqC + 2 * kC1Pad;
+constexpr int kC1Win = kFrames * kC1Row * 8;  // floats per window
 
 // pyramid level k (1..8) lives at kPyrOff[k] inside a window's pyr row; level 0 is the audio itself
 __host__ __device__ constexpr int level_len(int k) {

@@ -50,7 +50,7 @@ static_assert(kBrTilesPerRow * 30 >= kFreqN, "tiles cover a row");
 struct BranchParams {
   const uint4* wfrag;  // [A1 hi: KS1*64][A1 lo: KS1*64][A2 hi: 2*64][A2 lo: 2*64] x (8 x f16)
   const float* wf32;   // bias1[32], extra[9] (onset: taps of the note channel), bias2
-  const void* src;     // note: contour f32 [n][172][264]; onset: zp u32 [n][172][kZRow]
+  const void* src;     // note: contour f32 [n][172][264]; onset: zp u32 [n][kZRowsP][kZRow] (padded, bp_common.h)
   const float* note;   // onset only: note posteriorgram [n][172][88]
   float* out;          // [n][172][88]
   int n_windows;
@@ -119,8 +119,8 @@ __device__ __forceinline__ void stage_rows(const BranchParams& p, int b, int row
         img_lo[ring + w] = __builtin_bit_cast(uint4, vl);
       }
     } else {
-      const uint32_t* src =
-          static_cast<const uint32_t*>(p.src) + ((int64_t)b * kFrames + (rvalid ? row : 0)) * kZRow;
+      const uint32_t* src = static_cast<const uint32_t*>(p.src) + (int64_t)b * kZWin +
+                            (int64_t)((rvalid ? row : 0) + 1) * kZRow + kZPadL;
       for (int sl = lane; sl < Br::SLOTS; sl += 64) {
         const int f = sl - 1;
         const bool inside = rvalid && f >= 0 && f < kFreqC;  // crop to 264 bins before "same" padding (nn.py:87)
@@ -333,11 +333,14 @@ __global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ lp
   const float mn = ord2f(mm[2 * b]);
   const float range = ord2f(mm[2 * b + 1]) - mn;
   const float* lpb = lp + (int64_t)b * kFrames * kBins;
-  uint32_t* zb = zp + (int64_t)b * kFrames * kZRow;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < kFrames * kZRow; i += gridDim.x * 256) {
-    const int t = i / kZRow, g = i - t * kZRow;
+  uint32_t* zb = zp + (int64_t)b * kZWin;
+  // the whole padded window is written every time (pad frames and pad words are zero: the zero padding of the
+  // harmonic stack, nn.py:73-85, and of the convolutions' frame halo)
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < kZWin; i += gridDim.x * 256) {
+    const int tp = i / kZRow, g = i - tp * kZRow - kZPadL;
+    const int t = tp - 1;
     uint32_t u = 0;
-    if (g < kBins) {
+    if (t >= 0 && t < kFrames && g >= 0 && g < kBins) {
       const float z = norm_bn(lpb[t * kBins + g], mn, range, kc);
       _Float16 hi, lo;
       split_f16(z, hi, lo);

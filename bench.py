@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path (bp_infer_async: pyramid -> filterbank -> 3 branches of the CNN
+One "step" = one pass of the hot path (bp_infer_async: pyramid -> filterbank -> zpack -> 3 branches of the CNN
 -> three posteriorgrams) over one batch of 256 synthetic 2-second 22.05 kHz windows that is already
 resident in HBM (BASELINE.json configs[1]: "Batch=256 synthetic 2 s @ 22.05 kHz mono windows,
 1xMI355X, fp32"); outputs stay in HBM.  Every rank owns its own batch (windows are independent
@@ -12,7 +12,7 @@ units: file/window sharding, no collective on the data path — SURVEY.md §8e),
 and `value` = windows processed by all ranks / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (the fused contour branch, 67 % of the path's FLOPs): algorithmic FLOP per
+  roofline      dominant kernel (contour_conv1_kernel: Conv2D 8->8 3x39, 65 % of the path's FLOPs): algorithmic FLOP per
                 launch / mean launch duration measured with HIP events on the kernel's stream over the
                 timed steps, against the dense f16 MFMA peak (2.5 PFLOP/s; the kernel spends 3 f16 MFMAs per
                 product to keep fp32-class accuracy, so frac <= 1/3 by construction — executed_frac is the
@@ -41,18 +41,23 @@ C1_FLOP_PER_WINDOW = 680_030_208         # contour conv1: 2*8*8*3*39*172*264 (mo
 C2_FLOP_PER_WINDOW = 18_163_200          # contour conv2: 2*8*25*172*264 (models.py:254-263)
 F32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: dense f32 matrix peak (= f32 vector peak)
 F16_MFMA_PEAK_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
-# contour_branch_kernel (conv_contour.hip) issues, per 32-position tile, 63 k-steps x 3 f16 MFMAs (hi*hi, lo*hi,
-# hi*lo) of 32x32x16 for conv1 plus 4 waves x 2 for the conv2 tap projection; 186 tiles per chunk, 2 chunks
+# contour_branch_kernel (conv_contour.hip, BP_CONTOUR_PATH=fused) issues, per 32-position tile, 63 k-steps x 3 f16
+# MFMAs (hi*hi, lo*hi, hi*lo) of 32x32x16 for conv1 plus 4 waves x 2 for the conv2 tap projection; 186 tiles per
+# chunk, 2 chunks
 CB_EXECUTED_FLOP_PER_WINDOW = 2 * 186 * (63 * 3 + 4 * 2) * (2 * 32 * 32 * 16)
+# contour_conv1_kernel (conv_contour_direct.hip): a window is 172 x 66 positions = 45 rounds of 256; per round each of
+# the 4 waves issues 63 k-steps x 6 MFMAs (2 tiles x {hi*hi, lo*hi, hi*lo})
+D1_EXECUTED_FLOP_PER_WINDOW = 45 * 4 * 63 * 6 * (2 * 32 * 32 * 16)
+D1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 268 * 8 * 4  # zp read + c1 written
 HBM_PEAK_GBS = 8000.0
 
 
 def pmc_traffic(kernel_key: str, batch: int):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate passes, gfx950 x2 correction on the read side — profiles/r01_c_pmc.md).  PMC
+    WRITE_SIZE in separate passes, gfx950 x2 correction on the read side — profiles/r01_e_pmc.md).  PMC
     counters cannot be collected from inside the timed run, so this is the per-launch figure of the same
     command at the same batch, or None when no profile for this batch is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_c_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r01_e_pmc.json")
     if batch != 256 or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -186,6 +191,17 @@ def main() -> None:
             c1_kernel = "contour1_kernel (Conv2D 8->8 3x39 + norm/BN/stack; exact-f32 MFMA 32x32x2)"
             c1_peak = F32_MFMA_PEAK_TFLOPS
             c1_exec = 355 * 504 * (2 * 32 * 32 * 2) * B / (c1_ms * 1e-3) / 1e12
+            c1_bytes = None
+            c1_key = None
+        elif stage.get("contour_conv1", 0.0) > 0.0:
+            c1_ms = stage["contour_conv1"]
+            c1_flop = C1_FLOP_PER_WINDOW
+            c1_kernel = ("contour_conv1_kernel (harmonic stack + Conv2D 8->8 3x39 + ReLU; f16 MFMA 32x32x16 on hi/lo-split "
+                         "operands from LDS, fp32 accumulate, no K split)")
+            c1_peak = F16_MFMA_PEAK_TFLOPS
+            c1_exec = D1_EXECUTED_FLOP_PER_WINDOW * B / (c1_ms * 1e-3) / 1e12
+            c1_bytes = D1_BYTES_PER_WINDOW * B
+            c1_key = "contour_conv1_kernel"
         else:
             c1_ms = stage["contour"]
             c1_flop = C1_FLOP_PER_WINDOW + C2_FLOP_PER_WINDOW
@@ -193,6 +209,8 @@ def main() -> None:
                          "f16 MFMA 32x32x16 on hi/lo-split operands, fp32 accumulate)")
             c1_peak = F16_MFMA_PEAK_TFLOPS
             c1_exec = CB_EXECUTED_FLOP_PER_WINDOW * B / (c1_ms * 1e-3) / 1e12
+            c1_bytes = (214_656 + 181_632) * B
+            c1_key = "contour_branch_kernel"
         achieved = c1_flop * B / (c1_ms * 1e-3) / 1e12
         line = {
             "metric": "audio windows/sec (2 s @ 22.05 kHz) end-to-end CQT+CNN",
@@ -220,9 +238,9 @@ def main() -> None:
                 "peak": c1_peak,
                 "unit": "TFLOP/s",
                 "frac": achieved / c1_peak,
-                "traffic": None if args.exact_f32 else pmc_traffic("contour_branch_kernel", B),
-                "traffic_unit": "bytes per launch (PMC, profiles/r01_c_pmc.md)",
-                "algorithmic_bytes_per_launch": (214_656 + 181_632) * B,  # zp read + contour written
+                "traffic": pmc_traffic(c1_key, B) if c1_key else None,
+                "traffic_unit": "bytes per launch (PMC, profiles/r01_e_pmc.md)",
+                "algorithmic_bytes_per_launch": c1_bytes,
                 "executed_mfma_tflops": c1_exec,  # incl. the 3-product split and Toeplitz padding
                 "executed_frac": c1_exec / c1_peak,
                 "launch_ms": c1_ms,

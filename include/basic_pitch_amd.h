@@ -143,10 +143,12 @@ enum {
   BP_STAGE_ZPACK = 8,     /* norm + BN, f16 hi|lo words  lp,mm -> zp          */
   BP_STAGE_NOTE = 9,      /* fused note branch           contour -> note      */
   BP_STAGE_ONSET = 10,    /* fused onset branch          zp,note -> onset     */
-  BP_STAGE_CONTOUR = 11,  /* fused contour branch        zp -> contour        */
-  BP_N_STAGES = 12
+  BP_STAGE_CONTOUR = 11,  /* contour branch (bp_run_stage: both kernels; timing: the fused A/B kernel) */
+  BP_STAGE_CONTOUR_CONV1 = 12, /* contour conv 3x39 + ReLU on the matrix cores   zp -> c1 (internal)   */
+  BP_STAGE_CONTOUR_CONV2 = 13, /* contour conv 5x5 + sigmoid                      c1 -> contour         */
+  BP_N_STAGES = 14
 };
-/* Default (split-precision) path runs: PYRAMID, FILTERBANK, ZPACK, CONTOUR, NOTE, ONSET.
+/* Default (split-precision) path runs: PYRAMID, FILTERBANK, ZPACK, CONTOUR_CONV1, CONTOUR_CONV2, NOTE, ONSET.
  * BP_FLAG_F32_MFMA runs:               PYRAMID, FILTERBANK, CONTOUR1, CONTOUR2, NOTE1, NOTE2, ONSET1, ONSET2. */
 
 /* With BP_FLAG_STAGE_TIMING: mean milliseconds per stage over the chunks (<= 128 most recent) run
@@ -158,10 +160,14 @@ int bp_get_stage_ms(bp_handle h, float* ms, int n);
  * Test hook: run ONE stage on caller-supplied DEVICE buffers (layouts in DESIGN.md "HBM layout"):
  *   audio [n,43844]  pyr [n,BP_PYR_STRIDE]  lp [n,172,309]  mm int32 [n,2] (ordered-int min,max)
  *   c1 [n,8,172,264]  contour [n,172,264]  n1 [n,32,172,88]  note [n,172,88]  o1 [n,32,172,88]
- *   onset [n,172,88]  zp uint32 [n,172,BP_Z_ROW] (z = normalised, BatchNorm-ed CQT as f16 hi | f16 lo << 16 with
- *   lo = (z - hi) * 2^11; words 309..311 of a row are zero).  Unused pointers for a stage may be NULL.  Synchronous.
+ *   onset [n,172,88]  zp uint32 [n,BP_Z_ROWS,BP_Z_ROW] (z = normalised, BatchNorm-ed CQT as f16 hi | f16 lo << 16
+ *   with lo = (z - hi) * 2^11; frame t, bin g at [t + 1][BP_Z_PAD + g], everything else zero: the zero padding of
+ *   the harmonic stack and of the frame halo is part of the tensor).  Unused pointers for a stage may be NULL.
+ *   Synchronous.
  */
-#define BP_Z_ROW 312
+#define BP_Z_ROW 448
+#define BP_Z_ROWS 174
+#define BP_Z_PAD 56
 #define BP_PYR_STRIDE 43712
 typedef struct bp_stage_buffers {
   const float* audio;

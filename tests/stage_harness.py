@@ -29,19 +29,20 @@ def ord_decode(i: np.ndarray) -> np.ndarray:
 
 
 def zp_pack(z: np.ndarray) -> np.ndarray:
-    """z (n,172,309) fp32 -> the library's pre-split words (n,172,312): f16 hi | f16 lo << 16, lo = (z - hi) * 2^11."""
+    """z (n,172,309) fp32 -> the library's pre-split, zero-padded words (n,174,448): f16 hi | f16 lo << 16 with
+    lo = (z - hi) * 2^11; frame t, bin g at [t + 1][56 + g] (include/basic_pitch_amd.h: BP_Z_ROWS / ROW / PAD)."""
     z = np.ascontiguousarray(z, dtype=np.float32)
     hi = z.astype(np.float16)
     lo = ((z - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)  # kLoScale (bp_common.h)
     u = hi.view(np.uint16).astype(np.uint32) | (lo.view(np.uint16).astype(np.uint32) << 16)
-    out = np.zeros(z.shape[:2] + (_native.BP_Z_ROW,), dtype=np.uint32)
-    out[:, :, : z.shape[2]] = u
+    out = np.zeros((z.shape[0], _native.BP_Z_ROWS, _native.BP_Z_ROW), dtype=np.uint32)
+    out[:, 1 : 1 + z.shape[1], _native.BP_Z_PAD : _native.BP_Z_PAD + z.shape[2]] = u
     return out
 
 
 def zp_unpack(zp: np.ndarray) -> np.ndarray:
-    """inverse of zp_pack (hi + lo in fp32), pad words dropped"""
-    zp = np.ascontiguousarray(zp).view(np.uint32)[:, :, :309]
+    """inverse of zp_pack (hi + lo in fp32), padding dropped"""
+    zp = np.ascontiguousarray(zp).view(np.uint32)[:, 1:173, _native.BP_Z_PAD : _native.BP_Z_PAD + 309]
     hi = (zp & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float32)
     lo = (zp >> 16).astype(np.uint16).view(np.float16).astype(np.float32)
     return hi + lo / np.float32(2048.0)

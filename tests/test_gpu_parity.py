@@ -113,9 +113,11 @@ def test_stage_zpack(runner, cases):
     x, r32, r64 = cases
     n = x.shape[0]
     out = runner.run("zpack", n, {"lp": r32["lp"], "mm": ord_encode(r32["minmax"])},
-                     {"zp": ((n, 172, 312), torch.int32)})
+                     {"zp": ((n, 174, 448), torch.int32)})
     zp = out["zp"].view(np.uint32)
-    assert (zp[:, :, 309:] == 0).all()
+    pad = zp.copy()
+    pad[:, 1:173, 56 : 56 + 309] = 0
+    assert (pad == 0).all()  # the zero padding of the stack / frame halo is part of the tensor
     z = zp_unpack(zp)
     assert np.abs(z - r32["z"]).max() <= 2e-6  # fp32 rounding of the normalisation + 2^-22 split residue
 
@@ -158,6 +160,24 @@ def test_exact_f32_reference_path(cases):
         e_f32 = np.abs(outs["f32"][k][:3] - r64[k][:3]).max()
         assert e_f32 <= 1e-4 and e_split <= 1e-4, (k, e_split, e_f32)
         assert e_split <= e_f32 + 3e-5, (k, e_split, e_f32)
+
+
+def test_fused_contour_kernel_ab(cases, monkeypatch):
+    """BP_CONTOUR_PATH=fused swaps the two-kernel contour branch (conv_contour_direct.hip, default) for the
+    single fused kernel (conv_contour.hip).  Same operators, same split-precision products, different summation
+    order: the two must agree to fp32 rounding, and both with the fp64 oracle like any other path."""
+    from basic_pitch_amd import Model
+
+    x, r32, r64 = cases
+    outs = {}
+    for name in ("direct", "fused"):
+        monkeypatch.setenv("BP_CONTOUR_PATH", name)
+        m = Model(max_windows=8)
+        outs[name] = m.predict(x)
+        m.close()
+    for k in ("note", "onset", "contour"):
+        assert np.abs(outs["direct"][k] - outs["fused"][k]).max() <= 5e-6, k
+        assert np.abs(outs["fused"][k][:3] - r64[k][:3]).max() <= 1e-4, k
 
 
 def _noise_aware(got, r32, r64, floor=1e-4, factor=4.0):
