@@ -218,18 +218,30 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
             acc[r] = 0.0f;
             accc[r] = 0.0f;
           }
-#pragma unroll
-          for (int s = 0; s < KS1; ++s) {
+          // image fragments are read kBrPf k-steps ahead of the MFMAs that consume them (the compiler's own
+          // schedule waits for every read right after issuing it)
+          constexpr int kBrPf = KS1 < 3 ? KS1 : 3;
+          f16x8 bhf[KS1], blf[KS1];
+          auto issue = [&](int s) {
             const int o0 = rb[Br::d_of(s, 0)] + Br::x_of(s, 0);
             const int o1 = rb[Br::d_of(s, 1)] + Br::x_of(s, 1);
             const int slot = lane_off + (h ? o1 : o0);
-            const f16x8 bh = __builtin_bit_cast(f16x8, img_hi[slot]);
-            const f16x8 bl = __builtin_bit_cast(f16x8, img_lo[slot]);
+            bhf[s] = __builtin_bit_cast(f16x8, img_hi[slot]);
+            blf[s] = __builtin_bit_cast(f16x8, img_lo[slot]);
+          };
+#pragma unroll
+          for (int s = 0; s < kBrPf; ++s) issue(s);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s = 0; s < KS1; ++s) {
+            if (s + kBrPf < KS1) issue(s + kBrPf);
+            __builtin_amdgcn_sched_barrier(0);
             const f16x8 ah = __builtin_bit_cast(f16x8, a1h[s]);
             const f16x8 al = __builtin_bit_cast(f16x8, a1l[s]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-            accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accc, 0, 0, 0);
-            accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accc, 0, 0, 0);
+            accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhf[s], accc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhf[s], acc, 0, 0, 0);
+            accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blf[s], accc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
 
           // bias + ReLU (+ zero padding of conv2 outside the row), split, and the tap projection
