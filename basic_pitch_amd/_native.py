@@ -16,6 +16,7 @@ BP_MEM_HOST = 0
 BP_MEM_DEVICE = 1
 BP_FLAG_STAGE_TIMING = 1
 BP_FLAG_F32_MFMA = 2
+BP_FLAG_BF16_WEIGHTS = 4
 BP_N_STAGES = 14
 BP_Z_ROW = 448
 BP_Z_ROWS = 174

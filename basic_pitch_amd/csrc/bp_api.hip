@@ -46,13 +46,13 @@ void launch_filterbank_mfma(const float* audio, const float* pyr, const void* bf
                             hipStream_t s);
 void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc, hipStream_t s);
 void launch_contour_conv1(const uint32_t* zp, const void* wlds, const float* bias, float* c1, int n_windows,
-                          int n_cu, hipStream_t stream);
+                          int n_cu, bool weights_have_lo, hipStream_t stream);
 void launch_contour_conv2(const float* c1, const float* w2, float bias, float* contour, int n_windows, int n_cu,
                           hipStream_t stream);
 void launch_note_branch(const float* contour, const void* wfrag, const float* wf32, float* note,
-                        int n_windows, int n_cu, hipStream_t s);
+                        int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
 void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32,
-                         float* onset, int n_windows, int n_cu, hipStream_t s);
+                         float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
 }  // namespace bp
 
 using namespace bp;
@@ -516,6 +516,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
               float* contour_dev) {
   hipStream_t s = h->stream;
   const bool timing = (h->flags & BP_FLAG_STAGE_TIMING) != 0;
+  const bool wlo = !(h->flags & BP_FLAG_BF16_WEIGHTS);  // conv weights carry an f16 lo part
   int e = 0;
   hipEvent_t* ev = h->ev[h->timed_chunks % bp_context::kTimedRing];
   if (timing) BP_HIP(hipEventRecord(ev[0], s));
@@ -562,15 +563,15 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
       BP_MARK(BP_STAGE_CONTOUR);
     } else {
       launch_contour_conv1(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wlds, h->d_d1_bias, h->c1s, n,
-                           h->n_cu, s);
+                           h->n_cu, wlo, s);
       BP_MARK(BP_STAGE_CONTOUR_CONV1);
       launch_contour_conv2(h->c1s, h->d_d2_w, h->b_contour2, contour_dev, n, h->n_cu, s);
       BP_MARK(BP_STAGE_CONTOUR_CONV2);
     }
-    launch_note_branch(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, h->n_cu, s);
+    launch_note_branch(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, h->n_cu, wlo, s);
     BP_MARK(BP_STAGE_NOTE);
     launch_onset_branch(reinterpret_cast<const uint32_t*>(h->zp), note_dev, h->d_onset_wfrag, h->d_onset_wf32,
-                        onset_dev, n, h->n_cu, s);
+                        onset_dev, n, h->n_cu, wlo, s);
     BP_MARK(BP_STAGE_ONSET);
   }
 #undef BP_MARK
@@ -618,6 +619,28 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     g_create_error = err;
     return BP_ERR_BAD_WEIGHTS;
   }
+  // BP_FLAG_BF16_WEIGHTS: the six Conv2D weight tensors rounded to bf16 (round to nearest even); everything
+  // downstream (packing, the exact same kernels) sees ordinary fp32 numbers with 8 significant bits
+  std::vector<std::vector<float>> rounded;
+  std::vector<Tensor> rounded_t;
+  rounded.reserve(6);
+  rounded_t.reserve(6);
+  if ((flags & BP_FLAG_BF16_WEIGHTS) && !(flags & BP_FLAG_F32_MFMA)) {
+    auto to_bf16 = [&](const Tensor*& t) {
+      rounded.emplace_back(t->data, t->data + t->count);
+      for (float& v : rounded.back()) {
+        uint32_t u;
+        std::memcpy(&u, &v, 4);
+        u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+        std::memcpy(&v, &u, 4);
+      }
+      Tensor c = *t;
+      c.data = rounded.back().data();
+      rounded_t.push_back(c);
+      t = &rounded_t.back();
+    };
+    to_bf16(c1w), to_bf16(c2w), to_bf16(n1w), to_bf16(n2w), to_bf16(o1w), to_bf16(o2w);
+  }
   std::vector<float> fb;
   if (!pack_filterbank(re, im, fb, err)) {
     g_create_error = err;
@@ -646,7 +669,7 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
 
   bp_handle h = new bp_context();
   h->device = device_ordinal;
-  h->flags = flags;
+  h->flags = (flags & BP_FLAG_F32_MFMA) ? (flags & ~BP_FLAG_BF16_WEIGHTS) : flags;
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   std::snprintf(h->arch, sizeof h->arch, "%s", prop.gcnArchName);
   h->cap = max_windows_hint > 0 ? max_windows_hint : 256;
@@ -956,6 +979,7 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
   hipStream_t s = h->stream;
   const int n = (int)n_windows;
   auto need = [&](const void* p) { return p != nullptr; };
+  const bool wlo = !(h->flags & BP_FLAG_BF16_WEIGHTS);
   bool ok = true;
   switch (stage) {
     case BP_STAGE_PYRAMID:
@@ -1012,18 +1036,18 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
           h->err = "bp_run_stage: contour needs n_windows <= max_windows (internal c1 buffer)";
           return BP_ERR_INVALID_ARG;
         } else {
-          launch_contour_conv1(bf->zp, h->d_d1_wlds, h->d_d1_bias, h->c1s, n, h->n_cu, s);
+          launch_contour_conv1(bf->zp, h->d_d1_wlds, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
           launch_contour_conv2(h->c1s, h->d_d2_w, h->b_contour2, bf->contour, n, h->n_cu, s);
         }
       }
       break;
     case BP_STAGE_NOTE:
       if ((ok = need(bf->contour) && need(bf->note)))
-        launch_note_branch(bf->contour, h->d_note_wfrag, h->d_note_wf32, bf->note, n, h->n_cu, s);
+        launch_note_branch(bf->contour, h->d_note_wfrag, h->d_note_wf32, bf->note, n, h->n_cu, wlo, s);
       break;
     case BP_STAGE_ONSET:
       if ((ok = need(bf->zp) && need(bf->note) && need(bf->onset)))
-        launch_onset_branch(bf->zp, bf->note, h->d_onset_wfrag, h->d_onset_wf32, bf->onset, n, h->n_cu, s);
+        launch_onset_branch(bf->zp, bf->note, h->d_onset_wfrag, h->d_onset_wf32, bf->onset, n, h->n_cu, wlo, s);
       break;
     default:
       h->err = "bp_run_stage: unknown stage";

@@ -147,7 +147,8 @@ __device__ __forceinline__ void stage_rows(const BranchParams& p, int b, int row
   }
 }
 
-template <class Br>
+// WLO = false: conv1 weights without a lo part (BP_FLAG_BF16_WEIGHTS): 2 MFMAs per k-step
+template <class Br, bool WLO>
 __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
   constexpr int KS1 = Br::KS1, KH2 = Br::KH2, PH1 = Br::PH1, PH2 = Br::PH2, NT2 = Br::NT2;
   __shared__ __attribute__((aligned(16))) uint4 img_hi[Br::RING * Br::SLOTS];
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
             __builtin_amdgcn_sched_barrier(0);
             const f16x8 ah = __builtin_bit_cast(f16x8, a1h[s]);
             const f16x8 al = __builtin_bit_cast(f16x8, a1l[s]);
-            accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhf[s], accc, 0, 0, 0);
+            if (WLO) accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhf[s], accc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhf[s], acc, 0, 0, 0);
             accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blf[s], accc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -368,22 +369,25 @@ void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, L
 }
 
 template <class Br>
-static void launch_branch(const BranchParams& p, int n_cu, hipStream_t stream) {
+static void launch_branch(const BranchParams& p, int n_cu, bool weights_have_lo, hipStream_t stream) {
   const int items = p.n_windows * kBrChunks;
   const int grid = items < 2 * n_cu ? items : 2 * n_cu;
-  hipLaunchKernelGGL(branch_kernel<Br>, dim3(grid), dim3(kBrThreads), 0, stream, p);
+  if (weights_have_lo)
+    hipLaunchKernelGGL((branch_kernel<Br, true>), dim3(grid), dim3(kBrThreads), 0, stream, p);
+  else
+    hipLaunchKernelGGL((branch_kernel<Br, false>), dim3(grid), dim3(kBrThreads), 0, stream, p);
 }
 
 void launch_note_branch(const float* contour, const void* wfrag, const float* wf32, float* note,
-                        int n_windows, int n_cu, hipStream_t stream) {
+                        int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream) {
   BranchParams p{static_cast<const uint4*>(wfrag), wf32, contour, nullptr, note, n_windows};
-  launch_branch<NoteBr>(p, n_cu, stream);
+  launch_branch<NoteBr>(p, n_cu, weights_have_lo, stream);
 }
 
 void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32,
-                         float* onset, int n_windows, int n_cu, hipStream_t stream) {
+                         float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream) {
   BranchParams p{static_cast<const uint4*>(wfrag), wf32, zp, note, onset, n_windows};
-  launch_branch<OnsetBr>(p, n_cu, stream);
+  launch_branch<OnsetBr>(p, n_cu, weights_have_lo, stream);
 }
 
 }  // namespace bp

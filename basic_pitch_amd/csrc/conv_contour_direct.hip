@@ -91,6 +91,8 @@ __device__ __forceinline__ void d1_gather(const uint32_t* __restrict__ zorigin, 
   for (int c = 0; c < 8; ++c) u[c] = zr[harm_shift(c)];
 }
 
+// WLO = false: the weights have no lo part (BP_FLAG_BF16_WEIGHTS): no lo fragment reads, 2 MFMAs per k-step
+template <bool WLO>
 __global__ __launch_bounds__(kD1Threads, 2) void contour_conv1_kernel(Conv1Params p) {
   __shared__ __attribute__((aligned(16))) uint4 img[2 * kD1LoOff];
   __shared__ __attribute__((aligned(16))) uint4 wl[2 * kD1WHalf];
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(kD1Threads, 2) void contour_conv1_kernel(Conv1Param
         const int r0 = (2 * ep + 1) & 3, q0 = (2 * ep + 1) >> 2;
         const int widx = aidx + (dt * kD1WTap + 2 * ep) * 8;
         const int sb = ((r0 == 1) ? lo_base[dt] : hi_base[dt]) + r0 * kD1Q + q0;
-        al[s] = __builtin_bit_cast(f16x8, wl[widx + kD1WHalf]);
+        if (WLO) al[s] = __builtin_bit_cast(f16x8, wl[widx + kD1WHalf]);
         bh[s] = __builtin_bit_cast(f16x8, img[sb]);
         ah[s] = __builtin_bit_cast(f16x8, wl[widx]);
         bl[s] = __builtin_bit_cast(f16x8, img[sb + kD1LoOff]);
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(kD1Threads, 2) void contour_conv1_kernel(Conv1Param
         if (s % 20 == 1 && s / 20 < kD1Stage) stage_issue(s / 20);
         if (s % 20 == 16 && s / 20 < kD1Stage) stage_put();
         __builtin_amdgcn_sched_barrier(0);
-        xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], xx, 0, 0, 0);
+        if (WLO) xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], xx, 0, 0, 0);
         hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s], hh, 0, 0, 0);
         xx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], xx, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -360,28 +362,37 @@ __global__ __launch_bounds__(256) void contour_conv2_kernel(Conv2Params p) {
 }
 
 void launch_contour_conv1(const uint32_t* zp, const void* wlds, const float* bias, float* c1, int n_windows,
-                          int n_cu, hipStream_t stream) {
+                          int n_cu, bool weights_have_lo, hipStream_t stream) {
   // one workgroup per CU; split windows into row chunks when there are fewer windows than CUs
   int chunks = 1;
   while (chunks < 4 && n_windows * chunks < n_cu) chunks *= 2;
   Conv1Params p{zp, static_cast<const uint4*>(wlds), bias, c1, n_windows, chunks};
   const int items = n_windows * chunks;
   const int grid = items < n_cu ? items : n_cu;
-  hipLaunchKernelGGL(contour_conv1_kernel, dim3(grid), dim3(kD1Threads), 0, stream, p);
+  if (weights_have_lo)
+    hipLaunchKernelGGL(contour_conv1_kernel<true>, dim3(grid), dim3(kD1Threads), 0, stream, p);
+  else
+    hipLaunchKernelGGL(contour_conv1_kernel<false>, dim3(grid), dim3(kD1Threads), 0, stream, p);
 }
 
 void launch_contour_conv2(const float* c1, const float* w2, float bias, float* contour, int n_windows, int n_cu,
                           hipStream_t stream) {
-  // as many frame slabs per window as keep every wave resident at once (2 waves per SIMD at ~220 VGPRs): a second,
-  // partially filled round of waves would double the kernel's duration
+  // Every wave of a launch should be resident at once (2 waves per SIMD at ~220 VGPRs): a second, partially filled
+  // round of waves doubles a launch's duration.  So: sub-batches of at most `per_launch` windows, each cut into as
+  // many frame slabs as fill the chip (>= 7 slabs keeps the 4-row halo re-read under 16 %).
   const int64_t slots = (int64_t)n_cu * 4 * 2 * 64;  // resident threads
-  int n_slabs = (int)(slots / ((int64_t)n_windows * kD2Strips));
-  n_slabs = n_slabs < 1 ? 1 : (n_slabs > 16 ? 16 : n_slabs);
-  const int slab_rows = (kFrames + n_slabs - 1) / n_slabs;
-  n_slabs = (kFrames + slab_rows - 1) / slab_rows;
-  Conv2Params p{c1, w2, bias, contour, n_windows, slab_rows, n_slabs};
-  const int64_t total = (int64_t)n_windows * n_slabs * kD2Strips;
-  hipLaunchKernelGGL(contour_conv2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+  int per_launch = (int)(slots / (7 * kD2Strips));
+  per_launch = per_launch < 1 ? 1 : per_launch;
+  for (int w0 = 0; w0 < n_windows; w0 += per_launch) {
+    const int n = n_windows - w0 < per_launch ? n_windows - w0 : per_launch;
+    int n_slabs = (int)(slots / ((int64_t)n * kD2Strips));
+    n_slabs = n_slabs < 1 ? 1 : (n_slabs > 16 ? 16 : n_slabs);
+    const int slab_rows = (kFrames + n_slabs - 1) / n_slabs;
+    n_slabs = (kFrames + slab_rows - 1) / slab_rows;
+    Conv2Params p{c1 + (int64_t)w0 * kC1Win, w2, bias, contour + (int64_t)w0 * kPlaneC, n, slab_rows, n_slabs};
+    const int64_t total = (int64_t)n * n_slabs * kD2Strips;
+    hipLaunchKernelGGL(contour_conv2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+  }
 }
 
 }  // namespace bp

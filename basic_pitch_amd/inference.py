@@ -71,6 +71,7 @@ class Model:
         max_windows: int = 256,
         stage_timing: bool = False,
         exact_f32_mfma: bool = False,
+        bf16_weights: bool = False,
     ):
         self.model_type = Model.MODEL_TYPES.MI355X_HIP
         self._lib = _native.load_library()
@@ -82,6 +83,8 @@ class Model:
         flags = _native.BP_FLAG_STAGE_TIMING if stage_timing else 0
         if exact_f32_mfma:  # A/B reference: contour conv1 on the exact-f32 MFMA kernel
             flags |= _native.BP_FLAG_F32_MFMA
+        if bf16_weights:  # BASELINE.json configs[3]: conv weights rounded to bf16, 2 matrix instructions per product
+            flags |= _native.BP_FLAG_BF16_WEIGHTS
         rc = self._lib.bp_create(blob, len(blob), int(device), flags, int(max_windows), C.byref(self._handle))
         if rc != _native.BP_OK:
             self._handle = C.c_void_p()

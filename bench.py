@@ -123,6 +123,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact-f32", action="store_true", help="contour conv1 on the exact-f32 MFMA kernel (A/B)")
+    ap.add_argument("--bf16-weights", action="store_true",
+                    help="BASELINE.json configs[3]: bf16 CNN weights + fp32 CQT (use with --batch 1024); not the headline line")
     args = ap.parse_args()
 
     import torch
@@ -152,7 +154,8 @@ def main() -> None:
         "onset": torch.empty((B, 172, 88), device=dev),
         "contour": torch.empty((B, 172, 264), device=dev),
     }
-    model = Model(device=local_rank, max_windows=B, stage_timing=True, exact_f32_mfma=args.exact_f32)
+    model = Model(device=local_rank, max_windows=B, stage_timing=True, exact_f32_mfma=args.exact_f32,
+                  bf16_weights=args.bf16_weights)
 
     def step():
         model._predict_device(audio, out=out, sync=False)
@@ -199,7 +202,7 @@ def main() -> None:
             c1_kernel = ("contour_conv1_kernel (harmonic stack + Conv2D 8->8 3x39 + ReLU; f16 MFMA 32x32x16 on hi/lo-split "
                          "operands from LDS, fp32 accumulate, no K split)")
             c1_peak = F16_MFMA_PEAK_TFLOPS
-            c1_exec = D1_EXECUTED_FLOP_PER_WINDOW * B / (c1_ms * 1e-3) / 1e12
+            c1_exec = D1_EXECUTED_FLOP_PER_WINDOW * (2 / 3 if args.bf16_weights else 1) * B / (c1_ms * 1e-3) / 1e12
             c1_bytes = D1_BYTES_PER_WINDOW * B
             c1_key = "contour_conv1_kernel"
         else:
@@ -223,11 +226,14 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",  # fp32 data and accumulation; matrix products on f16 hi+lo operand pairs (22 bits)
+            # fp32 data and accumulation; matrix products on f16 hi+lo operand pairs (22 bits); --bf16-weights: conv
+            # weights rounded to bf16 (one f16 operand), activations and CQT unchanged
+            "dtype": "bf16 weights / f32" if args.bf16_weights else "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"batch={B} synthetic uniform[-1,1) 2 s @ 22.05 kHz mono windows per GPU, fp32, "
-                "HBM-resident in/out (BASELINE.json configs[1])",
+                "workload": f"batch={B} synthetic uniform[-1,1) 2 s @ 22.05 kHz mono windows per GPU, "
+                + ("bf16 CNN weights + fp32 CQT, HBM-resident in/out (BASELINE.json configs[3])" if args.bf16_weights
+                   else "fp32, HBM-resident in/out (BASELINE.json configs[1])"),
                 "windows_per_step_per_gpu": B,
                 "sharding": "independent windows per rank, no collective",
             },

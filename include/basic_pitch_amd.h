@@ -65,6 +65,12 @@ typedef enum bp_mem_kind {
                                    HBM) instead of the default split-precision path (operands split into
                                    f16 hi + lo, three f16 MFMAs per product, fp32 accumulate: fp32-class
                                    accuracy at the f16 matrix rate; note / onset branches fused) */
+#define BP_FLAG_BF16_WEIGHTS 4u /* BASELINE.json configs[3]: the six Conv2D weight tensors are rounded to bf16 at
+                                 * bp_create (biases, CQT constants and all activations keep fp32-class precision);
+                                 * a bf16 value is one f16 operand, so every conv1 product needs 2 matrix
+                                 * instructions instead of 3.  Results follow the graph with bf16-rounded weights to
+                                 * the usual 1e-4; against the fp32-weight graph the rounding itself costs up to
+                                 * ~5e-3.  Ignored with BP_FLAG_F32_MFMA. */
 
 /*
  * Weights blob ("BPAMDW01", little endian) — produced by tools/extract_weights.py from the
