@@ -105,6 +105,9 @@ EXPORTED_SYMBOLS = [
     "bp_infer",
     "bp_infer_async",
     "bp_infer_track",
+    "bp_resampled_length",
+    "bp_resample",
+    "bp_infer_pcm",
     "bp_track_n_windows",
     "bp_track_n_frames",
     "bp_set_stream",
@@ -150,6 +153,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bp_infer_async.restype = C.c_int
     lib.bp_infer_track.argtypes = [vp, fp, i64, fp, fp, fp, C.c_int]
     lib.bp_infer_track.restype = C.c_int
+    lib.bp_resampled_length.argtypes = [i64, C.c_int]
+    lib.bp_resampled_length.restype = i64
+    lib.bp_resample.argtypes = [vp, fp, i64, C.c_int, C.c_int, fp, C.c_int]
+    lib.bp_resample.restype = C.c_int
+    lib.bp_infer_pcm.argtypes = [vp, fp, i64, C.c_int, C.c_int, fp, fp, fp, C.c_int]
+    lib.bp_infer_pcm.restype = C.c_int
     lib.bp_track_n_windows.argtypes = [i64]
     lib.bp_track_n_windows.restype = i64
     lib.bp_track_n_frames.argtypes = [i64]

@@ -45,6 +45,10 @@ void launch_filterbank_mfma(const float* audio, const float* pyr, const void* bf
                             float* lp, int* mm, float* scratch, int n_windows, LogConsts kc, int n_cu,
                             hipStream_t s);
 void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc, hipStream_t s);
+ResamplePlan make_resample_plan(int source_rate, int target_rate, std::vector<double>& taps);
+void launch_downmix(const float* pcm, int64_t n_frames, int channels, float* mono, hipStream_t stream);
+void launch_resample(const float* x, int64_t n_in, const double* taps, const ResamplePlan& pl, float* y,
+                     int64_t n_out, hipStream_t stream);
 void launch_contour_conv1(const uint32_t* zp, const void* wlds, const float* bias, float* c1, int n_windows,
                           int n_cu, bool weights_have_lo, hipStream_t stream);
 void launch_contour_conv2(const float* c1, const float* w2, float bias, float* contour, int n_windows, int n_cu,
@@ -170,6 +174,12 @@ struct bp_context {
   // track path staging (grow-only)
   float* track = nullptr;
   int64_t track_cap = 0;
+  // audio ingest (audio_ingest.hip): staging for PCM / mono / 22.05 kHz signal (grow-only), cached filter
+  float *pcm_dev = nullptr, *mono_dev = nullptr, *res_dev = nullptr;
+  int64_t pcm_cap = 0, mono_cap = 0, res_cap = 0;
+  double* taps_dev = nullptr;
+  int taps_rate = 0;
+  ResamplePlan plan{1, 1, 0, 0, 0};
   float* track_out = nullptr;  // [T, 88+88+264] staging when outputs are host pointers
   int64_t track_out_cap = 0;
 
@@ -490,7 +500,7 @@ int free_all(bp_handle h) {
   float* ptrs[] = {h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_bias, h->d_d2_w, h->d_cb_wfrag, h->d_cb_wf32, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
-                   h->track_out, h->fb_scratch};
+                   h->track_out, h->fb_scratch, h->pcm_dev, h->mono_dev, h->res_dev, reinterpret_cast<float*>(h->taps_dev)};
   for (float* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->mm) (void)hipFree(h->mm);
@@ -882,36 +892,14 @@ int64_t bp_track_n_frames(int64_t n_samples) {
   return rows < avail ? rows : avail;
 }
 
-int bp_infer_track(bp_handle h, const float* samples, int64_t n_samples, float* note, float* onset,
-                   float* contour, int mem_kind) {
-  if (!h) return BP_ERR_INVALID_ARG;
-  if (n_samples < 0 || (mem_kind != BP_MEM_HOST && mem_kind != BP_MEM_DEVICE)) {
-    h->err = "bp_infer_track: bad argument";
-    return BP_ERR_INVALID_ARG;
-  }
+// windows of a device-resident 22.05 kHz signal -> un-overlapped posteriorgrams (host or device outputs)
+static int track_core(bp_handle h, const float* d_samples, int64_t n_samples, float* note, float* onset,
+                      float* contour, int out_kind) {
+  hipStream_t s = h->stream;
   const int64_t n_win = bp_track_n_windows(n_samples);
   const int64_t T = bp_track_n_frames(n_samples);
-  if (n_win == 0) return BP_OK;
-  if (!samples || (T > 0 && (!note || !onset || !contour))) {
-    h->err = "bp_infer_track: null pointer";
-    return BP_ERR_INVALID_ARG;
-  }
-  BP_HIP(hipSetDevice(h->device));
-  hipStream_t s = h->stream;
-  const float* d_samples = samples;
-  if (mem_kind == BP_MEM_HOST) {
-    if (n_samples > h->track_cap) {
-      if (h->track) BP_HIP(hipFree(h->track));
-      h->track = nullptr;
-      h->track_cap = 0;
-      BP_HIP(hipMalloc(&h->track, (size_t)n_samples * 4));
-      h->track_cap = n_samples;
-    }
-    BP_HIP(hipMemcpyAsync(h->track, samples, (size_t)n_samples * 4, hipMemcpyHostToDevice, s));
-    d_samples = h->track;
-  }
   float *d_note = note, *d_onset = onset, *d_contour = contour;
-  if (mem_kind == BP_MEM_HOST) {
+  if (out_kind == BP_MEM_HOST) {
     const int64_t need = T * (88 + 88 + 264);
     if (need > h->track_out_cap) {
       if (h->track_out) BP_HIP(hipFree(h->track_out));
@@ -936,13 +924,141 @@ int bp_infer_track(bp_handle h, const float* samples, int64_t n_samples, float* 
     }
   }
   BP_HIP(hipGetLastError());
-  if (mem_kind == BP_MEM_HOST && T > 0) {
+  if (out_kind == BP_MEM_HOST && T > 0) {
     BP_HIP(hipMemcpyAsync(note, d_note, (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
     BP_HIP(hipMemcpyAsync(onset, d_onset, (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
     BP_HIP(hipMemcpyAsync(contour, d_contour, (size_t)T * 264 * 4, hipMemcpyDeviceToHost, s));
   }
   BP_HIP(hipStreamSynchronize(s));
   return BP_OK;
+}
+
+static int grow(bp_handle h, float** buf, int64_t* cap, int64_t need) {
+  if (need <= *cap) return BP_OK;
+  if (*buf) BP_HIP(hipFree(*buf));
+  *buf = nullptr;
+  *cap = 0;
+  BP_HIP(hipMalloc(buf, (size_t)(need > 0 ? need : 1) * 4));
+  *cap = need;
+  return BP_OK;
+}
+
+int bp_infer_track(bp_handle h, const float* samples, int64_t n_samples, float* note, float* onset,
+                   float* contour, int mem_kind) {
+  if (!h) return BP_ERR_INVALID_ARG;
+  if (n_samples < 0 || (mem_kind != BP_MEM_HOST && mem_kind != BP_MEM_DEVICE)) {
+    h->err = "bp_infer_track: bad argument";
+    return BP_ERR_INVALID_ARG;
+  }
+  const int64_t n_win = bp_track_n_windows(n_samples);
+  const int64_t T = bp_track_n_frames(n_samples);
+  if (n_win == 0) return BP_OK;
+  if (!samples || (T > 0 && (!note || !onset || !contour))) {
+    h->err = "bp_infer_track: null pointer";
+    return BP_ERR_INVALID_ARG;
+  }
+  BP_HIP(hipSetDevice(h->device));
+  const float* d_samples = samples;
+  if (mem_kind == BP_MEM_HOST) {
+    int rc = grow(h, &h->track, &h->track_cap, n_samples);
+    if (rc) return rc;
+    BP_HIP(hipMemcpyAsync(h->track, samples, (size_t)n_samples * 4, hipMemcpyHostToDevice, h->stream));
+    d_samples = h->track;
+  }
+  return track_core(h, d_samples, n_samples, note, onset, contour, mem_kind);
+}
+
+int64_t bp_resampled_length(int64_t n_frames, int sample_rate) {
+  if (n_frames <= 0 || sample_rate <= 0) return 0;
+  return (n_frames * (int64_t)BP_AUDIO_SAMPLE_RATE + sample_rate - 1) / sample_rate;
+}
+
+// downmix + resample into h->res_dev (or straight through when already mono 22.05 kHz on the device);
+// *out = device pointer of the 22.05 kHz signal, *n_out = its length
+static int ingest(bp_handle h, const float* pcm, int64_t n_frames, int channels, int sample_rate, int mem_kind,
+                  const float** out, int64_t* n_out) {
+  if (n_frames < 0 || channels < 1 || channels > 64 || sample_rate < 1000 || sample_rate > 768000 ||
+      (mem_kind != BP_MEM_HOST && mem_kind != BP_MEM_DEVICE) || (n_frames > 0 && !pcm)) {
+    h->err = "audio ingest: bad argument (n_frames, channels, sample_rate, mem_kind or null pcm)";
+    return BP_ERR_INVALID_ARG;
+  }
+  BP_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  *n_out = bp_resampled_length(n_frames, sample_rate);
+  *out = nullptr;
+  if (n_frames == 0) return BP_OK;
+  const float* d_pcm = pcm;
+  if (mem_kind == BP_MEM_HOST) {
+    int rc = grow(h, &h->pcm_dev, &h->pcm_cap, n_frames * channels);
+    if (rc) return rc;
+    BP_HIP(hipMemcpyAsync(h->pcm_dev, pcm, (size_t)n_frames * channels * 4, hipMemcpyHostToDevice, s));
+    d_pcm = h->pcm_dev;
+  }
+  const float* d_mono = d_pcm;
+  if (channels > 1) {
+    int rc = grow(h, &h->mono_dev, &h->mono_cap, n_frames);
+    if (rc) return rc;
+    launch_downmix(d_pcm, n_frames, channels, h->mono_dev, s);
+    d_mono = h->mono_dev;
+  }
+  if (sample_rate == BP_AUDIO_SAMPLE_RATE) {
+    *out = d_mono;
+    return BP_OK;
+  }
+  if (h->taps_rate != sample_rate) {
+    std::vector<double> taps;
+    const ResamplePlan pl = make_resample_plan(sample_rate, BP_AUDIO_SAMPLE_RATE, taps);
+    if (pl.up > 2000 || pl.down > 2000) {
+      h->err = "audio ingest: sample-rate ratio too irregular (reduced up / down factor > 2000)";
+      return BP_ERR_INVALID_ARG;
+    }
+    if (h->taps_dev) BP_HIP(hipFree(h->taps_dev));
+    h->taps_dev = nullptr;
+    h->taps_rate = 0;
+    BP_HIP(hipMalloc(&h->taps_dev, taps.size() * sizeof(double)));
+    BP_HIP(hipMemcpy(h->taps_dev, taps.data(), taps.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->plan = pl;
+    h->taps_rate = sample_rate;
+  }
+  int rc = grow(h, &h->res_dev, &h->res_cap, *n_out);
+  if (rc) return rc;
+  launch_resample(d_mono, n_frames, h->taps_dev, h->plan, h->res_dev, *n_out, s);
+  BP_HIP(hipGetLastError());
+  *out = h->res_dev;
+  return BP_OK;
+}
+
+int bp_resample(bp_handle h, const float* pcm, int64_t n_frames, int channels, int sample_rate, float* out22k,
+                int mem_kind) {
+  if (!h) return BP_ERR_INVALID_ARG;
+  const float* d = nullptr;
+  int64_t n_out = 0;
+  int rc = ingest(h, pcm, n_frames, channels, sample_rate, mem_kind, &d, &n_out);
+  if (rc) return rc;
+  if (n_out == 0) return BP_OK;
+  if (!out22k) {
+    h->err = "bp_resample: out22k is NULL";
+    return BP_ERR_INVALID_ARG;
+  }
+  BP_HIP(hipMemcpyAsync(out22k, d, (size_t)n_out * 4,
+                        mem_kind == BP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->stream));
+  BP_HIP(hipStreamSynchronize(h->stream));
+  return BP_OK;
+}
+
+int bp_infer_pcm(bp_handle h, const float* pcm, int64_t n_frames, int channels, int sample_rate, float* note,
+                 float* onset, float* contour, int mem_kind) {
+  if (!h) return BP_ERR_INVALID_ARG;
+  const float* d = nullptr;
+  int64_t n = 0;
+  int rc = ingest(h, pcm, n_frames, channels, sample_rate, mem_kind, &d, &n);
+  if (rc) return rc;
+  if (bp_track_n_windows(n) == 0) return BP_OK;
+  if (bp_track_n_frames(n) > 0 && (!note || !onset || !contour)) {
+    h->err = "bp_infer_pcm: null output pointer";
+    return BP_ERR_INVALID_ARG;
+  }
+  return track_core(h, d, n, note, onset, contour, mem_kind);
 }
 
 int bp_get_stage_ms(bp_handle h, float* ms, int n) {

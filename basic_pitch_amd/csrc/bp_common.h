@@ -78,6 +78,14 @@ __device__ __forceinline__ float norm_bn(float lp, float mn, float range, const 
   return __fadd_rn(__fmul_rn(nrm, k.bn_a), k.bn_b);  // Mul then Add in the frozen graph: no FMA contraction
 }
 
+// rational polyphase resampler (audio_ingest.hip): scipy.signal.resample_poly's alignment for up / down
+struct ResamplePlan {
+  int up, down;
+  int n_taps;        // 2 * 10 * max(up, down) + 1
+  int n_pre_pad;     // zeros scipy prepends to the filter
+  int n_pre_remove;  // leading outputs scipy drops
+};
+
 __device__ __forceinline__ float sigmoidf_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }

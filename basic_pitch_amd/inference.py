@@ -195,6 +195,45 @@ class Model:
         _native.check(self._lib, self._handle, rc, "bp_infer_track")
         return out
 
+    @staticmethod
+    def _as_pcm(pcm: np.ndarray) -> np.ndarray:
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        if pcm.ndim == 1:
+            pcm = pcm[:, None]
+        if pcm.ndim != 2 or pcm.shape[1] < 1:
+            raise ValueError("expected PCM as float32 [n_frames] or [n_frames, channels]")
+        return pcm
+
+    def resample(self, pcm: np.ndarray, sample_rate: int) -> np.ndarray:
+        """Decoded PCM [n_frames(, channels)] at `sample_rate` -> mono 22.05 kHz float32, computed on the device
+        (channel mean + polyphase FIR; the `librosa.load(..., sr=22050, mono=True)` tail of inference.py:239)."""
+        pcm = self._as_pcm(pcm)
+        n_out = int(self._lib.bp_resampled_length(pcm.shape[0], int(sample_rate)))
+        out = np.empty((n_out,), dtype=np.float32)
+        rc = self._lib.bp_resample(
+            self._handle, pcm.ctypes.data, pcm.shape[0], pcm.shape[1], int(sample_rate), out.ctypes.data, _native.BP_MEM_HOST
+        )
+        _native.check(self._lib, self._handle, rc, "bp_resample")
+        return out
+
+    def predict_pcm(self, pcm: np.ndarray, sample_rate: int) -> Dict[str, np.ndarray]:
+        """Decoded PCM at any rate / channel count -> un-overlapped posteriorgrams: downmix, resampling, windowing,
+        CQT + CNN and un-overlapping all on the device (bp_infer_pcm)."""
+        pcm = self._as_pcm(pcm)
+        n22 = int(self._lib.bp_resampled_length(pcm.shape[0], int(sample_rate)))
+        T = int(self._lib.bp_track_n_frames(n22))
+        out = {
+            "note": np.empty((T, N_FREQ_BINS_NOTES), dtype=np.float32),
+            "onset": np.empty((T, N_FREQ_BINS_NOTES), dtype=np.float32),
+            "contour": np.empty((T, N_FREQ_BINS_CONTOURS), dtype=np.float32),
+        }
+        rc = self._lib.bp_infer_pcm(
+            self._handle, pcm.ctypes.data, pcm.shape[0], pcm.shape[1], int(sample_rate),
+            out["note"].ctypes.data, out["onset"].ctypes.data, out["contour"].ctypes.data, _native.BP_MEM_HOST,
+        )
+        _native.check(self._lib, self._handle, rc, "bp_infer_pcm")
+        return out
+
     # -- introspection ----------------------------------------------------------------------------
     def info(self) -> Dict[str, Any]:
         inf = _native.bp_info()
@@ -268,9 +307,11 @@ def run_inference(
     overlap_len = n_overlapping_frames * FFT_HOP
     hop_size = AUDIO_N_SAMPLES - overlap_len
 
-    audio_original, _ = _audio.load(str(audio_path), sr=AUDIO_SAMPLE_RATE, mono=True)
-    audio_original_length = audio_original.shape[0]
-    unwrapped_output = model.predict_track(audio_original)
+    # decode on the host (container parsing), everything after it on the device: channel-mean downmix, resampling
+    # to 22.05 kHz, the 3840-sample lead-in + windowing, CQT + CNN, un-overlapping (inference.py:239-244, 302-315)
+    pcm, file_sr = _audio.read_wav(str(audio_path))
+    audio_original_length = int(-(-pcm.shape[0] * AUDIO_SAMPLE_RATE // file_sr))  # librosa.resample: ceil(n * sr / file_sr)
+    unwrapped_output = model.predict_pcm(pcm, file_sr)
 
     if debug_file:
         with open(debug_file, "w") as f:

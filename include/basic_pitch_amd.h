@@ -117,6 +117,23 @@ int bp_infer_async(bp_handle h, const float* audio_dev, int64_t n_windows, float
 int bp_infer_track(bp_handle h, const float* samples, int64_t n_samples, float* note, float* onset,
                    float* contour, int mem_kind);
 
+/*
+ * Replaces: the decode-side tail of librosa.load(path, sr=22050, mono=True) (inference.py:239) for PCM that is
+ * already decoded: channel-mean downmix (librosa.to_mono) + rational polyphase resampling to 22.05 kHz, on the
+ * device.  `pcm` = interleaved float32 [n_frames][channels] at `sample_rate` Hz (host or device per mem_kind).
+ * The resampler is scipy.signal.resample_poly's default design (librosa's soxr_hq needs libsoxr: DESIGN.md §2).
+ *   bp_resampled_length  ceil(n_frames * 22050 / sample_rate) samples (librosa.resample's output length)
+ *   bp_resample          the mono 22.05 kHz signal itself -> out22k [bp_resampled_length] (host or device)
+ *   bp_infer_pcm         bp_resample + bp_infer_track without the signal leaving the device; outputs as
+ *                        bp_infer_track with T = bp_track_n_frames(bp_resampled_length(n_frames, sample_rate))
+ * Errors: BP_ERR_INVALID_ARG for channels < 1, sample_rate < 1000 or ratios whose reduced up / down exceed 2000.
+ */
+int64_t bp_resampled_length(int64_t n_frames, int sample_rate);
+int bp_resample(bp_handle h, const float* pcm, int64_t n_frames, int channels, int sample_rate, float* out22k,
+                int mem_kind);
+int bp_infer_pcm(bp_handle h, const float* pcm, int64_t n_frames, int channels, int sample_rate, float* note,
+                 float* onset, float* contour, int mem_kind);
+
 /* ceil((n_samples + 3840) / 36164) windows (inference.py:207,242); 0 for n_samples <= 0 */
 int64_t bp_track_n_windows(int64_t n_samples);
 /* min(n_windows*142, int(n_samples / 36164 * 142)) rows (inference.py:277-279) */

@@ -324,6 +324,36 @@ def test_track_path_equals_windowed_path_and_golden(weights, clip_22k):
     m.close()
 
 
+def test_device_audio_ingest(weights):
+    """downmix + resampling on the device.  bp_resample must reproduce the host ingest
+    (basic_pitch_amd/audio.py = scipy.signal.resample_poly in float64, rounded to float32) for the rate pairs that
+    occur in practice, mono and multi-channel, and bp_infer_pcm must equal resample-then-bp_infer_track bit for bit."""
+    from basic_pitch_amd import Model, audio as A
+
+    m = Model(max_windows=8)
+    rng = np.random.default_rng(3)
+    for sr, ch, n in ((44100, 2, 150001), (48000, 1, 96000), (16000, 3, 40000), (8000, 1, 9999), (22050, 2, 50000),
+                      (32000, 1, 1), (11025, 2, 30000)):
+        pcm = rng.uniform(-1, 1, (n, ch)).astype(np.float32)
+        t = np.arange(n) / sr
+        pcm[:, 0] += 0.5 * np.sin(2 * np.pi * 440.0 * t).astype(np.float32)
+        ref = A.resample(np.ascontiguousarray(A.to_mono(pcm)), sr, 22050)
+        got = m.resample(pcm, sr)
+        assert got.shape == ref.shape == (int(np.ceil(n * 22050 / sr)),), (sr, got.shape, ref.shape)
+        assert np.abs(got - ref).max() <= 2e-6, (sr, ch, np.abs(got - ref).max())
+    # whole-path equivalence on the reference's 44.1 kHz clip
+    pcm, sr = A.read_wav(os.path.join(GOLDEN, "vocadito_10.wav"))
+    a = m.predict_pcm(pcm, sr)
+    b = m.predict_track(m.resample(pcm, sr))
+    for k in a:
+        assert a[k].shape[0] == 787 and np.array_equal(a[k], b[k]), k
+    with pytest.raises(ValueError):
+        m.resample(pcm, 0)
+    e = m.predict_pcm(np.zeros((0, 2), np.float32), 44100)
+    assert e["note"].shape == (0, 88)
+    m.close()
+
+
 def test_predict_note_events_match_reference_golden(tmp_path):
     """BASELINE.json north star: MIDI note events identical to the reference's on its test clip.
     `predict()` end to end (decode + resample on the host, CQT + CNN on the MI355X, note decoding in C++)
