@@ -105,6 +105,7 @@ EXPORTED_SYMBOLS = [
     "bp_infer",
     "bp_infer_async",
     "bp_infer_track",
+    "bp_infer_tracks",
     "bp_resampled_length",
     "bp_resample",
     "bp_infer_pcm",
@@ -153,6 +154,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bp_infer_async.restype = C.c_int
     lib.bp_infer_track.argtypes = [vp, fp, i64, fp, fp, fp, C.c_int]
     lib.bp_infer_track.restype = C.c_int
+    lib.bp_infer_tracks.argtypes = [vp, i64, vp, vp, vp, vp, vp, C.c_int]
+    lib.bp_infer_tracks.restype = C.c_int
     lib.bp_resampled_length.argtypes = [i64, C.c_int]
     lib.bp_resampled_length.restype = i64
     lib.bp_resample.argtypes = [vp, fp, i64, C.c_int, C.c_int, fp, C.c_int]

@@ -968,6 +968,113 @@ int bp_infer_track(bp_handle h, const float* samples, int64_t n_samples, float* 
   return track_core(h, d_samples, n_samples, note, onset, contour, mem_kind);
 }
 
+int bp_infer_tracks(bp_handle h, int64_t n_tracks, const float* const* samples, const int64_t* n_samples,
+                    float* const* note, float* const* onset, float* const* contour, int mem_kind) {
+  if (!h) return BP_ERR_INVALID_ARG;
+  if (n_tracks < 0 || (mem_kind != BP_MEM_HOST && mem_kind != BP_MEM_DEVICE) ||
+      (n_tracks > 0 && (!samples || !n_samples || !note || !onset || !contour))) {
+    h->err = "bp_infer_tracks: bad argument";
+    return BP_ERR_INVALID_ARG;
+  }
+  int64_t total_samples = 0, total_rows = 0;
+  for (int64_t t = 0; t < n_tracks; ++t) {
+    if (n_samples[t] < 0 || (n_samples[t] > 0 && !samples[t])) {
+      h->err = "bp_infer_tracks: negative length or null samples";
+      return BP_ERR_INVALID_ARG;
+    }
+    const int64_t T = bp_track_n_frames(n_samples[t]);
+    if (T > 0 && (!note[t] || !onset[t] || !contour[t])) {
+      h->err = "bp_infer_tracks: null output pointer";
+      return BP_ERR_INVALID_ARG;
+    }
+    total_samples += n_samples[t];
+    total_rows += T;
+  }
+  if (total_samples == 0) return BP_OK;
+  BP_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  // device views of every track's input and outputs
+  std::vector<const float*> d_in(n_tracks);
+  std::vector<float*> d_note(n_tracks), d_onset(n_tracks), d_contour(n_tracks);
+  if (mem_kind == BP_MEM_HOST) {
+    int rc = grow(h, &h->track, &h->track_cap, total_samples);
+    if (rc) return rc;
+    rc = grow(h, &h->track_out, &h->track_out_cap, total_rows * (88 + 88 + 264));
+    if (rc) return rc;
+    int64_t so = 0, ro = 0;
+    for (int64_t t = 0; t < n_tracks; ++t) {
+      const int64_t T = bp_track_n_frames(n_samples[t]);
+      if (n_samples[t] > 0)
+        BP_HIP(hipMemcpyAsync(h->track + so, samples[t], (size_t)n_samples[t] * 4, hipMemcpyHostToDevice, s));
+      d_in[t] = h->track + so;
+      d_note[t] = h->track_out + ro * 440;
+      d_onset[t] = d_note[t] + T * 88;
+      d_contour[t] = d_onset[t] + T * 88;
+      so += n_samples[t];
+      ro += T;
+    }
+  } else {
+    for (int64_t t = 0; t < n_tracks; ++t) {
+      d_in[t] = samples[t];
+      d_note[t] = note[t];
+      d_onset[t] = onset[t];
+      d_contour[t] = contour[t];
+    }
+  }
+  struct Seg {
+    int64_t track, w0;
+    int n, at;
+  };
+  std::vector<Seg> segs;
+  int cur = 0;
+  auto flush = [&]() -> int {
+    if (cur == 0) return BP_OK;
+    int rc = run_chunk(h, h->audio, cur, h->note, h->onset, h->contour);
+    if (rc) return rc;
+    for (const Seg& g : segs) {
+      const int64_t T = bp_track_n_frames(n_samples[g.track]);
+      if (T <= 0) continue;
+      launch_unwrap(h->note + (int64_t)g.at * kPlaneN, 88, g.w0, g.n, T, d_note[g.track], s);
+      launch_unwrap(h->onset + (int64_t)g.at * kPlaneN, 88, g.w0, g.n, T, d_onset[g.track], s);
+      launch_unwrap(h->contour + (int64_t)g.at * kPlaneC, 264, g.w0, g.n, T, d_contour[g.track], s);
+    }
+    segs.clear();
+    cur = 0;
+    return BP_OK;
+  };
+  for (int64_t t = 0; t < n_tracks; ++t) {
+    const int64_t n_win = bp_track_n_windows(n_samples[t]);
+    for (int64_t w0 = 0; w0 < n_win;) {
+      const int64_t room = h->cap - cur;
+      const int n = (int)((n_win - w0) < room ? (n_win - w0) : room);
+      launch_window_track(d_in[t], n_samples[t], w0, n, h->audio + (int64_t)cur * kAudioN, s);
+      segs.push_back({t, w0, n, cur});
+      cur += n;
+      w0 += n;
+      if (cur == h->cap) {
+        int rc = flush();
+        if (rc) return rc;
+      }
+    }
+  }
+  {
+    int rc = flush();
+    if (rc) return rc;
+  }
+  BP_HIP(hipGetLastError());
+  if (mem_kind == BP_MEM_HOST) {
+    for (int64_t t = 0; t < n_tracks; ++t) {
+      const int64_t T = bp_track_n_frames(n_samples[t]);
+      if (T <= 0) continue;
+      BP_HIP(hipMemcpyAsync(note[t], d_note[t], (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
+      BP_HIP(hipMemcpyAsync(onset[t], d_onset[t], (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
+      BP_HIP(hipMemcpyAsync(contour[t], d_contour[t], (size_t)T * 264 * 4, hipMemcpyDeviceToHost, s));
+    }
+  }
+  BP_HIP(hipStreamSynchronize(s));
+  return BP_OK;
+}
+
 int64_t bp_resampled_length(int64_t n_frames, int sample_rate) {
   if (n_frames <= 0 || sample_rate <= 0) return 0;
   return (n_frames * (int64_t)BP_AUDIO_SAMPLE_RATE + sample_rate - 1) / sample_rate;

@@ -195,6 +195,72 @@ class Model:
         _native.check(self._lib, self._handle, rc, "bp_infer_track")
         return out
 
+    def predict_tracks(self, tracks: "List[Any]") -> "List[Dict[str, Any]]":
+        """Several mono 22.05 kHz tracks in one call, windows packed across track boundaries into full batches
+        (bp_infer_tracks).  All numpy arrays (host in / host out) or all 1-D float32 CUDA tensors (device in / out)."""
+        n = len(tracks)
+        if n == 0:
+            return []
+        on_device = all(hasattr(t, "is_cuda") and t.is_cuda for t in tracks)
+        if on_device:
+            import torch
+
+            tr = [t.contiguous() for t in tracks]
+            if any(t.dtype != torch.float32 or t.dim() != 1 for t in tr):
+                raise ValueError("expected 1-D float32 CUDA tensors")
+            lens = [int(t.shape[0]) for t in tr]
+            outs = [
+                {k: torch.empty((int(self._lib.bp_track_n_frames(L)), w), dtype=torch.float32, device=tr[0].device)
+                 for k, w in (("note", N_FREQ_BINS_NOTES), ("onset", N_FREQ_BINS_NOTES), ("contour", N_FREQ_BINS_CONTOURS))}
+                for L in lens
+            ]
+            ptr = lambda a: a.data_ptr()  # noqa: E731
+            kind = _native.BP_MEM_DEVICE
+            self._lib.bp_set_stream(self._handle, C.c_void_p(torch.cuda.current_stream(tr[0].device).cuda_stream))
+        else:
+            tr = [np.ascontiguousarray(t, dtype=np.float32) for t in tracks]
+            if any(t.ndim != 1 for t in tr):
+                raise ValueError("predict_tracks expects 1-D mono signals")
+            lens = [int(t.shape[0]) for t in tr]
+            outs = [
+                {k: np.empty((int(self._lib.bp_track_n_frames(L)), w), dtype=np.float32)
+                 for k, w in (("note", N_FREQ_BINS_NOTES), ("onset", N_FREQ_BINS_NOTES), ("contour", N_FREQ_BINS_CONTOURS))}
+                for L in lens
+            ]
+            ptr = lambda a: a.ctypes.data  # noqa: E731
+            kind = _native.BP_MEM_HOST
+        arr = lambda vals: (C.c_void_p * n)(*[C.c_void_p(v) for v in vals])  # noqa: E731
+        rc = self._lib.bp_infer_tracks(
+            self._handle, n, arr([ptr(t) for t in tr]), (C.c_int64 * n)(*lens),
+            arr([ptr(o["note"]) for o in outs]), arr([ptr(o["onset"]) for o in outs]),
+            arr([ptr(o["contour"]) for o in outs]), kind,
+        )
+        _native.check(self._lib, self._handle, rc, "bp_infer_tracks")
+        return outs
+
+    def _predict_track_device(self, samples: "Any", out: Optional[Dict[str, "Any"]] = None) -> Dict[str, "Any"]:
+        """Device-resident mono 22.05 kHz track (1-D float32 CUDA tensor) -> device posteriorgrams (zero copy)."""
+        import torch
+
+        if not (samples.is_cuda and samples.dtype == torch.float32 and samples.dim() == 1):
+            raise ValueError("expected a 1-D float32 CUDA tensor")
+        samples = samples.contiguous()
+        n = int(samples.shape[0])
+        T = int(self._lib.bp_track_n_frames(n))
+        if out is None:
+            out = {
+                "note": torch.empty((T, N_FREQ_BINS_NOTES), dtype=torch.float32, device=samples.device),
+                "onset": torch.empty((T, N_FREQ_BINS_NOTES), dtype=torch.float32, device=samples.device),
+                "contour": torch.empty((T, N_FREQ_BINS_CONTOURS), dtype=torch.float32, device=samples.device),
+            }
+        self._lib.bp_set_stream(self._handle, C.c_void_p(torch.cuda.current_stream(samples.device).cuda_stream))
+        rc = self._lib.bp_infer_track(
+            self._handle, samples.data_ptr(), n, out["note"].data_ptr(), out["onset"].data_ptr(),
+            out["contour"].data_ptr(), _native.BP_MEM_DEVICE,
+        )
+        _native.check(self._lib, self._handle, rc, "bp_infer_track")
+        return out
+
     @staticmethod
     def _as_pcm(pcm: np.ndarray) -> np.ndarray:
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)

@@ -115,6 +115,79 @@ def cpu_baseline(seconds_budget: float = 12.0) -> dict:
     }
 
 
+def run_tracks(args, torch, dist, world, rank, local_rank) -> None:
+    """BASELINE.json configs[2]: N synthetic 3-minute tracks (180 s @ 22.05 kHz = 3,969,000 samples -> 110 windows,
+    15,584 output frames each; lengths jittered by up to 2 % so the shard plan has something to balance), sharded by
+    file over the ranks with the LPT plan of basic_pitch_amd/sharding.py, each through bp_infer_track with device
+    input and output: windowing with the 3840-sample lead-in, CQT + CNN, un-overlapping.  One "step" = one pass over
+    the rank's shard; no collective on the data path."""
+    from basic_pitch_amd.inference import Model
+    from basic_pitch_amd.sharding import plan_shards, shard_imbalance
+
+    dev = torch.device("cuda", local_rank)
+    rng = np.random.default_rng(2024)
+    base = 180 * 22050
+    lengths = [int(base * (1.0 - 0.02 * rng.random())) for _ in range(args.tracks)]
+    shards = plan_shards(lengths, world)
+    mine = shards[rank]
+    model = Model(device=local_rank, max_windows=256)
+    lib = model._lib
+    g = torch.Generator(device=dev)
+    g.manual_seed(99 + rank)
+    pool = [(torch.rand((base,), generator=g, device=dev) * 2.0 - 1.0).contiguous() for _ in range(4)]
+    n_windows = sum(int(lib.bp_track_n_windows(lengths[i])) for i in mine)
+
+    group = 64  # tracks per bp_infer_tracks call (windows are packed across track boundaries into full batches)
+
+    def step():
+        for g0 in range(0, len(mine), group):
+            ids = mine[g0 : g0 + group]
+            model.predict_tracks([pool[j % len(pool)][: lengths[i]] for j, i in enumerate(ids)])
+
+    for _ in range(args.warmup if args.warmup < 2 else 1):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    total = torch.tensor([float(n_windows)], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        elapsed = float(tmax.item())
+        line = {
+            "metric": "audio windows/sec (2 s @ 22.05 kHz) end-to-end CQT+CNN",
+            "value": float(total.item()) * args.steps / elapsed,
+            "unit": "windows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.tracks} synthetic 3-minute tracks (110 windows each) through bp_infer_track, "
+                "device-resident in/out, file-sharded (BASELINE.json configs[2])",
+                "tracks_per_s": args.tracks * args.steps / elapsed,
+                "shard_imbalance": shard_imbalance(lengths, shards),
+                "sharding": "LPT by sample count, no collective",
+            },
+        }
+        print(json.dumps(line), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +196,10 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact-f32", action="store_true", help="contour conv1 on the exact-f32 MFMA kernel (A/B)")
+    ap.add_argument("--workload", choices=["windows", "tracks"], default="windows",
+                    help="windows: BASELINE.json configs[1] (the headline line); tracks: configs[2], whole synthetic "
+                    "3-minute tracks through bp_infer_track, file-sharded over the ranks")
+    ap.add_argument("--tracks", type=int, default=1000, help="tracks in the whole job (--workload tracks)")
     ap.add_argument("--bf16-weights", action="store_true",
                     help="BASELINE.json configs[3]: bf16 CNN weights + fp32 CQT (use with --batch 1024); not the headline line")
     args = ap.parse_args()
@@ -143,6 +220,12 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from basic_pitch_amd.inference import Model
+
+    if args.workload == "tracks":
+        run_tracks(args, torch, dist, world, rank, local_rank)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     B = args.batch
     dev = torch.device("cuda", local_rank)

@@ -118,6 +118,15 @@ int bp_infer_track(bp_handle h, const float* samples, int64_t n_samples, float* 
                    float* contour, int mem_kind);
 
 /*
+ * Many tracks in one call: the per-file loop of predict_and_save (inference.py:548-604) with the windows of
+ * consecutive tracks packed into full batches (a 3-minute track is only 110 windows; one track per launch leaves a
+ * third of the GPU idle).  samples[i] = mono 22.05 kHz float32 [n_samples[i]]; note[i] / onset[i] / contour[i] as
+ * bp_infer_track for track i.  Results are bit-identical to n_tracks separate bp_infer_track calls.
+ */
+int bp_infer_tracks(bp_handle h, int64_t n_tracks, const float* const* samples, const int64_t* n_samples,
+                    float* const* note, float* const* onset, float* const* contour, int mem_kind);
+
+/*
  * Replaces: the decode-side tail of librosa.load(path, sr=22050, mono=True) (inference.py:239) for PCM that is
  * already decoded: channel-mean downmix (librosa.to_mono) + rational polyphase resampling to 22.05 kHz, on the
  * device.  `pcm` = interleaved float32 [n_frames][channels] at `sample_rate` Hz (host or device per mem_kind).

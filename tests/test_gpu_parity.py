@@ -324,6 +324,29 @@ def test_track_path_equals_windowed_path_and_golden(weights, clip_22k):
     m.close()
 
 
+def test_multi_track_packing_is_bit_identical():
+    """bp_infer_tracks packs the windows of consecutive tracks into full batches; every track must come out exactly
+    as from its own bp_infer_track call (ragged lengths, an empty track, tracks spanning several chunks)."""
+    from basic_pitch_amd import Model
+
+    m = Model(max_windows=16)
+    rng = np.random.default_rng(5)
+    lens = [50000, 0, 36164 * 3 + 17, 1, 36164 * 20, 7000, 36164 * 16 - 3840]
+    tracks = [rng.uniform(-0.5, 0.5, n).astype(np.float32) for n in lens]
+    packed = m.predict_tracks(tracks)
+    for t, got in zip(tracks, packed):
+        ref = m.predict_track(t)
+        for k in ref:
+            assert got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k]), (len(t), k)
+    dev = m.predict_tracks([torch.from_numpy(t).cuda() for t in tracks if len(t)])
+    for t, got in zip([t for t in tracks if len(t)], dev):
+        ref = m.predict_track(t)
+        for k in ref:
+            assert np.array_equal(got[k].cpu().numpy(), ref[k]), k
+    assert m.predict_tracks([]) == []
+    m.close()
+
+
 def test_device_audio_ingest(weights):
     """downmix + resampling on the device.  bp_resample must reproduce the host ingest
     (basic_pitch_amd/audio.py = scipy.signal.resample_poly in float64, rounded to float32) for the rate pairs that
@@ -379,3 +402,28 @@ def test_predict_note_events_match_reference_golden(tmp_path):
     saved = np.load(stem.with_suffix(".npz"), allow_pickle=True)["basic_pitch_model_output"].item()
     assert saved["note"].shape == (787, 88)
     assert len(stem.with_suffix(".csv").read_text().strip().splitlines()) == 29
+
+
+def test_ort_shim_session_runs_reference_call_pattern(cases):
+    """The reference's ONNX leg, verbatim call pattern (inference.py:134-136, 173-180), against the shim: the session
+    only accepts the reference's nmp.onnx (by SHA-256), so here the model bytes are faked by patching the expected
+    digest; outputs come back in the requested order with the reference's shapes."""
+    import hashlib
+
+    import basic_pitch_amd.ort_shim as ort
+
+    x, r32, r64 = cases
+    fake = b"stand-in for saved_models/icassp_2022/nmp.onnx (absent on the GPU box)"
+    old = ort.NMP_ONNX_SHA256
+    ort.NMP_ONNX_SHA256 = hashlib.sha256(fake).hexdigest()
+    try:
+        sess = ort.InferenceSession(fake, providers=ort.get_available_providers())
+    finally:
+        ort.NMP_ONNX_SHA256 = old
+    res = sess.run(
+        ["StatefulPartitionedCall:1", "StatefulPartitionedCall:2", "StatefulPartitionedCall:0"],
+        {"serving_default_input_2:0": x[:, :, None]},
+    )
+    assert [r.shape for r in res] == [(4, 172, 88), (4, 172, 88), (4, 172, 264)]
+    for got, k in zip(res, ("note", "onset", "contour")):
+        assert np.abs(got[:3] - r64[k][:3]).max() <= 1e-4, k

@@ -190,3 +190,21 @@ def test_shard_planning():
     assert split_windows(110, 8) == [(0, 14), (14, 28), (28, 42), (42, 56), (56, 70), (70, 84), (84, 97), (97, 110)]
     with pytest.raises(ValueError):
         plan_shards([1], 0)
+
+
+def test_ort_shim_contract_cpu(tmp_path):
+    """basic_pitch_amd.ort_shim presents the three onnxruntime entry points the reference uses (inference.py:134-136,
+    173-180); without a GPU the session must fail loudly (no CPU fallback), and a foreign model file is a ValueError."""
+    import basic_pitch_amd.ort_shim as shim
+    from basic_pitch_amd._native import NativeLibraryError
+
+    assert shim.get_available_providers() == ["MI355XExecutionProvider"]
+    bad = tmp_path / "other.onnx"
+    bad.write_bytes(b"not the reference model")
+    with pytest.raises(ValueError):
+        shim.InferenceSession(str(bad), providers=shim.get_available_providers())
+    assert shim.OUTPUT_KEYS == {"StatefulPartitionedCall:1": "note", "StatefulPartitionedCall:2": "onset",
+                                "StatefulPartitionedCall:0": "contour"}
+    import sys
+
+    assert "onnxruntime" not in sys.modules or sys.modules["onnxruntime"] is not shim  # never installed implicitly
