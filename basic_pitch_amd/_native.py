@@ -17,7 +17,7 @@ BP_MEM_DEVICE = 1
 BP_FLAG_STAGE_TIMING = 1
 BP_FLAG_F32_MFMA = 2
 BP_FLAG_BF16_WEIGHTS = 4
-BP_N_STAGES = 14
+BP_N_STAGES = 15
 BP_Z_ROW = 448
 BP_Z_ROWS = 174
 BP_Z_PAD = 56
@@ -25,7 +25,7 @@ BP_PYR_STRIDE = 43712
 
 STAGE_NAMES = [
     "pyramid", "filterbank", "contour1", "contour2", "note1", "note2", "onset1", "onset2",
-    "zpack", "note", "onset", "contour", "contour_conv1", "contour_conv2",
+    "zpack", "note", "onset", "contour", "contour_conv1", "contour_conv2", "contour_conv1_edge",
 ]
 
 _ERR_NAMES = {

@@ -49,8 +49,11 @@ ResamplePlan make_resample_plan(int source_rate, int target_rate, std::vector<do
 void launch_downmix(const float* pcm, int64_t n_frames, int channels, float* mono, hipStream_t stream);
 void launch_resample(const float* x, int64_t n_in, const double* taps, const ResamplePlan& pl, float* y,
                      int64_t n_out, hipStream_t stream);
-void launch_contour_conv1(const uint32_t* zp, const void* wlds, const float* bias, float* c1, int n_windows,
-                          int n_cu, bool weights_have_lo, hipStream_t stream);
+void launch_contour_conv1_exact(const uint32_t* zp, const void* wlds, const float* bias, float* c1, int n_windows,
+                                int n_cu, bool weights_have_lo, hipStream_t stream);
+void launch_contour_conv1_folded(const uint32_t* zp, const void* wfold, const float* bias, float* c1, int n_windows,
+                                 int n_cu, bool weights_have_lo, hipStream_t stream);
+bool contour_conv1_full();
 void launch_contour_conv2(const float* c1, const float* w2, float bias, float* contour, int n_windows, int n_cu,
                           hipStream_t stream);
 void launch_note_branch(const float* contour, const void* wfrag, const float* wf32, float* note,
@@ -158,7 +161,7 @@ struct bp_context {
   float *d_note_wfrag = nullptr, *d_note_wf32 = nullptr, *d_onset_wfrag = nullptr, *d_onset_wf32 = nullptr;
   float* zp = nullptr;  // uint32 [cap][kZRowsP][kZRow] pre-split z, zero padded (bp_common.h)
   // contour branch, two-kernel form (conv_contour_direct.hip): LDS weight image, bias[8], conv2 taps [5][5][8]
-  float *d_d1_wlds = nullptr, *d_d1_bias = nullptr, *d_d2_w = nullptr;
+  float *d_d1_wlds = nullptr, *d_d1_wfold = nullptr, *d_d1_bias = nullptr, *d_d2_w = nullptr;
   float* c1s = nullptr;  // [cap][172][kC1Row][8] relu(conv1); pad bins zeroed once at allocation
   bool fused_contour = false;  // BP_CONTOUR_PATH=fused: the single-kernel contour branch (A/B comparisons)
   float *d_dec_hfrag = nullptr, *d_fbh_bfrag = nullptr;  // cqt_mfma.hip f16 hi/lo fragments (raw bytes)
@@ -374,6 +377,32 @@ void pack_contour_direct(const Tensor* w1, std::vector<uint16_t>& out) {
         }
 }
 
+// Folded contour conv1 (conv_contour_direct.hip, interior groups): the 8 stack channels are shifted copies of one
+// image, so K[o][dt][g] = sum_c W1[o][c][dt][g - s_c + 19], g in [-55, 120].  A fragments [3 dt][12 k-steps][hi|lo]
+// [64 lanes] x (8 x f16): lane (row i = 8 j + o, half kh), element el -> tap' = 16 e + 8 kh + el, g = tap' - j - 56.
+void pack_contour_folded(const Tensor* w1, std::vector<uint16_t>& out) {
+  static const int shifts[8] = {-36, 0, 36, 57, 72, 84, 93, 101};  // nn.py:51-54 (bp_common.h harm_shift)
+  std::vector<double> keff((size_t)8 * 3 * 176, 0.0);               // [o][dt][g + 55]
+  for (int o = 0; o < 8; ++o)
+    for (int c = 0; c < 8; ++c)
+      for (int dt = 0; dt < 3; ++dt)
+        for (int df = 0; df < 39; ++df)
+          keff[((size_t)o * 3 + dt) * 176 + (df - 19 + shifts[c] + 55)] += (double)w1->data[((o * 8 + c) * 3 + dt) * 39 + df];
+  out.assign((size_t)36 * 2 * 64 * 8, 0);
+  for (int dt = 0; dt < 3; ++dt)
+    for (int e = 0; e < 12; ++e)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int kh = lane >> 5, i = lane & 31, j = i >> 3, o = i & 7;
+        const size_t base_hi = (((size_t)(dt * 12 + e) * 2 + 0) * 64 + lane) * 8;
+        const size_t base_lo = (((size_t)(dt * 12 + e) * 2 + 1) * 64 + lane) * 8;
+        for (int el = 0; el < 8; ++el) {
+          const int g = 16 * e + 8 * kh + el - j - 56;
+          const float v = (g >= -55 && g <= 120) ? (float)keff[((size_t)o * 3 + dt) * 176 + g + 55] : 0.0f;
+          put_split(out, base_hi, base_lo, el, v, 2048.0f);
+        }
+      }
+}
+
 // contour conv1 Toeplitz B fragments [4 waves][126][64] (conv_contour1.hip).
 void pack_contour1(const Tensor* w, std::vector<float>& out) {
   static const int chan[4][2] = {{0, 1}, {2, 4}, {5, 3}, {6, 7}};
@@ -497,7 +526,7 @@ void pack_filterbank_f16(const Tensor* re, const Tensor* im, std::vector<uint16_
 }
 
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_bias, h->d_d2_w, h->d_cb_wfrag, h->d_cb_wf32, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_bias, h->d_d2_w, h->d_cb_wfrag, h->d_cb_wf32, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->fb_scratch, h->pcm_dev, h->mono_dev, h->res_dev, reinterpret_cast<float*>(h->taps_dev)};
@@ -572,8 +601,13 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
                             h->n_cu, s);
       BP_MARK(BP_STAGE_CONTOUR);
     } else {
-      launch_contour_conv1(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wlds, h->d_d1_bias, h->c1s, n,
-                           h->n_cu, wlo, s);
+      launch_contour_conv1_exact(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wlds, h->d_d1_bias, h->c1s, n,
+                                 h->n_cu, wlo, s);
+      if (!contour_conv1_full()) {
+        BP_MARK(BP_STAGE_CONTOUR_CONV1_EDGE);
+        launch_contour_conv1_folded(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wfold, h->d_d1_bias, h->c1s, n,
+                                    h->n_cu, wlo, s);
+      }
       BP_MARK(BP_STAGE_CONTOUR_CONV1);
       launch_contour_conv2(h->c1s, h->d_d2_w, h->b_contour2, contour_dev, n, h->n_cu, s);
       BP_MARK(BP_STAGE_CONTOUR_CONV2);
@@ -733,6 +767,8 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wlds)) || (rc = upload(h, vec(c1b), &h->d_d1_bias)) ||
         (rc = upload(h, w2t, &h->d_d2_w)))
       return fail(rc);
+    pack_contour_folded(c1w, frag);
+    if ((rc = upload(h, raw_of(frag), &h->d_d1_wfold))) return fail(rc);
     {
       const char* e = std::getenv("BP_CONTOUR_PATH");
       h->fused_contour = e && std::strcmp(e, "fused") == 0;
@@ -1259,7 +1295,8 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
           h->err = "bp_run_stage: contour needs n_windows <= max_windows (internal c1 buffer)";
           return BP_ERR_INVALID_ARG;
         } else {
-          launch_contour_conv1(bf->zp, h->d_d1_wlds, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
+          launch_contour_conv1_exact(bf->zp, h->d_d1_wlds, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
+          launch_contour_conv1_folded(bf->zp, h->d_d1_wfold, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
           launch_contour_conv2(h->c1s, h->d_d2_w, h->b_contour2, bf->contour, n, h->n_cu, s);
         }
       }

@@ -45,10 +45,14 @@ F16_MFMA_PEAK_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense f16/bf16 m
 # MFMAs (hi*hi, lo*hi, hi*lo) of 32x32x16 for conv1 plus 4 waves x 2 for the conv2 tap projection; 186 tiles per
 # chunk, 2 chunks
 CB_EXECUTED_FLOP_PER_WINDOW = 2 * 186 * (63 * 3 + 4 * 2) * (2 * 32 * 32 * 16)
-# contour_conv1_kernel (conv_contour_direct.hip): a window is 172 x 66 positions = 45 rounds of 256; per round each of
-# the 4 waves issues 63 k-steps x 6 MFMAs (2 tiles x {hi*hi, lo*hi, hi*lo})
-D1_EXECUTED_FLOP_PER_WINDOW = 45 * 4 * 63 * 6 * (2 * 32 * 32 * 16)
-D1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 268 * 8 * 4  # zp read + c1 written
+# contour_conv1_folded_kernel (conv_contour_direct.hip) computes the 56 interior groups of every frame (bins 20..243,
+# 56/66 of conv1's products): 172 x 56 positions = 38 rounds of 256; per round each of the 8 waves issues 36 k-steps x 3
+# MFMAs (hi*hi, lo*hi, hi*lo).  BP_CONV1=full: the exact kernel over all 66 groups, 45 rounds x 8 waves x 63 x 3.
+F1_SHARE = 56.0 / 66.0
+F1_EXECUTED_FLOP_PER_WINDOW = 38 * 8 * 36 * 3 * (2 * 32 * 32 * 16)
+F1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 224 * 8 * 4  # zp read + interior c1 written
+D1_EXECUTED_FLOP_PER_WINDOW = 45 * 8 * 63 * 3 * (2 * 32 * 32 * 16)
+D1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 264 * 8 * 4  # zp read + c1 written
 HBM_PEAK_GBS = 8000.0
 
 
@@ -281,13 +285,24 @@ def main() -> None:
             c1_key = None
         elif stage.get("contour_conv1", 0.0) > 0.0:
             c1_ms = stage["contour_conv1"]
-            c1_flop = C1_FLOP_PER_WINDOW
-            c1_kernel = ("contour_conv1_kernel (harmonic stack + Conv2D 8->8 3x39 + ReLU; f16 MFMA 32x32x16 on hi/lo-split "
-                         "operands from LDS, fp32 accumulate, no K split)")
+            folded = stage.get("contour_conv1_edge", 0.0) > 0.0
+            mf = (2 / 3 if args.bf16_weights else 1)
+            if folded:
+                c1_flop = C1_FLOP_PER_WINDOW * F1_SHARE
+                c1_kernel = ("contour_conv1_folded_kernel (interior 56/66 of harmonic stack + Conv2D 8->8 3x39 + ReLU with the 8 "
+                             "shifted channels folded into one 176-tap kernel; f16 MFMA 32x32x16 on hi/lo-split operands from "
+                             "LDS, fp32 accumulate; algorithmic FLOPs = the reference's 8-channel products it replaces)")
+                c1_exec = F1_EXECUTED_FLOP_PER_WINDOW * mf * B / (c1_ms * 1e-3) / 1e12
+                c1_bytes = F1_BYTES_PER_WINDOW * B
+                c1_key = "contour_conv1_folded_kernel"
+            else:
+                c1_flop = C1_FLOP_PER_WINDOW
+                c1_kernel = ("contour_conv1_kernel<FullGeo> (harmonic stack + Conv2D 8->8 3x39 + ReLU; f16 MFMA 32x32x16 on "
+                             "hi/lo-split operands from LDS, fp32 accumulate, no K split)")
+                c1_exec = D1_EXECUTED_FLOP_PER_WINDOW * mf * B / (c1_ms * 1e-3) / 1e12
+                c1_bytes = D1_BYTES_PER_WINDOW * B
+                c1_key = "contour_conv1_kernel"
             c1_peak = F16_MFMA_PEAK_TFLOPS
-            c1_exec = D1_EXECUTED_FLOP_PER_WINDOW * (2 / 3 if args.bf16_weights else 1) * B / (c1_ms * 1e-3) / 1e12
-            c1_bytes = D1_BYTES_PER_WINDOW * B
-            c1_key = "contour_conv1_kernel"
         else:
             c1_ms = stage["contour"]
             c1_flop = C1_FLOP_PER_WINDOW + C2_FLOP_PER_WINDOW

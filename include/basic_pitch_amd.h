@@ -178,9 +178,11 @@ enum {
   BP_STAGE_CONTOUR = 11,  /* contour branch (bp_run_stage: both kernels; timing: the fused A/B kernel) */
   BP_STAGE_CONTOUR_CONV1 = 12, /* contour conv 3x39 + ReLU on the matrix cores   zp -> c1 (internal)   */
   BP_STAGE_CONTOUR_CONV2 = 13, /* contour conv 5x5 + sigmoid                      c1 -> contour         */
-  BP_N_STAGES = 14
+  BP_STAGE_CONTOUR_CONV1_EDGE = 14, /* the rim groups of CONTOUR_CONV1 on the exact 8-channel kernel (CONTOUR_CONV1 is
+                                     * then the folded kernel over the interior groups)                              */
+  BP_N_STAGES = 15
 };
-/* Default (split-precision) path runs: PYRAMID, FILTERBANK, ZPACK, CONTOUR_CONV1, CONTOUR_CONV2, NOTE, ONSET.
+/* Default (split-precision) path runs: PYRAMID, FILTERBANK, ZPACK, CONTOUR_CONV1_EDGE, CONTOUR_CONV1, CONTOUR_CONV2, NOTE, ONSET.
  * BP_FLAG_F32_MFMA runs:               PYRAMID, FILTERBANK, CONTOUR1, CONTOUR2, NOTE1, NOTE2, ONSET1, ONSET2. */
 
 /* With BP_FLAG_STAGE_TIMING: mean milliseconds per stage over the chunks (<= 128 most recent) run
