@@ -32,6 +32,9 @@
 // Roofline: bound = f16 MFMA issue.  Algorithmic work per window: note 47.5 + 20.3 MFLOP, onset
 // 193.7 + 9.0 MFLOP.  HBM bytes per window: note 181,632 read + 60,544
 // written; onset 214,656 (zp) + 60,544 (note) read + 60,544 written.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "bp_common.h"
 
 namespace bp {
@@ -54,6 +57,7 @@ struct BranchParams {
   const float* note;   // onset only: note posteriorgram [n][172][88]
   float* out;          // [n][172][88]
   int n_windows;
+  unsigned long long* prof;  // tools only: per-phase reference-clock totals of block 0 (null in production)
 };
 
 // ---- branch descriptions ----------------------------------------------------------------------
@@ -67,6 +71,7 @@ struct NoteBr {
   static constexpr int SLOTS = kFreqN;      // slot (row, w) = contour bins 3w-2 .. 3w+5
   static constexpr int RING = kBrRows + 2 * PH1;
   static constexpr int QRING = kBrRows + 2 * PH2;
+  static constexpr int PIECE = 4;           // rows per staging call (2 tasks of 8 loads per thread)
   static __device__ constexpr int d_of(int s, int h) { return 2 * s + h; }
   static __device__ constexpr int x_of(int, int) { return 0; }
   static __device__ __forceinline__ int lane_slot(int wc) { return wc; }
@@ -82,6 +87,7 @@ struct OnsetBr {
   static constexpr int SLOTS = kFreqC + 2;  // slot (row, s) = stack bin s-1, 8 channels; bins -1 and 264 zero
   static constexpr int RING = kBrRows + 2 * PH1;
   static constexpr int QRING = kBrRows + 2 * PH2;
+  static constexpr int PIECE = 2;           // rows per staging call (3 tasks of 8 loads per thread)
   static __device__ constexpr int d_of(int s, int h) { return (2 * s + h) / 5; }
   static __device__ constexpr int x_of(int s, int h) { return (2 * s + h) % 5; }
   static __device__ __forceinline__ int lane_slot(int wc) { return 3 * wc; }  // bin 3w+dw-1 -> slot 3w+dw
@@ -92,64 +98,137 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
   lo = (_Float16)((v - (float)hi) * kLoScale);
 }
 
-// ---- image staging: `nrows` rows starting at `row_first` (absolute frame index, may be outside the window)
-template <class Br>
-__device__ __forceinline__ void stage_rows(const BranchParams& p, int b, int row_first, int nrows,
-                                           uint4* __restrict__ img_hi, uint4* __restrict__ img_lo, int wave,
-                                           int lane) {
-  for (int rr = wave; rr < nrows; rr += kBrThreads / 64) {
-    const int row = row_first + rr;
-    const bool rvalid = row >= 0 && row < kFrames;
-    const int ring = ((row + 64 * Br::RING) % Br::RING) * Br::SLOTS;
-    if constexpr (!Br::kOnset) {
+// ---- image staging: `nrows` rows starting at `row_first` (absolute frame index, may be outside the window).
+// Tasks (row, slot) are dealt round-robin to the 256 threads; a thread first ISSUES the loads of all its tasks
+// (NT x 8 in flight), then splits / packs and writes them: the global-load latency is paid once per call, not once
+// per task.  Slots that are zero for every row (onset: the two padding bins of "same") are written by init_rows.
+// note branch: the staging of NROWS contour rows as two halves (issue all loads, then split and write).  Issuing a
+// whole phase ahead was tried: the compiler's vmcnt bookkeeping across the tile loop waits for the loads at the top of
+// the loop anyway (register reuse), so the two halves run back to back
+template <int NROWS>
+struct NoteStage {
+  static constexpr int NT = (NROWS * kFreqN + kBrThreads - 1) / kBrThreads;
+  float v[NT][8];
+  int dst[NT];
+  unsigned ok[NT];  // bit i: value i is inside the window (applied at commit: a select right after the load would
+                    // make the issue side wait for the data)
+};
+
+template <class Br, int NROWS>
+__device__ __forceinline__ void note_stage_issue(const BranchParams& p, int b, int row_first, int tid,
+                                                 NoteStage<NROWS>& st) {
+  constexpr int NT = NoteStage<NROWS>::NT;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const int e = tid + k * kBrThreads;
+    st.dst[k] = -1;
+    if (e < NROWS * kFreqN) {
+      const int rr = e / kFreqN, w = e - rr * kFreqN;
+      const int row = row_first + rr;
+      const bool rvalid = row >= 0 && row < kFrames;
       const float* src = static_cast<const float*>(p.src) + ((int64_t)b * kFrames + (rvalid ? row : 0)) * kFreqC;
-      for (int w = lane; w < Br::SLOTS; w += 64) {
-        f16x8 vh, vl;
+      st.dst[k] = ((row + 64 * Br::RING) % Br::RING) * Br::SLOTS + w;
+      unsigned okm = 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int bin = 3 * w + e - 2;
-          const bool ok = rvalid && bin >= 0 && bin < kFreqC;
-          const float v = ok ? src[ok ? bin : 0] : 0.0f;
-          _Float16 hi, lo;
-          split_f16(v, hi, lo);
-          vh[e] = hi;
-          vl[e] = lo;
-        }
-        img_hi[ring + w] = __builtin_bit_cast(uint4, vh);
-        img_lo[ring + w] = __builtin_bit_cast(uint4, vl);
+      for (int i = 0; i < 8; ++i) {
+        const int bin = 3 * w + i - 2;
+        const bool ok = rvalid && bin >= 0 && bin < kFreqC;
+        okm |= ok ? (1u << i) : 0u;
+        st.v[k][i] = src[ok ? bin : 0];
       }
-    } else {
-      const uint32_t* src = static_cast<const uint32_t*>(p.src) + (int64_t)b * kZWin +
-                            (int64_t)((rvalid ? row : 0) + 1) * kZRow + kZPadL;
-      for (int sl = lane; sl < Br::SLOTS; sl += 64) {
-        const int f = sl - 1;
-        const bool inside = rvalid && f >= 0 && f < kFreqC;  // crop to 264 bins before "same" padding (nn.py:87)
-        uint32_t u[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const int g = f + harm_shift(c);
-          const bool ok = inside && g >= 0 && g < kBins;
-          u[c] = ok ? src[ok ? g : 0] : 0u;
-        }
-        uint4 vh, vl;
-        vh.x = (u[0] & 0xffffu) | (u[1] << 16);
-        vh.y = (u[2] & 0xffffu) | (u[3] << 16);
-        vh.z = (u[4] & 0xffffu) | (u[5] << 16);
-        vh.w = (u[6] & 0xffffu) | (u[7] << 16);
-        vl.x = (u[0] >> 16) | (u[1] & 0xffff0000u);
-        vl.y = (u[2] >> 16) | (u[3] & 0xffff0000u);
-        vl.z = (u[4] >> 16) | (u[5] & 0xffff0000u);
-        vl.w = (u[6] >> 16) | (u[7] & 0xffff0000u);
-        img_hi[ring + sl] = vh;
-        img_lo[ring + sl] = vl;
-      }
+      st.ok[k] = okm;
     }
   }
 }
 
+template <int NROWS>
+__device__ __forceinline__ void note_stage_commit(const NoteStage<NROWS>& st, uint4* __restrict__ img_hi,
+                                                  uint4* __restrict__ img_lo) {
+#pragma unroll
+  for (int k = 0; k < NoteStage<NROWS>::NT; ++k) {
+    if (st.dst[k] < 0) continue;
+    f16x8 vh, vl;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      _Float16 hi, lo;
+      split_f16(((st.ok[k] >> i) & 1u) ? st.v[k][i] : 0.0f, hi, lo);
+      vh[i] = hi;
+      vl[i] = lo;
+    }
+    img_hi[st.dst[k]] = __builtin_bit_cast(uint4, vh);
+    img_lo[st.dst[k]] = __builtin_bit_cast(uint4, vl);
+  }
+}
+
+template <class Br, int NROWS>
+__device__ __forceinline__ void stage_rows(const BranchParams& p, int b, int row_first,
+                                           uint4* __restrict__ img_hi, uint4* __restrict__ img_lo, int tid) {
+  constexpr int PER_ROW = Br::kOnset ? kFreqC : Br::SLOTS;       // tasks per row
+  constexpr int NT = (NROWS * PER_ROW + kBrThreads - 1) / kBrThreads;
+  constexpr int ntask = NROWS * PER_ROW;
+  if constexpr (!Br::kOnset) {
+    NoteStage<NROWS> st;
+    note_stage_issue<Br, NROWS>(p, b, row_first, tid, st);
+    note_stage_commit<NROWS>(st, img_hi, img_lo);
+  } else {
+    // stack bin f -> slot f + 1; zp is zero outside the CQT and in its pad frames -1 / 172 (bp_common.h): only rows
+    // further outside the window need a guard
+    uint32_t u[NT][8];
+    int dst[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      const int e = tid + k * kBrThreads;
+      dst[k] = -1;
+      if (e < ntask) {
+        const int rr = e / PER_ROW, f = e - rr * PER_ROW;
+        const int row = row_first + rr;
+        const bool rvalid = row >= -1 && row <= kFrames;
+        const uint32_t* src = static_cast<const uint32_t*>(p.src) + (int64_t)b * kZWin +
+                              (int64_t)((rvalid ? row : -1) + 1) * kZRow + kZPadL + f;
+        dst[k] = ((row + 64 * Br::RING) % Br::RING) * Br::SLOTS + f + 1;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) u[k][c] = src[harm_shift(c)];  // row -1 is all zero: also serves rows < -1
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      if (dst[k] < 0) continue;
+      uint4 vh, vl;
+      vh.x = (u[k][0] & 0xffffu) | (u[k][1] << 16);
+      vh.y = (u[k][2] & 0xffffu) | (u[k][3] << 16);
+      vh.z = (u[k][4] & 0xffffu) | (u[k][5] << 16);
+      vh.w = (u[k][6] & 0xffffu) | (u[k][7] << 16);
+      vl.x = (u[k][0] >> 16) | (u[k][1] & 0xffff0000u);
+      vl.y = (u[k][2] >> 16) | (u[k][3] & 0xffff0000u);
+      vl.z = (u[k][4] >> 16) | (u[k][5] & 0xffff0000u);
+      vl.w = (u[k][6] >> 16) | (u[k][7] & 0xffff0000u);
+      img_hi[dst[k]] = vh;
+      img_lo[dst[k]] = vl;
+    }
+  }
+}
+
+// `NROWS` rows in pieces of Br::PIECE rows: bounds the registers a staging call holds in flight
+template <class Br, int NROWS>
+__device__ __forceinline__ void stage_block(const BranchParams& p, int b, int row_first, uint4* __restrict__ img_hi,
+                                            uint4* __restrict__ img_lo, int tid) {
+  constexpr int P = Br::PIECE;
+#pragma unroll
+  for (int r = 0; r + P <= NROWS; r += P) stage_rows<Br, P>(p, b, row_first + r, img_hi, img_lo, tid);
+  if constexpr (NROWS % P != 0) stage_rows<Br, NROWS % P>(p, b, row_first + NROWS - NROWS % P, img_hi, img_lo, tid);
+}
+
 // WLO = false: conv1 weights without a lo part (BP_FLAG_BF16_WEIGHTS): 2 MFMAs per k-step
-template <class Br, bool WLO>
+template <class Br, bool WLO, bool PROF = false>
 __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
+  unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = PROF ? __builtin_readcyclecounter() : 0;
+#define BR_STAMP(k)                                                \
+  if (PROF) {                                                      \
+    const unsigned long long t_now = __builtin_readcyclecounter(); \
+    acc_t[k] += t_now - t_prev;                                    \
+    t_prev = t_now;                                                \
+  }
   constexpr int KS1 = Br::KS1, KH2 = Br::KH2, PH1 = Br::PH1, PH2 = Br::PH2, NT2 = Br::NT2;
   __shared__ __attribute__((aligned(16))) uint4 img_hi[Br::RING * Br::SLOTS];
   __shared__ __attribute__((aligned(16))) uint4 img_lo[Br::RING * Br::SLOTS];
@@ -181,6 +260,12 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
   for (int i = 0; i < 9; ++i) extra[i] = p.wf32[32 + i];
   const float bias2 = p.wf32[41];
 
+  // slots no staging call writes (onset: the two zero bins either side of a row) are zero from here on
+  for (int i = threadIdx.x; i < Br::RING * Br::SLOTS; i += kBrThreads) {
+    img_hi[i] = uint4{0u, 0u, 0u, 0u};
+    img_lo[i] = uint4{0u, 0u, 0u, 0u};
+  }
+
   const int n_items = p.n_windows * kBrChunks;
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int b = item / kBrChunks;
@@ -189,11 +274,12 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
     const int n_phase = (T1 - T0 + 2 * PH2 + kBrRows - 1) / kBrRows;
 
     __syncthreads();  // previous item finished with the rings
-    stage_rows<Br>(p, b, T0 - PH2 - PH1, Br::RING, img_hi, img_lo, wave, lane);
+    stage_block<Br, Br::RING>(p, b, T0 - PH2 - PH1, img_hi, img_lo, threadIdx.x);
     __syncthreads();
 
     for (int ph = 0; ph < n_phase; ++ph) {
       const int r0 = T0 - PH2 + kBrRows * ph;  // first conv1 row of this phase
+      BR_STAMP(0);
 
       // ---- conv1 + projection, 12 tiles: 4 rows x 3 overlapping 32-pixel tiles (30 inner pixels each)
 #pragma unroll 1
@@ -212,6 +298,23 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
 #pragma unroll
           for (int d = 0; d < Br::ND; ++d) rb[d] = ((row - PH1 + d + 64 * Br::RING) % Br::RING) * Br::SLOTS;
           const int lane_off = Br::lane_slot(wc);
+          // onset: the three note values each Q output needs (concat channel 0, models.py:305), fetched now so that
+          // their latency hides behind the MFMAs
+          constexpr int kQIter = (30 * KH2 + 63) / 64;
+          float nv[kQIter][3];
+          if constexpr (Br::kOnset) {
+            const float* note_row = p.note + ((int64_t)b * kFrames + row) * kFreqN;
+#pragma unroll
+            for (int it = 0; it < kQIter; ++it) {
+              const int idx = lane + 64 * it;
+              const int dtq = idx / 30;
+              const int wq = wbase + 1 + idx - 30 * dtq;
+              const bool ok = idx < 30 * KH2 && wq < kFreqN;
+              nv[it][0] = (ok && wq > 0) ? note_row[wq - 1] : 0.0f;
+              nv[it][1] = ok ? note_row[wq] : 0.0f;
+              nv[it][2] = (ok && wq + 1 < kFreqN) ? note_row[wq + 1] : 0.0f;
+            }
+          }
 
           f32x16 acc, accc;
 #pragma unroll
@@ -283,22 +386,23 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
             }
           }
           __builtin_amdgcn_wave_barrier();
-          // Q[row][dt][w] = sum_dw P[w+dw-1][(dt,dw)]  (+ the note channel of the concat for the onset head)
-          const float* note_row = Br::kOnset ? p.note + ((int64_t)b * kFrames + row) * kFreqN : nullptr;
-          for (int idx = lane; idx < 30 * KH2; idx += 64) {
-            const int dt = idx / 30;
-            const int l2 = 1 + idx - 30 * dt;
-            const int wq = wbase + l2;
-            const float* sp = scr + (dt * 3) * kScrStride + l2;
-            float q = (sp[-1] + sp[kScrStride]) + sp[2 * kScrStride + 1];
-            if (wq < kFreqN) {
-              if constexpr (Br::kOnset) {
-                const float nl = wq > 0 ? note_row[wq - 1] : 0.0f;
-                const float nc = note_row[wq];
-                const float nr = wq + 1 < kFreqN ? note_row[wq + 1] : 0.0f;
-                q += (nl * extra[dt * 3] + nc * extra[dt * 3 + 1]) + nr * extra[dt * 3 + 2];
+          // Q[row][dt][w] = sum_dw P[w+dw-1][(dt,dw)]  (+ the note channel of the concat for the onset head, whose
+          // values were fetched before the MFMAs)
+#pragma unroll
+          for (int it = 0; it < kQIter; ++it) {
+            const int idx = lane + 64 * it;
+            if (idx < 30 * KH2) {
+              const int dt = idx / 30;
+              const int l2 = 1 + idx - 30 * dt;
+              const int wq = wbase + l2;
+              const float* sp = scr + (dt * 3) * kScrStride + l2;
+              float q = (sp[-1] + sp[kScrStride]) + sp[2 * kScrStride + 1];
+              if (wq < kFreqN) {
+                if constexpr (Br::kOnset) {
+                  q += (nv[it][0] * extra[dt * 3] + nv[it][1] * extra[dt * 3 + 1]) + nv[it][2] * extra[dt * 3 + 2];
+                }
+                qrow[dt * kFreqN + wq] = q;
               }
-              qrow[dt * kFreqN + wq] = q;
             }
           }
           __builtin_amdgcn_wave_barrier();
@@ -311,7 +415,9 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
           }
         }
       }
+      BR_STAMP(1);
       __syncthreads();
+      BR_STAMP(2);
 
       // ---- output rows r0-PH2 .. r0-PH2+3 (one per wave), then the next 4 image rows
       {
@@ -330,11 +436,18 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
           }
         }
       }
-      if (ph + 1 < n_phase)
-        stage_rows<Br>(p, b, r0 + kBrRows + PH1, kBrRows, img_hi, img_lo, wave, lane);
+      BR_STAMP(3);
+      if (ph + 1 < n_phase) stage_block<Br, kBrRows>(p, b, r0 + kBrRows + PH1, img_hi, img_lo, threadIdx.x);
+      BR_STAMP(4);
       __syncthreads();
+      BR_STAMP(5);
     }
   }
+  if (PROF && blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p.prof[wave * 6 + k] = acc_t[k];
+  }
+#undef BR_STAMP
 }
 
 // ---- z pack: NormalizedLog tail + BatchNorm affine, stored pre-split as (f16 hi | f16 lo << 16) ----
@@ -372,6 +485,23 @@ template <class Br>
 static void launch_branch(const BranchParams& p, int n_cu, bool weights_have_lo, hipStream_t stream) {
   const int items = p.n_windows * kBrChunks;
   const int grid = items < 2 * n_cu ? items : 2 * n_cu;
+  static const bool prof = getenv("BP_BRANCH_PROF") != nullptr;
+  if (prof) {  // tools only: phase profile of block 0 to stderr
+    BranchParams q = p;
+    unsigned long long hbuf[24];
+    if (hipMalloc(&q.prof, sizeof hbuf) != hipSuccess) return;
+    (void)hipMemsetAsync(q.prof, 0, sizeof hbuf, stream);
+    hipLaunchKernelGGL((branch_kernel<Br, true, true>), dim3(grid), dim3(kBrThreads), 0, stream, q);
+    (void)hipMemcpyAsync(hbuf, q.prof, sizeof hbuf, hipMemcpyDeviceToHost, stream);
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(q.prof);
+    for (int w = 0; w < 4; ++w) {
+      fprintf(stderr, "brprof %s wave %d:", Br::kOnset ? "onset" : "note", w);
+      for (int k = 0; k < 6; ++k) fprintf(stderr, " %llu", hbuf[w * 6 + k]);
+      fprintf(stderr, "\n");
+    }
+    return;
+  }
   if (weights_have_lo)
     hipLaunchKernelGGL((branch_kernel<Br, true>), dim3(grid), dim3(kBrThreads), 0, stream, p);
   else
@@ -380,13 +510,13 @@ static void launch_branch(const BranchParams& p, int n_cu, bool weights_have_lo,
 
 void launch_note_branch(const float* contour, const void* wfrag, const float* wf32, float* note,
                         int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream) {
-  BranchParams p{static_cast<const uint4*>(wfrag), wf32, contour, nullptr, note, n_windows};
+  BranchParams p{static_cast<const uint4*>(wfrag), wf32, contour, nullptr, note, n_windows, nullptr};
   launch_branch<NoteBr>(p, n_cu, weights_have_lo, stream);
 }
 
 void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32,
                          float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream) {
-  BranchParams p{static_cast<const uint4*>(wfrag), wf32, zp, note, onset, n_windows};
+  BranchParams p{static_cast<const uint4*>(wfrag), wf32, zp, note, onset, n_windows, nullptr};
   launch_branch<OnsetBr>(p, n_cu, weights_have_lo, stream);
 }
 
