@@ -88,6 +88,18 @@ struct ResamplePlan {
 
 __device__ __forceinline__ float sigmoidf_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() is a workgroup-scope fence + s_barrier, and on gfx9 that
+// fence drains vmcnt: every global load still in flight is waited for at every barrier, which defeats fetching the
+// next step's data ahead of a barrier.  This one waits for the wave's own LDS operations (lgkmcnt) and meets the other
+// waves; global loads stay in flight, the compiler still waits for them before their first use.  Not a fence for
+// global memory: do not use it to publish global stores to other waves.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // vmcnt = 63, expcnt = 7, lgkmcnt = 0
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
 }  // namespace bp

@@ -102,9 +102,8 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 // Tasks (row, slot) are dealt round-robin to the 256 threads; a thread first ISSUES the loads of all its tasks
 // (NT x 8 in flight), then splits / packs and writes them: the global-load latency is paid once per call, not once
 // per task.  Slots that are zero for every row (onset: the two padding bins of "same") are written by init_rows.
-// note branch: the staging of NROWS contour rows as two halves (issue all loads, then split and write).  Issuing a
-// whole phase ahead was tried: the compiler's vmcnt bookkeeping across the tile loop waits for the loads at the top of
-// the loop anyway (register reuse), so the two halves run back to back
+// note branch: the staging of NROWS contour rows as two halves, so that the loads can be issued a whole phase before
+// the LDS writes (their latency then hides behind the phase's tiles)
 template <int NROWS>
 struct NoteStage {
   static constexpr int NT = (NROWS * kFreqN + kBrThreads - 1) / kBrThreads;
@@ -280,6 +279,11 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
     for (int ph = 0; ph < n_phase; ++ph) {
       const int r0 = T0 - PH2 + kBrRows * ph;  // first conv1 row of this phase
       BR_STAMP(0);
+      // note branch: the next phase's contour rows are requested now and written to LDS after this phase's tiles
+      // (the barriers in between are lds_barrier: they do not wait for these loads)
+      NoteStage<kBrRows> early;
+      if constexpr (!Br::kOnset)
+        if (ph + 1 < n_phase) note_stage_issue<Br, kBrRows>(p, b, r0 + kBrRows + PH1, threadIdx.x, early);
 
       // ---- conv1 + projection, 12 tiles: 4 rows x 3 overlapping 32-pixel tiles (30 inner pixels each)
 #pragma unroll 1
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
         }
       }
       BR_STAMP(1);
-      __syncthreads();
+      lds_barrier();
       BR_STAMP(2);
 
       // ---- output rows r0-PH2 .. r0-PH2+3 (one per wave), then the next 4 image rows
@@ -437,9 +441,14 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
         }
       }
       BR_STAMP(3);
-      if (ph + 1 < n_phase) stage_block<Br, kBrRows>(p, b, r0 + kBrRows + PH1, img_hi, img_lo, threadIdx.x);
+      if (ph + 1 < n_phase) {
+        if constexpr (Br::kOnset)
+          stage_block<Br, kBrRows>(p, b, r0 + kBrRows + PH1, img_hi, img_lo, threadIdx.x);
+        else
+          note_stage_commit<kBrRows>(early, img_hi, img_lo);
+      }
       BR_STAMP(4);
-      __syncthreads();
+      lds_barrier();
       BR_STAMP(5);
     }
   }

@@ -1,10 +1,6 @@
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-timeout 120 python bench.py --no-cpu-baseline --steps 30 --warmup 5 2>&1 | tail -1 | python -c "
-import sys, json
-for line in sys.stdin:
-    if line.startswith('{'):
-        d = json.loads(line)
-        print(round(d['value']), {k: round(v, 4) for k, v in d['stage_ms'].items() if v}, round(d['roofline']['frac'],4))
-    else: print(line)
-"
-BP_BRANCH_PROF=1 timeout 120 python bench.py --no-cpu-baseline --steps 1 --warmup 0 2>&1 | grep brprof | grep "wave 1"
+bash tools/profile_gpu.sh g > gpurun_out/prof_g.log 2>&1
+timeout 300 python bench.py > gpurun_out/r01g_bench.json 2> gpurun_out/r01g_bench.err
+cut -c1-300 gpurun_out/r01g_bench.json
+timeout 300 python bench.py --workload tracks --steps 2 --warmup 1 > gpurun_out/r01g_bench_tracks.json 2>/dev/null
+timeout 300 python bench.py --bf16-weights --batch 1024 --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/r01g_bench_bf16_b1024.json 2>/dev/null
+timeout 300 python bench.py --batch 1024 --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/r01g_bench_b1024.json 2>/dev/null
