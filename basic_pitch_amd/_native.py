@@ -17,6 +17,7 @@ BP_MEM_DEVICE = 1
 BP_FLAG_STAGE_TIMING = 1
 BP_FLAG_F32_MFMA = 2
 BP_FLAG_BF16_WEIGHTS = 4
+BP_FLAG_EXT_CQT_44K = 8
 BP_N_STAGES = 15
 BP_Z_ROW = 448
 BP_Z_ROWS = 174
@@ -110,6 +111,11 @@ EXPORTED_SYMBOLS = [
     "bp_resample",
     "bp_infer_pcm",
     "bp_track_n_windows",
+    "bp_handle_track_n_windows",
+    "bp_handle_track_n_frames",
+    "bp_handle_window_samples",
+    "bp_handle_sample_rate",
+    "bp_handle_resampled_length",
     "bp_track_n_frames",
     "bp_set_stream",
     "bp_synchronize",
@@ -162,6 +168,16 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bp_resample.restype = C.c_int
     lib.bp_infer_pcm.argtypes = [vp, fp, i64, C.c_int, C.c_int, fp, fp, fp, C.c_int]
     lib.bp_infer_pcm.restype = C.c_int
+    lib.bp_handle_track_n_windows.argtypes = [vp, i64]
+    lib.bp_handle_track_n_windows.restype = i64
+    lib.bp_handle_track_n_frames.argtypes = [vp, i64]
+    lib.bp_handle_track_n_frames.restype = i64
+    lib.bp_handle_window_samples.argtypes = [vp]
+    lib.bp_handle_window_samples.restype = i64
+    lib.bp_handle_sample_rate.argtypes = [vp]
+    lib.bp_handle_sample_rate.restype = C.c_int
+    lib.bp_handle_resampled_length.argtypes = [vp, i64, C.c_int]
+    lib.bp_handle_resampled_length.restype = i64
     lib.bp_track_n_windows.argtypes = [i64]
     lib.bp_track_n_windows.restype = i64
     lib.bp_track_n_frames.argtypes = [i64]

@@ -19,7 +19,7 @@ namespace bp {
 // kernels (one translation unit each)
 void launch_pyramid(const float* audio, float* pyr, const float* lowpass, int n_windows, hipStream_t s);
 void launch_window_track(const float* samples, int64_t n_samples, int64_t first_window, int n_windows,
-                         float* audio, hipStream_t s);
+                         float* audio, int win_len, int hop, int lead, hipStream_t stream);
 void launch_unwrap(const float* win_out, int n_freq, int64_t first_window, int n_windows,
                    int64_t total_rows, float* out, hipStream_t s);
 size_t filterbank_scratch_floats(int n_windows);
@@ -40,11 +40,12 @@ void launch_note2(const float* n1, const float* wgt, float bias, float* note, in
                   hipStream_t s);
 void launch_onset2(const float* note, const float* o1, const float* wgt, float bias, float* onset,
                    int n_windows, hipStream_t s);
-void launch_pyramid_mfma(const float* audio, float* pyr, const void* hfrag, int n_windows, hipStream_t s);
+void launch_pyramid_mfma(const float* audio, float* pyr, const void* hfrag, int n_windows, bool ext, hipStream_t s);
 void launch_filterbank_mfma(const float* audio, const float* pyr, const void* bfrag, const float* sqrt_len,
-                            float* lp, int* mm, float* scratch, int n_windows, LogConsts kc, int n_cu,
-                            hipStream_t s);
-void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc, hipStream_t s);
+                            float* lp, int* mm, float* scratch, int n_windows, LogConsts kc, int n_cu, bool ext,
+                            hipStream_t stream);
+void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc, int n_bins,
+                  hipStream_t s);
 ResamplePlan make_resample_plan(int source_rate, int target_rate, std::vector<double>& taps);
 void launch_downmix(const float* pcm, int64_t n_frames, int channels, float* mono, hipStream_t stream);
 void launch_resample(const float* x, int64_t n_in, const double* taps, const ResamplePlan& pl, float* y,
@@ -151,6 +152,11 @@ struct bp_context {
   int64_t cap = 0;
   int64_t workspace_bytes = 0;
   std::string err;
+
+  // window geometry: the reference's 22.05 kHz model, or the extended 44.1 kHz range (BP_FLAG_EXT_CQT_44K)
+  bool ext = false;
+  int win_len = kAudioN, hop = BP_HOP_SIZE, lead = BP_OVERLAP_LEN / 2, n_bins = kBins, rate = BP_AUDIO_SAMPLE_RATE;
+  int64_t pyr_stride = kPyrStride;
 
   LogConsts kc{};
   float b_contour2 = 0, b_note2 = 0, b_onset2 = 0;
@@ -574,10 +580,10 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
                       h->n_cu, s);
     BP_MARK(BP_STAGE_FILTERBANK);
   } else {
-    launch_pyramid_mfma(audio_dev, h->pyr, h->d_dec_hfrag, n, s);
+    launch_pyramid_mfma(audio_dev, h->pyr, h->d_dec_hfrag, n, h->ext, s);
     BP_MARK(BP_STAGE_PYRAMID);
     launch_filterbank_mfma(audio_dev, h->pyr, h->d_fbh_bfrag, h->d_sqrt_len, h->lp, h->mm, h->fb_scratch, n,
-                           h->kc, h->n_cu, s);
+                           h->kc, h->n_cu, h->ext, s);
     BP_MARK(BP_STAGE_FILTERBANK);
   }
   if (h->flags & BP_FLAG_F32_MFMA) {
@@ -594,7 +600,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
     launch_onset2(note_dev, h->o1, h->d_w_onset2, h->b_onset2, onset_dev, n, s);
     BP_MARK(BP_STAGE_ONSET2);
   } else {
-    launch_zpack(h->lp, h->mm, reinterpret_cast<uint32_t*>(h->zp), n, h->kc, s);
+    launch_zpack(h->lp, h->mm, reinterpret_cast<uint32_t*>(h->zp), n, h->kc, h->n_bins, s);
     BP_MARK(BP_STAGE_ZPACK);
     if (h->fused_contour) {
       launch_contour_branch(reinterpret_cast<const uint32_t*>(h->zp), h->d_cb_wfrag, h->d_cb_wf32, contour_dev, n,
@@ -717,6 +723,20 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   std::snprintf(h->arch, sizeof h->arch, "%s", prop.gcnArchName);
   h->cap = max_windows_hint > 0 ? max_windows_hint : 256;
+  if (flags & BP_FLAG_EXT_CQT_44K) {
+    if (flags & BP_FLAG_F32_MFMA) {
+      g_create_error = "bp_create: BP_FLAG_EXT_CQT_44K is not available on the exact-f32 path (BP_FLAG_F32_MFMA)";
+      delete h;
+      return BP_ERR_UNSUPPORTED;
+    }
+    h->ext = true;
+    h->win_len = kAudioNExt;
+    h->hop = 2 * BP_HOP_SIZE;
+    h->lead = BP_OVERLAP_LEN;
+    h->n_bins = kBinsExt;
+    h->rate = 2 * BP_AUDIO_SAMPLE_RATE;
+    h->pyr_stride = kPyrStrideExt;
+  }
   h->kc.eps = eps->data[0];
   h->kc.s0 = lsc->data[0];
   h->kc.s1 = lsc->data[1];
@@ -789,7 +809,22 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
   pack_contour1(c1w, c1f);
   pack_onset1(o1w, o1f);
   pack_note1(n1w, n1f);
-  if ((rc = upload(h, vec(lowp), &h->d_lowpass)) || (rc = upload(h, vec(sq), &h->d_sqrt_len)) ||
+  std::vector<float> sqrt_len = vec(sq);
+  if (h->ext) {
+    // lengths = ceil(Q * sr / f_b), f_b = 27.5 * 2^(b / 36), Q = 1 / (2^(1/36) - 1) at sr = 44100 (nnaudio.py:532,
+    // 590-593); bin b + 36 of this table must reproduce bin b of the 22.05 kHz artifact
+    const double Q = 1.0 / (std::pow(2.0, 1.0 / 36.0) - 1.0);
+    std::vector<float> ext(kBinsExt);
+    for (int bn = 0; bn < kBinsExt; ++bn)
+      ext[bn] = (float)std::sqrt(std::ceil(Q * 44100.0 / (27.5 * std::pow(2.0, bn / 36.0))));
+    for (int bn = 0; bn < kBins; ++bn)
+      if (std::fabs(ext[bn + 36] - sqrt_len[bn]) > 1e-6f * sqrt_len[bn]) {
+        h->err = "bp_create: the extended sqrt(lengths) table does not continue the model's table";
+        return fail(BP_ERR_BAD_WEIGHTS);
+      }
+    sqrt_len = ext;
+  }
+  if ((rc = upload(h, vec(lowp), &h->d_lowpass)) || (rc = upload(h, sqrt_len, &h->d_sqrt_len)) ||
       (rc = upload(h, fb, &h->d_fb_bfrag)) || (rc = upload(h, c1f, &h->d_c1_bfrag)) ||
       (rc = upload(h, vec(c1b), &h->d_c1_bias)) || (rc = upload(h, o1f, &h->d_o1_bfrag)) ||
       (rc = upload(h, vec(o1b), &h->d_o1_bias)) || (rc = upload(h, n1f, &h->d_n1_bfrag)) ||
@@ -798,8 +833,8 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     return fail(rc);
 
   const int64_t cap = h->cap;
-  if ((rc = alloc(h, &h->audio, cap * kAudioN)) || (rc = alloc(h, &h->pyr, cap * kPyrStride)) ||
-      (rc = alloc(h, &h->lp, cap * kFrames * kBins)) || (rc = alloc(h, &h->c1, cap * 8 * kPlaneC)) ||
+  if ((rc = alloc(h, &h->audio, cap * (int64_t)h->win_len)) || (rc = alloc(h, &h->pyr, cap * h->pyr_stride)) ||
+      (rc = alloc(h, &h->lp, cap * kFrames * (int64_t)h->n_bins)) || (rc = alloc(h, &h->c1, cap * 8 * kPlaneC)) ||
       (rc = alloc(h, &h->contour, cap * kPlaneC)) || (rc = alloc(h, &h->n1, cap * 32 * kPlaneN)) ||
       (rc = alloc(h, &h->note, cap * kPlaneN)) || (rc = alloc(h, &h->o1, cap * 32 * kPlaneN)) ||
       (rc = alloc(h, &h->onset, cap * kPlaneN)) || (rc = alloc(h, &h->zp, cap * (int64_t)kZWin)) ||
@@ -875,7 +910,7 @@ int bp_infer_async(bp_handle h, const float* audio_dev, int64_t n_windows, float
   BP_HIP(hipSetDevice(h->device));
   for (int64_t w0 = 0; w0 < n_windows; w0 += h->cap) {
     const int n = (int)((n_windows - w0) < h->cap ? (n_windows - w0) : h->cap);
-    int rc = run_chunk(h, audio_dev + w0 * kAudioN, n, note_dev + w0 * kPlaneN, onset_dev + w0 * kPlaneN,
+    int rc = run_chunk(h, audio_dev + w0 * h->win_len, n, note_dev + w0 * kPlaneN, onset_dev + w0 * kPlaneN,
                        contour_dev + w0 * kPlaneC);
     if (rc) return rc;
   }
@@ -903,7 +938,7 @@ int bp_infer(bp_handle h, const float* audio, int64_t n_windows, float* note, fl
   hipStream_t s = h->stream;
   for (int64_t w0 = 0; w0 < n_windows; w0 += h->cap) {
     const int n = (int)((n_windows - w0) < h->cap ? (n_windows - w0) : h->cap);
-    BP_HIP(hipMemcpyAsync(h->audio, audio + w0 * kAudioN, (size_t)n * kAudioN * 4, hipMemcpyHostToDevice, s));
+    BP_HIP(hipMemcpyAsync(h->audio, audio + w0 * h->win_len, (size_t)n * h->win_len * 4, hipMemcpyHostToDevice, s));
     int rc = run_chunk(h, h->audio, n, h->note, h->onset, h->contour);
     if (rc) return rc;
     BP_HIP(hipMemcpyAsync(note + w0 * kPlaneN, h->note, (size_t)n * kPlaneN * 4, hipMemcpyDeviceToHost, s));
@@ -912,6 +947,28 @@ int bp_infer(bp_handle h, const float* audio, int64_t n_windows, float* note, fl
     BP_HIP(hipStreamSynchronize(s));
   }
   return BP_OK;
+}
+
+// the same counts for a handle's geometry (hop 36164 / lead-in 3840 at 22.05 kHz, doubled for the extended range)
+static int64_t h_track_n_windows(bp_handle h, int64_t n_samples) {
+  if (n_samples <= 0) return 0;
+  return (n_samples + h->lead + h->hop - 1) / h->hop;
+}
+static int64_t h_track_n_frames(bp_handle h, int64_t n_samples) {
+  if (n_samples <= 0) return 0;
+  const double n_expected_windows = (double)n_samples / (double)h->hop;
+  const int64_t rows = (int64_t)(n_expected_windows * (double)BP_FRAMES_PER_WINDOW);
+  const int64_t avail = h_track_n_windows(h, n_samples) * BP_FRAMES_PER_WINDOW;
+  return rows < avail ? rows : avail;
+}
+
+int64_t bp_handle_track_n_windows(bp_handle h, int64_t n_samples) { return h ? h_track_n_windows(h, n_samples) : 0; }
+int64_t bp_handle_track_n_frames(bp_handle h, int64_t n_samples) { return h ? h_track_n_frames(h, n_samples) : 0; }
+int64_t bp_handle_window_samples(bp_handle h) { return h ? h->win_len : 0; }
+int bp_handle_sample_rate(bp_handle h) { return h ? h->rate : 0; }
+int64_t bp_handle_resampled_length(bp_handle h, int64_t n_frames, int sample_rate) {
+  if (!h || n_frames <= 0 || sample_rate <= 0) return 0;
+  return (n_frames * (int64_t)h->rate + sample_rate - 1) / sample_rate;
 }
 
 int64_t bp_track_n_windows(int64_t n_samples) {
@@ -932,8 +989,8 @@ int64_t bp_track_n_frames(int64_t n_samples) {
 static int track_core(bp_handle h, const float* d_samples, int64_t n_samples, float* note, float* onset,
                       float* contour, int out_kind) {
   hipStream_t s = h->stream;
-  const int64_t n_win = bp_track_n_windows(n_samples);
-  const int64_t T = bp_track_n_frames(n_samples);
+  const int64_t n_win = h_track_n_windows(h, n_samples);
+  const int64_t T = h_track_n_frames(h, n_samples);
   float *d_note = note, *d_onset = onset, *d_contour = contour;
   if (out_kind == BP_MEM_HOST) {
     const int64_t need = T * (88 + 88 + 264);
@@ -950,7 +1007,7 @@ static int track_core(bp_handle h, const float* d_samples, int64_t n_samples, fl
   }
   for (int64_t w0 = 0; w0 < n_win; w0 += h->cap) {
     const int n = (int)((n_win - w0) < h->cap ? (n_win - w0) : h->cap);
-    launch_window_track(d_samples, n_samples, w0, n, h->audio, s);
+    launch_window_track(d_samples, n_samples, w0, n, h->audio, h->win_len, h->hop, h->lead, s);
     int rc = run_chunk(h, h->audio, n, h->note, h->onset, h->contour);
     if (rc) return rc;
     if (T > 0) {
@@ -986,8 +1043,8 @@ int bp_infer_track(bp_handle h, const float* samples, int64_t n_samples, float* 
     h->err = "bp_infer_track: bad argument";
     return BP_ERR_INVALID_ARG;
   }
-  const int64_t n_win = bp_track_n_windows(n_samples);
-  const int64_t T = bp_track_n_frames(n_samples);
+  const int64_t n_win = h_track_n_windows(h, n_samples);
+  const int64_t T = h_track_n_frames(h, n_samples);
   if (n_win == 0) return BP_OK;
   if (!samples || (T > 0 && (!note || !onset || !contour))) {
     h->err = "bp_infer_track: null pointer";
@@ -1018,7 +1075,7 @@ int bp_infer_tracks(bp_handle h, int64_t n_tracks, const float* const* samples, 
       h->err = "bp_infer_tracks: negative length or null samples";
       return BP_ERR_INVALID_ARG;
     }
-    const int64_t T = bp_track_n_frames(n_samples[t]);
+    const int64_t T = h_track_n_frames(h, n_samples[t]);
     if (T > 0 && (!note[t] || !onset[t] || !contour[t])) {
       h->err = "bp_infer_tracks: null output pointer";
       return BP_ERR_INVALID_ARG;
@@ -1039,7 +1096,7 @@ int bp_infer_tracks(bp_handle h, int64_t n_tracks, const float* const* samples, 
     if (rc) return rc;
     int64_t so = 0, ro = 0;
     for (int64_t t = 0; t < n_tracks; ++t) {
-      const int64_t T = bp_track_n_frames(n_samples[t]);
+      const int64_t T = h_track_n_frames(h, n_samples[t]);
       if (n_samples[t] > 0)
         BP_HIP(hipMemcpyAsync(h->track + so, samples[t], (size_t)n_samples[t] * 4, hipMemcpyHostToDevice, s));
       d_in[t] = h->track + so;
@@ -1068,7 +1125,7 @@ int bp_infer_tracks(bp_handle h, int64_t n_tracks, const float* const* samples, 
     int rc = run_chunk(h, h->audio, cur, h->note, h->onset, h->contour);
     if (rc) return rc;
     for (const Seg& g : segs) {
-      const int64_t T = bp_track_n_frames(n_samples[g.track]);
+      const int64_t T = h_track_n_frames(h, n_samples[g.track]);
       if (T <= 0) continue;
       launch_unwrap(h->note + (int64_t)g.at * kPlaneN, 88, g.w0, g.n, T, d_note[g.track], s);
       launch_unwrap(h->onset + (int64_t)g.at * kPlaneN, 88, g.w0, g.n, T, d_onset[g.track], s);
@@ -1079,11 +1136,12 @@ int bp_infer_tracks(bp_handle h, int64_t n_tracks, const float* const* samples, 
     return BP_OK;
   };
   for (int64_t t = 0; t < n_tracks; ++t) {
-    const int64_t n_win = bp_track_n_windows(n_samples[t]);
+    const int64_t n_win = h_track_n_windows(h, n_samples[t]);
     for (int64_t w0 = 0; w0 < n_win;) {
       const int64_t room = h->cap - cur;
       const int n = (int)((n_win - w0) < room ? (n_win - w0) : room);
-      launch_window_track(d_in[t], n_samples[t], w0, n, h->audio + (int64_t)cur * kAudioN, s);
+      launch_window_track(d_in[t], n_samples[t], w0, n, h->audio + (int64_t)cur * h->win_len, h->win_len, h->hop, h->lead,
+                          s);
       segs.push_back({t, w0, n, cur});
       cur += n;
       w0 += n;
@@ -1100,7 +1158,7 @@ int bp_infer_tracks(bp_handle h, int64_t n_tracks, const float* const* samples, 
   BP_HIP(hipGetLastError());
   if (mem_kind == BP_MEM_HOST) {
     for (int64_t t = 0; t < n_tracks; ++t) {
-      const int64_t T = bp_track_n_frames(n_samples[t]);
+      const int64_t T = h_track_n_frames(h, n_samples[t]);
       if (T <= 0) continue;
       BP_HIP(hipMemcpyAsync(note[t], d_note[t], (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
       BP_HIP(hipMemcpyAsync(onset[t], d_onset[t], (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
@@ -1127,7 +1185,7 @@ static int ingest(bp_handle h, const float* pcm, int64_t n_frames, int channels,
   }
   BP_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
-  *n_out = bp_resampled_length(n_frames, sample_rate);
+  *n_out = bp_handle_resampled_length(h, n_frames, sample_rate);
   *out = nullptr;
   if (n_frames == 0) return BP_OK;
   const float* d_pcm = pcm;
@@ -1144,13 +1202,13 @@ static int ingest(bp_handle h, const float* pcm, int64_t n_frames, int channels,
     launch_downmix(d_pcm, n_frames, channels, h->mono_dev, s);
     d_mono = h->mono_dev;
   }
-  if (sample_rate == BP_AUDIO_SAMPLE_RATE) {
+  if (sample_rate == h->rate) {
     *out = d_mono;
     return BP_OK;
   }
   if (h->taps_rate != sample_rate) {
     std::vector<double> taps;
-    const ResamplePlan pl = make_resample_plan(sample_rate, BP_AUDIO_SAMPLE_RATE, taps);
+    const ResamplePlan pl = make_resample_plan(sample_rate, h->rate, taps);
     if (pl.up > 2000 || pl.down > 2000) {
       h->err = "audio ingest: sample-rate ratio too irregular (reduced up / down factor > 2000)";
       return BP_ERR_INVALID_ARG;
@@ -1196,8 +1254,8 @@ int bp_infer_pcm(bp_handle h, const float* pcm, int64_t n_frames, int channels, 
   int64_t n = 0;
   int rc = ingest(h, pcm, n_frames, channels, sample_rate, mem_kind, &d, &n);
   if (rc) return rc;
-  if (bp_track_n_windows(n) == 0) return BP_OK;
-  if (bp_track_n_frames(n) > 0 && (!note || !onset || !contour)) {
+  if (h_track_n_windows(h, n) == 0) return BP_OK;
+  if (h_track_n_frames(h, n) > 0 && (!note || !onset || !contour)) {
     h->err = "bp_infer_pcm: null output pointer";
     return BP_ERR_INVALID_ARG;
   }
@@ -1246,7 +1304,7 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
         if (h->flags & BP_FLAG_F32_MFMA)
           launch_pyramid(bf->audio, bf->pyr, h->d_lowpass, n, s);
         else
-          launch_pyramid_mfma(bf->audio, bf->pyr, h->d_dec_hfrag, n, s);
+          launch_pyramid_mfma(bf->audio, bf->pyr, h->d_dec_hfrag, n, h->ext, s);
       }
       break;
     case BP_STAGE_FILTERBANK:
@@ -1258,7 +1316,7 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
                             h->kc, h->n_cu, s);
         else
           launch_filterbank_mfma(bf->audio, bf->pyr, h->d_fbh_bfrag, h->d_sqrt_len, bf->lp, bf->mm,
-                                 h->fb_scratch, n, h->kc, h->n_cu, s);
+                                 h->fb_scratch, n, h->kc, h->n_cu, h->ext, s);
       }
       break;
     case BP_STAGE_CONTOUR1:
@@ -1285,7 +1343,7 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
         launch_onset2(bf->note, bf->o1, h->d_w_onset2, h->b_onset2, bf->onset, n, s);
       break;
     case BP_STAGE_ZPACK:
-      if ((ok = need(bf->lp) && need(bf->mm) && need(bf->zp))) launch_zpack(bf->lp, bf->mm, bf->zp, n, h->kc, s);
+      if ((ok = need(bf->lp) && need(bf->mm) && need(bf->zp))) launch_zpack(bf->lp, bf->mm, bf->zp, n, h->kc, h->n_bins, s);
       break;
     case BP_STAGE_CONTOUR:
       if ((ok = need(bf->zp) && need(bf->contour))) {

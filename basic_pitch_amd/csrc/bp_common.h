@@ -41,6 +41,15 @@ __host__ __device__ constexpr int pyr_off(int k) {
   return off;
 }
 static_assert(level_len(1) == 21922 && level_len(8) == 171, "pyramid geometry");
+
+// Extended range for 44.1 kHz input (BASELINE.json configs[4]; SURVEY.md App. A.6 — not a reference behaviour): the same
+// 36 kernels and low-pass, hop 512, one more octave on top: 10 levels, 345 bins, windows of 87,688 samples.  Level
+// k >= 1 of this pyramid has exactly the length of level k - 1 of the 22.05 kHz one.
+constexpr int kAudioNExt = 2 * kAudioN;          // 87688
+constexpr int kOctavesExt = kOctaves + 1;         // 10
+constexpr int kBinsExt = kBins + kBpo;            // 345
+constexpr int kPyrStrideExt = kAudioN + kPyrStride;  // level 1 (43844 samples), then levels 2..9 at the std offsets
+static_assert((kAudioNExt - 2) / 2 + 1 == kAudioN, "level 1 of the extended pyramid");
 static_assert(pyr_off(8) + level_len(8) <= kPyrStride, "pyr stride");
 
 // harmonic shifts round(36*log2(h)), h = 0.5,1,2..7   (nn.py:51-54, models.py:213-218)

@@ -463,11 +463,11 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
 // (signal.py:177-183, models.py:187-189).  One pass over lp; consumers gather these words straight
 // into MFMA operand slots with no further arithmetic.
 __global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ lp, const int* __restrict__ mm,
-                                                    uint32_t* __restrict__ zp, LogConsts kc) {
+                                                    uint32_t* __restrict__ zp, LogConsts kc, int n_bins) {
   const int b = blockIdx.y;
   const float mn = ord2f(mm[2 * b]);
   const float range = ord2f(mm[2 * b + 1]) - mn;
-  const float* lpb = lp + (int64_t)b * kFrames * kBins;
+  const float* lpb = lp + (int64_t)b * kFrames * n_bins;
   uint32_t* zb = zp + (int64_t)b * kZWin;
   // the whole padded window is written every time (pad frames and pad words are zero: the zero padding of the
   // harmonic stack, nn.py:73-85, and of the convolutions' frame halo)
@@ -475,8 +475,8 @@ __global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ lp
     const int tp = i / kZRow, g = i - tp * kZRow - kZPadL;
     const int t = tp - 1;
     uint32_t u = 0;
-    if (t >= 0 && t < kFrames && g >= 0 && g < kBins) {
-      const float z = norm_bn(lpb[t * kBins + g], mn, range, kc);
+    if (t >= 0 && t < kFrames && g >= 0 && g < n_bins) {
+      const float z = norm_bn(lpb[t * n_bins + g], mn, range, kc);
       _Float16 hi, lo;
       split_f16(z, hi, lo);
       u = (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
@@ -485,9 +485,9 @@ __global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ lp
   }
 }
 
-void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc,
+void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc, int n_bins,
                   hipStream_t stream) {
-  hipLaunchKernelGGL(zpack_kernel, dim3(16, n_windows), dim3(256), 0, stream, lp, mm, zp, kc);
+  hipLaunchKernelGGL(zpack_kernel, dim3(16, n_windows), dim3(256), 0, stream, lp, mm, zp, kc, n_bins);
 }
 
 template <class Br>

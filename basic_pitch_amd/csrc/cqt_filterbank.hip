@@ -180,12 +180,12 @@ __global__ __launch_bounds__(kFbThreads) void cqt_filterbank_kernel(
 constexpr int kMmPartials = kOctaves * kFbTilesPerLevel * 4;  // 396 per window
 
 // one wave per window: fold the partial extrema into mm[b] = (ord(min), ord(max))
-__global__ __launch_bounds__(64) void mm_reduce_kernel(const float2* __restrict__ mmp,
+__global__ __launch_bounds__(64) void mm_reduce_kernel(const float2* __restrict__ mmp, int n_partials,
                                                        int* __restrict__ mm) {
   const int b = blockIdx.x;
   float vmin = __int_as_float(0x7f800000), vmax = -__int_as_float(0x7f800000);
-  for (int i = threadIdx.x; i < kMmPartials; i += 64) {
-    const float2 p = mmp[(int64_t)b * kMmPartials + i];
+  for (int i = threadIdx.x; i < n_partials; i += 64) {
+    const float2 p = mmp[(int64_t)b * n_partials + i];
     vmin = fminf(vmin, p.x);
     vmax = fmaxf(vmax, p.y);
   }
@@ -212,12 +212,13 @@ static void launch_fb_level(const float* audio, const float* pyr, const float* b
                      bfrag, sqrt_len, lp, mmp, n_windows, kc);
 }
 
-void launch_mm_reduce(const float* scratch, int* mm, int n_windows, hipStream_t stream) {
+void launch_mm_reduce(const float* scratch, int* mm, int n_windows, int n_partials, hipStream_t stream) {
   hipLaunchKernelGGL(mm_reduce_kernel, dim3(n_windows), dim3(64), 0, stream,
-                     reinterpret_cast<const float2*>(scratch), mm);
+                     reinterpret_cast<const float2*>(scratch), n_partials, mm);
 }
 
-size_t filterbank_scratch_floats(int n_windows) { return (size_t)n_windows * kMmPartials * 2; }
+// sized for the extended 10-level pyramid as well
+size_t filterbank_scratch_floats(int n_windows) { return (size_t)n_windows * (kMmPartials + kFbTilesPerLevel * 4) * 2; }
 
 void launch_filterbank(const float* audio, const float* pyr, const float* bfrag,
                        const float* sqrt_len, float* lp, int* mm, float* scratch, int n_windows,
@@ -233,7 +234,7 @@ void launch_filterbank(const float* audio, const float* pyr, const float* bfrag,
   launch_fb_level<6>(audio, pyr, bfrag, sqrt_len, lp, mmp, n_windows, kc, grid, stream);
   launch_fb_level<7>(audio, pyr, bfrag, sqrt_len, lp, mmp, n_windows, kc, grid, stream);
   launch_fb_level<8>(audio, pyr, bfrag, sqrt_len, lp, mmp, n_windows, kc, grid, stream);
-  hipLaunchKernelGGL(mm_reduce_kernel, dim3(n_windows), dim3(64), 0, stream, mmp, mm);
+  hipLaunchKernelGGL(mm_reduce_kernel, dim3(n_windows), dim3(64), 0, stream, mmp, kMmPartials, mm);
 }
 
 }  // namespace bp

@@ -126,25 +126,13 @@ __global__ __launch_bounds__(kDmThreads) void decimate2_mfma_kernel(const float*
   }
 }
 
-void launch_pyramid_mfma(const float* audio, float* pyr, const void* hfrag, int n_windows,
-                         hipStream_t stream) {
-  for (int k = 1; k < kOctaves; ++k) {
-    const float* src = (k == 1) ? audio : pyr + pyr_off(k - 1);
-    const int64_t sstride = (k == 1) ? kAudioN : kPyrStride;
-    const int lin = level_len(k - 1), lout = level_len(k);
-    dim3 grid((lout + kDmOutPerWg - 1) / kDmOutPerWg, n_windows);
-    hipLaunchKernelGGL(decimate2_mfma_kernel, grid, dim3(kDmThreads), 0, stream, src, sstride, lin,
-                       pyr + pyr_off(k), (int64_t)kPyrStride, lout, static_cast<const uint4*>(hfrag));
-  }
-}
-
 // ================================================================================================
 // filterbank
 constexpr int kFmThreads = 256;
 constexpr int kFmTileFrames = 16;
 constexpr int kFmTilesPerLevel = (kFrames + kFmTileFrames - 1) / kFmTileFrames;  // 11
 constexpr int kFmSteps = 7;                       // k-steps (32 taps) per wave
-constexpr int kFmMaxUnits = (15 * 256 + 256 + 16 * 16) / 8;  // hop 256: 4096 samples + 16 skews
+constexpr int kFmMaxUnits = (15 * 512 + 256 + 16 * 16) / 8;  // hop 512 (extended 44.1 kHz CQT): 7936 samples + 16 skews
 constexpr int kFmExRow = 17;
 constexpr int kFmExTile = kFmTileFrames * kFmExRow;
 
@@ -248,15 +236,14 @@ __device__ __forceinline__ void fm_role_compute(const uint4* __restrict__ s_hi, 
   }
 }
 
-template <int LEVEL>
-__device__ __forceinline__ void fm_item(const float* __restrict__ audio, const float* __restrict__ pyr, int b,
-                                        int tile, const uint4 (&bh)[kFmSteps], const uint4 (&bl)[kFmSteps],
+// one (window, level, tile) item; x = that window's signal of the level, L its length, `level` its index in the
+// pyramid of `n_levels` levels (hop = hop0 >> level), n_bins the CQT width (levels * 36 - 15)
+template <int HOP>
+__device__ __forceinline__ void fm_item(const float* __restrict__ x, int L, int b, int level, int n_levels,
+                                        int n_bins, int tile, const uint4 (&bh)[kFmSteps], const uint4 (&bl)[kFmSteps],
                                         const float* __restrict__ sqrt_len, float* __restrict__ lp,
                                         float2* __restrict__ mmp, const LogConsts& kc, uint4* s_hi, uint4* s_lo,
                                         float* exch, int role, int lane) {
-  constexpr int HOP = 256 >> LEVEL;
-  constexpr int L = level_len(LEVEL);
-  const float* x = (LEVEL == 0) ? audio + (int64_t)b * kAudioN : pyr + (int64_t)b * kPyrStride + pyr_off(LEVEL);
   const int t0 = tile * kFmTileFrames;
   // keep the per-level LDS address arithmetic inside the item (hoisting all 36 level x role variants
   // out of the persistent loop costs > 100 VGPRs)
@@ -278,7 +265,7 @@ __device__ __forceinline__ void fm_item(const float* __restrict__ audio, const f
   for (int idx = threadIdx.x; idx < kFmTileFrames * kBpo; idx += kFmThreads) {
     const int fr = idx / kBpo, k = idx - fr * kBpo;
     const int t = t0 + fr;
-    const int bin = (kOctaves - 1 - LEVEL) * kBpo + k - 15;  // nnaudio.py:640-642
+    const int bin = (n_levels - 1 - level) * kBpo + k - 15;  // nnaudio.py:640-642
     if (t >= kFrames || bin < 0) continue;
     float re, im;
     const float* e = exch + fr * kFmExRow;
@@ -298,7 +285,7 @@ __device__ __forceinline__ void fm_item(const float* __restrict__ audio, const f
     const float mag = sqrtf(__fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)));  // nnaudio.py:661
     const float pw = __fmul_rn(mag, mag);                                      // signal.py:174
     const float v = __fmul_rn(__fmul_rn(logf(__fadd_rn(pw, kc.eps)), kc.s0), kc.s1);
-    lp[((int64_t)b * kFrames + t) * kBins + bin] = v;
+    lp[((int64_t)b * kFrames + t) * n_bins + bin] = v;
     vmin = fminf(vmin, v);
     vmax = fmaxf(vmax, v);
   }
@@ -308,13 +295,22 @@ __device__ __forceinline__ void fm_item(const float* __restrict__ audio, const f
     vmax = fmaxf(vmax, __shfl_xor(vmax, o));
   }
   if (lane == 0)
-    mmp[(((int64_t)b * kOctaves + LEVEL) * kFmTilesPerLevel + tile) * 4 + role] = make_float2(vmin, vmax);
+    mmp[(((int64_t)b * n_levels + level) * kFmTilesPerLevel + tile) * 4 + role] = make_float2(vmin, vmax);
 }
+
+// Pyramid geometry of a launch: the reference's 22.05 kHz model (9 levels, hop 256, 309 bins, 43,844 samples) or the
+// extended 44.1 kHz range of BASELINE.json configs[4] (10 levels, hop 512, 345 bins, 87,688 samples: SURVEY.md App. A.6).
+struct FmGeo {
+  int n_levels, hop0, n_bins;
+  int64_t audio_stride, pyr_stride;
+  int len[10];  // samples of level k
+  int off[10];  // offset of level k inside a window's pyramid row (level 0 is the audio itself)
+};
 
 __global__ __launch_bounds__(kFmThreads, 4) void cqt_filterbank_mfma_kernel(
     const float* __restrict__ audio, const float* __restrict__ pyr, const uint4* __restrict__ bfrag,
     const float* __restrict__ sqrt_len, float* __restrict__ lp, float2* __restrict__ mmp, int n_windows,
-    LogConsts kc) {
+    LogConsts kc, FmGeo geo) {
   __shared__ __attribute__((aligned(16))) uint4 s_hi[kFmMaxUnits];
   __shared__ __attribute__((aligned(16))) uint4 s_lo[kFmMaxUnits];
   __shared__ float exch[6 * kFmExTile];
@@ -330,43 +326,93 @@ __global__ __launch_bounds__(kFmThreads, 4) void cqt_filterbank_mfma_kernel(
       bl[s] = bp_[(2 * s + 1) * 64];
     }
   }
-  const int per_window = kOctaves * kFmTilesPerLevel;
+  const int per_window = geo.n_levels * kFmTilesPerLevel;
   const int n_items = n_windows * per_window;
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int b = item / per_window;
     const int rem = item - b * per_window;
     const int level = rem / kFmTilesPerLevel;
     const int tile = rem - level * kFmTilesPerLevel;
-#define BP_FM_CASE(LV)                                                                                          \
-  case LV:                                                                                                      \
-    fm_item<LV>(audio, pyr, b, tile, bh, bl, sqrt_len, lp, mmp, kc, s_hi, s_lo, exch, role, lane);              \
+    const float* x = (level == 0) ? audio + (int64_t)b * geo.audio_stride
+                                  : pyr + (int64_t)b * geo.pyr_stride + geo.off[level];
+    const int L = geo.len[level];
+#define BP_FM_CASE(HOP)                                                                                         \
+  case HOP:                                                                                                     \
+    fm_item<HOP>(x, L, b, level, geo.n_levels, geo.n_bins, tile, bh, bl, sqrt_len, lp, mmp, kc, s_hi, s_lo,      \
+                 exch, role, lane);                                                                             \
     break;
-    switch (level) {
-      BP_FM_CASE(0)
-      BP_FM_CASE(1)
-      BP_FM_CASE(2)
-      BP_FM_CASE(3)
+    switch (geo.hop0 >> level) {
+      BP_FM_CASE(512)
+      BP_FM_CASE(256)
+      BP_FM_CASE(128)
+      BP_FM_CASE(64)
+      BP_FM_CASE(32)
+      BP_FM_CASE(16)
+      BP_FM_CASE(8)
       BP_FM_CASE(4)
-      BP_FM_CASE(5)
-      BP_FM_CASE(6)
-      BP_FM_CASE(7)
-      default: fm_item<8>(audio, pyr, b, tile, bh, bl, sqrt_len, lp, mmp, kc, s_hi, s_lo, exch, role, lane); break;
+      BP_FM_CASE(2)
+      default:
+        fm_item<1>(x, L, b, level, geo.n_levels, geo.n_bins, tile, bh, bl, sqrt_len, lp, mmp, kc, s_hi, s_lo, exch,
+                   role, lane);
+        break;
     }
 #undef BP_FM_CASE
   }
 }
 
-void launch_mm_reduce(const float* scratch, int* mm, int n_windows, hipStream_t stream);
+void launch_mm_reduce(const float* scratch, int* mm, int n_windows, int n_partials, hipStream_t stream);
+
+FmGeo make_fm_geo(bool ext) {
+  FmGeo g{};
+  if (!ext) {
+    g.n_levels = kOctaves;
+    g.hop0 = 256;
+    g.n_bins = kBins;
+    g.audio_stride = kAudioN;
+    g.pyr_stride = kPyrStride;
+    for (int k = 0; k < kOctaves; ++k) {
+      g.len[k] = level_len(k);
+      g.off[k] = k ? pyr_off(k) : 0;
+    }
+  } else {  // level k >= 1 of the 44.1 kHz pyramid has the length of level k - 1 of the 22.05 kHz one
+    g.n_levels = kOctavesExt;
+    g.hop0 = 512;
+    g.n_bins = kBinsExt;
+    g.audio_stride = kAudioNExt;
+    g.pyr_stride = kPyrStrideExt;
+    g.len[0] = kAudioNExt;
+    g.off[0] = 0;
+    for (int k = 1; k < kOctavesExt; ++k) {
+      g.len[k] = level_len(k - 1);
+      g.off[k] = k == 1 ? 0 : kAudioN + pyr_off(k - 1);
+    }
+  }
+  return g;
+}
+
+void launch_pyramid_mfma(const float* audio, float* pyr, const void* hfrag, int n_windows, bool ext,
+                         hipStream_t stream) {
+  const FmGeo g = make_fm_geo(ext);
+  for (int k = 1; k < g.n_levels; ++k) {
+    const float* src = (k == 1) ? audio : pyr + g.off[k - 1];
+    const int64_t sstride = (k == 1) ? g.audio_stride : g.pyr_stride;
+    const int lin = g.len[k - 1], lout = g.len[k];
+    dim3 grid((lout + kDmOutPerWg - 1) / kDmOutPerWg, n_windows);
+    hipLaunchKernelGGL(decimate2_mfma_kernel, grid, dim3(kDmThreads), 0, stream, src, sstride, lin,
+                       pyr + g.off[k], g.pyr_stride, lout, static_cast<const uint4*>(hfrag));
+  }
+}
 
 void launch_filterbank_mfma(const float* audio, const float* pyr, const void* bfrag, const float* sqrt_len,
-                            float* lp, int* mm, float* scratch, int n_windows, LogConsts kc, int n_cu,
+                            float* lp, int* mm, float* scratch, int n_windows, LogConsts kc, int n_cu, bool ext,
                             hipStream_t stream) {
+  const FmGeo g = make_fm_geo(ext);
   float2* mmp = reinterpret_cast<float2*>(scratch);
-  const int items = n_windows * kOctaves * kFmTilesPerLevel;
+  const int items = n_windows * g.n_levels * kFmTilesPerLevel;
   const int grid = items < 4 * n_cu ? items : 4 * n_cu;
   hipLaunchKernelGGL(cqt_filterbank_mfma_kernel, dim3(grid), dim3(kFmThreads), 0, stream, audio, pyr,
-                     static_cast<const uint4*>(bfrag), sqrt_len, lp, mmp, n_windows, kc);
-  launch_mm_reduce(scratch, mm, n_windows, stream);
+                     static_cast<const uint4*>(bfrag), sqrt_len, lp, mmp, n_windows, kc, g);
+  launch_mm_reduce(scratch, mm, n_windows, g.n_levels * kFmTilesPerLevel * 4, stream);
 }
 
 }  // namespace bp

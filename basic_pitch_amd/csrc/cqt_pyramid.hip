@@ -89,22 +89,24 @@ void launch_pyramid(const float* audio, float* pyr, const float* lowpass, int n_
 }
 
 // ---- track windowing (inference.py:242 zero lead-in of 3840, 207-213 hop 36164 + tail pad) ----
+// win_len / hop / lead: 43844 / 36164 / 3840 samples at 22.05 kHz, doubled for the extended 44.1 kHz geometry
 __global__ __launch_bounds__(256) void window_track_kernel(const float* __restrict__ samples,
                                                            int64_t n_samples, int64_t first_window,
-                                                           float* __restrict__ audio) {
+                                                           float* __restrict__ audio, int win_len, int hop,
+                                                           int lead) {
   const int64_t w = first_window + blockIdx.y;
-  const int64_t start = w * 36164 - 3840;  // index into the un-padded track
-  float* dst = audio + (int64_t)blockIdx.y * kAudioN;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < kAudioN; i += gridDim.x * 256) {
+  const int64_t start = w * hop - lead;  // index into the un-padded track
+  float* dst = audio + (int64_t)blockIdx.y * win_len;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < win_len; i += gridDim.x * 256) {
     const int64_t g = start + i;
     dst[i] = (g >= 0 && g < n_samples) ? samples[g] : 0.0f;
   }
 }
 
 void launch_window_track(const float* samples, int64_t n_samples, int64_t first_window,
-                         int n_windows, float* audio, hipStream_t stream) {
+                         int n_windows, float* audio, int win_len, int hop, int lead, hipStream_t stream) {
   hipLaunchKernelGGL(window_track_kernel, dim3(43, n_windows), dim3(256), 0, stream, samples,
-                     n_samples, first_window, audio);
+                     n_samples, first_window, audio, win_len, hop, lead);
 }
 
 // ---- unwrap_output (inference.py:267-279): keep frames 15..156 of every window, trim to T rows ----

@@ -72,6 +72,7 @@ class Model:
         stage_timing: bool = False,
         exact_f32_mfma: bool = False,
         bf16_weights: bool = False,
+        ext_cqt_44k: bool = False,
     ):
         self.model_type = Model.MODEL_TYPES.MI355X_HIP
         self._lib = _native.load_library()
@@ -85,12 +86,17 @@ class Model:
             flags |= _native.BP_FLAG_F32_MFMA
         if bf16_weights:  # BASELINE.json configs[3]: conv weights rounded to bf16, 2 matrix instructions per product
             flags |= _native.BP_FLAG_BF16_WEIGHTS
+        if ext_cqt_44k:  # BASELINE.json configs[4]: 44.1 kHz windows of 87,688 samples, 10-octave / 345-bin CQT
+            flags |= _native.BP_FLAG_EXT_CQT_44K
         rc = self._lib.bp_create(blob, len(blob), int(device), flags, int(max_windows), C.byref(self._handle))
         if rc != _native.BP_OK:
             self._handle = C.c_void_p()
             _native.check(self._lib, None, rc, f"File {model_path} cannot be loaded into the MI355X backend")
         self.device = int(device)
         self.max_windows = int(max_windows)
+        # window length / sample rate of this handle's geometry (43844 @ 22050 unless ext_cqt_44k)
+        self.audio_n_samples = int(self._lib.bp_handle_window_samples(self._handle))
+        self.sample_rate = int(self._lib.bp_handle_sample_rate(self._handle))
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self) -> None:
@@ -122,8 +128,8 @@ class Model:
         x = np.asarray(x)
         if x.ndim == 3 and x.shape[2] == 1:
             x = x[:, :, 0]
-        if x.ndim != 2 or x.shape[1] != AUDIO_N_SAMPLES:
-            raise ValueError(f"expected input of shape (n, {AUDIO_N_SAMPLES}[, 1]), got {x.shape}")
+        if x.ndim != 2 or x.shape[1] != self.audio_n_samples:
+            raise ValueError(f"expected input of shape (n, {self.audio_n_samples}[, 1]), got {x.shape}")
         x = np.ascontiguousarray(x, dtype=np.float32)
         n = x.shape[0]
         out = {
@@ -149,8 +155,8 @@ class Model:
 
         if x.dim() == 3 and x.shape[2] == 1:
             x = x[:, :, 0]
-        if x.dim() != 2 or x.shape[1] != AUDIO_N_SAMPLES or x.dtype != torch.float32:
-            raise ValueError(f"expected float32 CUDA tensor of shape (n, {AUDIO_N_SAMPLES}[, 1]), got {tuple(x.shape)}")
+        if x.dim() != 2 or x.shape[1] != self.audio_n_samples or x.dtype != torch.float32:
+            raise ValueError(f"expected float32 CUDA tensor of shape (n, {self.audio_n_samples}[, 1]), got {tuple(x.shape)}")
         if x.device.index != self.device:
             raise ValueError(f"input lives on cuda:{x.device.index}, model on cuda:{self.device}")
         x = x.contiguous()
@@ -177,7 +183,7 @@ class Model:
         if samples.ndim != 1:
             raise ValueError("predict_track expects a 1-D mono signal")
         n = samples.shape[0]
-        T = int(self._lib.bp_track_n_frames(n))
+        T = int(self._lib.bp_handle_track_n_frames(self._handle, n))
         out = {
             "note": np.empty((T, N_FREQ_BINS_NOTES), dtype=np.float32),
             "onset": np.empty((T, N_FREQ_BINS_NOTES), dtype=np.float32),
@@ -210,7 +216,7 @@ class Model:
                 raise ValueError("expected 1-D float32 CUDA tensors")
             lens = [int(t.shape[0]) for t in tr]
             outs = [
-                {k: torch.empty((int(self._lib.bp_track_n_frames(L)), w), dtype=torch.float32, device=tr[0].device)
+                {k: torch.empty((int(self._lib.bp_handle_track_n_frames(self._handle, L)), w), dtype=torch.float32, device=tr[0].device)
                  for k, w in (("note", N_FREQ_BINS_NOTES), ("onset", N_FREQ_BINS_NOTES), ("contour", N_FREQ_BINS_CONTOURS))}
                 for L in lens
             ]
@@ -223,7 +229,7 @@ class Model:
                 raise ValueError("predict_tracks expects 1-D mono signals")
             lens = [int(t.shape[0]) for t in tr]
             outs = [
-                {k: np.empty((int(self._lib.bp_track_n_frames(L)), w), dtype=np.float32)
+                {k: np.empty((int(self._lib.bp_handle_track_n_frames(self._handle, L)), w), dtype=np.float32)
                  for k, w in (("note", N_FREQ_BINS_NOTES), ("onset", N_FREQ_BINS_NOTES), ("contour", N_FREQ_BINS_CONTOURS))}
                 for L in lens
             ]
@@ -246,7 +252,7 @@ class Model:
             raise ValueError("expected a 1-D float32 CUDA tensor")
         samples = samples.contiguous()
         n = int(samples.shape[0])
-        T = int(self._lib.bp_track_n_frames(n))
+        T = int(self._lib.bp_handle_track_n_frames(self._handle, n))
         if out is None:
             out = {
                 "note": torch.empty((T, N_FREQ_BINS_NOTES), dtype=torch.float32, device=samples.device),
@@ -274,7 +280,7 @@ class Model:
         """Decoded PCM [n_frames(, channels)] at `sample_rate` -> mono 22.05 kHz float32, computed on the device
         (channel mean + polyphase FIR; the `librosa.load(..., sr=22050, mono=True)` tail of inference.py:239)."""
         pcm = self._as_pcm(pcm)
-        n_out = int(self._lib.bp_resampled_length(pcm.shape[0], int(sample_rate)))
+        n_out = int(self._lib.bp_handle_resampled_length(self._handle, pcm.shape[0], int(sample_rate)))
         out = np.empty((n_out,), dtype=np.float32)
         rc = self._lib.bp_resample(
             self._handle, pcm.ctypes.data, pcm.shape[0], pcm.shape[1], int(sample_rate), out.ctypes.data, _native.BP_MEM_HOST
@@ -286,8 +292,8 @@ class Model:
         """Decoded PCM at any rate / channel count -> un-overlapped posteriorgrams: downmix, resampling, windowing,
         CQT + CNN and un-overlapping all on the device (bp_infer_pcm)."""
         pcm = self._as_pcm(pcm)
-        n22 = int(self._lib.bp_resampled_length(pcm.shape[0], int(sample_rate)))
-        T = int(self._lib.bp_track_n_frames(n22))
+        n22 = int(self._lib.bp_handle_resampled_length(self._handle, pcm.shape[0], int(sample_rate)))
+        T = int(self._lib.bp_handle_track_n_frames(self._handle, n22))
         out = {
             "note": np.empty((T, N_FREQ_BINS_NOTES), dtype=np.float32),
             "onset": np.empty((T, N_FREQ_BINS_NOTES), dtype=np.float32),

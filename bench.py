@@ -204,6 +204,9 @@ def main() -> None:
                     help="windows: BASELINE.json configs[1] (the headline line); tracks: configs[2], whole synthetic "
                     "3-minute tracks through bp_infer_track, file-sharded over the ranks")
     ap.add_argument("--tracks", type=int, default=1000, help="tracks in the whole job (--workload tracks)")
+    ap.add_argument("--ext-cqt-44k", action="store_true",
+                    help="BASELINE.json configs[4]: 44.1 kHz windows (87,688 samples), 10-octave / 345-bin CQT (use with "
+                    "--batch 512); not the headline line")
     ap.add_argument("--bf16-weights", action="store_true",
                     help="BASELINE.json configs[3]: bf16 CNN weights + fp32 CQT (use with --batch 1024); not the headline line")
     args = ap.parse_args()
@@ -235,14 +238,15 @@ def main() -> None:
     dev = torch.device("cuda", local_rank)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
-    audio = (torch.rand((B, 43844), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0).contiguous()
+    win = 87688 if args.ext_cqt_44k else 43844
+    audio = (torch.rand((B, win), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0).contiguous()
     out = {
         "note": torch.empty((B, 172, 88), device=dev),
         "onset": torch.empty((B, 172, 88), device=dev),
         "contour": torch.empty((B, 172, 264), device=dev),
     }
     model = Model(device=local_rank, max_windows=B, stage_timing=True, exact_f32_mfma=args.exact_f32,
-                  bf16_weights=args.bf16_weights)
+                  bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k)
 
     def step():
         model._predict_device(audio, out=out, sync=False)
@@ -314,7 +318,8 @@ def main() -> None:
             c1_key = "contour_branch_kernel"
         achieved = c1_flop * B / (c1_ms * 1e-3) / 1e12
         line = {
-            "metric": "audio windows/sec (2 s @ 22.05 kHz) end-to-end CQT+CNN",
+            "metric": "audio windows/sec (2 s @ 44.1 kHz) end-to-end CQT+CNN" if args.ext_cqt_44k
+            else "audio windows/sec (2 s @ 22.05 kHz) end-to-end CQT+CNN",
             "value": value,
             "unit": "windows/s",
             "n_gpus": world,
@@ -330,7 +335,9 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": f"batch={B} synthetic uniform[-1,1) 2 s @ 22.05 kHz mono windows per GPU, "
-                + ("bf16 CNN weights + fp32 CQT, HBM-resident in/out (BASELINE.json configs[3])" if args.bf16_weights
+                + ("44.1 kHz windows of 87,688 samples, extended 10-octave / 345-bin CQT, HBM-resident in/out "
+                   "(BASELINE.json configs[4])" if args.ext_cqt_44k else
+                   "bf16 CNN weights + fp32 CQT, HBM-resident in/out (BASELINE.json configs[3])" if args.bf16_weights
                    else "fp32, HBM-resident in/out (BASELINE.json configs[1])"),
                 "windows_per_step_per_gpu": B,
                 "sharding": "independent windows per rank, no collective",

@@ -71,6 +71,14 @@ typedef enum bp_mem_kind {
                                  * instructions instead of 3.  Results follow the graph with bf16-rounded weights to
                                  * the usual 1e-4; against the fp32-weight graph the rounding itself costs up to
                                  * ~5e-3.  Ignored with BP_FLAG_F32_MFMA. */
+#define BP_FLAG_EXT_CQT_44K 8u  /* BASELINE.json configs[4]: 44.1 kHz input with an extended CQT range (SURVEY.md App.
+                                 * A.6; NOT a behaviour of the reference, which always resamples to 22.05 kHz): the
+                                 * same 36 kernels and low-pass at sr = 44100, hop 512, 10 octaves, 345 bins; windows
+                                 * are 87,688 samples, track hop 72,328, lead-in 7,680; the CNN and the output shapes
+                                 * are unchanged (bins 309..344 feed the harmonic stack where the 22.05 kHz model has
+                                 * zeros).  Parity is against the re-parametrised restatement (oracle).  Window /
+                                 * track sizes of a handle: bp_handle_window_samples, bp_handle_track_n_*.
+                                 * Not available with BP_FLAG_F32_MFMA. */
 
 /*
  * Weights blob ("BPAMDW01", little endian) — produced by tools/extract_weights.py from the
@@ -147,6 +155,15 @@ int bp_infer_pcm(bp_handle h, const float* pcm, int64_t n_frames, int channels, 
 int64_t bp_track_n_windows(int64_t n_samples);
 /* min(n_windows*142, int(n_samples / 36164 * 142)) rows (inference.py:277-279) */
 int64_t bp_track_n_frames(int64_t n_samples);
+
+/* The same counts for a handle's geometry (identical to the functions above unless BP_FLAG_EXT_CQT_44K), the samples
+ * per window bp_infer expects (43844 / 87688), the sample rate bp_infer_track expects (22050 / 44100) and the length
+ * bp_resample / bp_infer_pcm produce for n_frames at sample_rate. */
+int64_t bp_handle_track_n_windows(bp_handle h, int64_t n_samples);
+int64_t bp_handle_track_n_frames(bp_handle h, int64_t n_samples);
+int64_t bp_handle_window_samples(bp_handle h);
+int bp_handle_sample_rate(bp_handle h);
+int64_t bp_handle_resampled_length(bp_handle h, int64_t n_frames, int sample_rate);
 
 /* Run on an externally owned hipStream_t (e.g. torch's current stream); NULL = library stream. */
 int bp_set_stream(bp_handle h, void* hip_stream);

@@ -80,33 +80,53 @@ def _t(a: np.ndarray, dtype) -> torch.Tensor:
 
 
 # ---- CQT -----------------------------------------------------------------------------------------
-def pyramid(x: torch.Tensor, lowpass: torch.Tensor):
-    """Levels 0..8: level k+1 = 256-tap FIR, stride 2, zero-pad 127 each side (nnaudio.py:269-279)."""
+# ---- extended range for 44.1 kHz input (BASELINE.json configs[4]) --------------------------
+# NOT a behaviour of the reference (it always resamples to 22.05 kHz): nnaudio.CQT2010v2 re-parametrised with
+# sr = 44100, hop = 512, n_bins = 345 -> n_octaves = 10, remainder 21 again; fmin_t / sr is unchanged, so the SAME 36
+# kernels and the same low-pass apply; `lengths` (nnaudio.py:590-593) use sr = 44100; windows are 87,688 samples.
+EXT_AUDIO_N_SAMPLES = 2 * AUDIO_N_SAMPLES
+EXT_N_OCTAVES = N_OCTAVES + 1
+EXT_N_BINS_CQT = N_BINS_CQT + BINS_PER_OCTAVE
+EXT_FFT_HOP = 2 * FFT_HOP
+EXT_SAMPLE_RATE = 2 * AUDIO_SAMPLE_RATE
+
+
+def ext_sqrt_len() -> np.ndarray:
+    """sqrt(ceil(Q * 44100 / f_b)), f_b = 27.5 * 2^(b/36), b < 345 (nnaudio.py:532, 590-593, 649-650)."""
+    q = 1.0 / (2.0 ** (1.0 / BINS_PER_OCTAVE) - 1.0)
+    f = 27.5 * 2.0 ** (np.arange(EXT_N_BINS_CQT) / float(BINS_PER_OCTAVE))
+    return np.sqrt(np.ceil(q * EXT_SAMPLE_RATE / f)).astype(np.float32)
+
+
+def pyramid(x: torch.Tensor, lowpass: torch.Tensor, n_octaves: int = N_OCTAVES):
+    """Levels 0..n_octaves-1: level k+1 = 256-tap FIR, stride 2, zero-pad 127 each side (nnaudio.py:269-279)."""
     levels = [x]
     cur = x[:, None, :]
-    for _ in range(N_OCTAVES - 1):
+    for _ in range(n_octaves - 1):
         cur = F.conv1d(F.pad(cur, (127, 127)), lowpass[None, None, :], stride=2)
         levels.append(cur[:, 0, :])
     return levels
 
 
-def cqt(x: torch.Tensor, W: Dict[str, np.ndarray], dtype=np.float64, return_levels: bool = False):
-    """x (B, 43844) -> magnitude (B, 172, 309)  (nnaudio.py:623-661, 'Magnitude' output)."""
+def cqt(x: torch.Tensor, W: Dict[str, np.ndarray], dtype=np.float64, return_levels: bool = False, ext: bool = False):
+    """x (B, 43844) -> magnitude (B, 172, 309)  (nnaudio.py:623-661, 'Magnitude' output).
+    ext: x (B, 87688) at 44.1 kHz -> (B, 172, 345), the re-parametrisation described above."""
     k_re = _t(W["cqt_kernel_re"], dtype)[:, None, :]
     k_im = _t(W["cqt_kernel_im"], dtype)[:, None, :]
     lowpass = _t(W["cqt_lowpass"], dtype)
-    sqrt_len = _t(W["cqt_sqrt_len"], dtype)
-    levels = pyramid(x, lowpass)
+    sqrt_len = _t(ext_sqrt_len() if ext else W["cqt_sqrt_len"], dtype)
+    n_bins = EXT_N_BINS_CQT if ext else N_BINS_CQT
+    levels = pyramid(x, lowpass, EXT_N_OCTAVES if ext else N_OCTAVES)
     re_oct, im_oct = [], []
-    hop = FFT_HOP
+    hop = EXT_FFT_HOP if ext else FFT_HOP
     for lvl in levels:
         xp = F.pad(lvl[:, None, :], (128, 128), mode="reflect")  # nnaudio.py:229, 300-301
         re_oct.append(F.conv1d(xp, k_re, stride=hop))  # (B, 36, 172)
         im_oct.append(-F.conv1d(xp, k_im, stride=hop))  # nnaudio.py:246
         hop //= 2
     # lower octaves are prepended (nnaudio.py:640) and the bottom 15 bins dropped (642)
-    re = torch.cat(re_oct[::-1], dim=1)[:, -N_BINS_CQT:, :]
-    im = torch.cat(im_oct[::-1], dim=1)[:, -N_BINS_CQT:, :]
+    re = torch.cat(re_oct[::-1], dim=1)[:, -n_bins:, :]
+    im = torch.cat(im_oct[::-1], dim=1)[:, -n_bins:, :]
     re = re * sqrt_len[None, :, None]  # nnaudio.py:650 (scale BEFORE squaring)
     im = im * sqrt_len[None, :, None]
     mag = torch.sqrt(re * re + im * im).permute(0, 2, 1).contiguous()  # nnaudio.py:661
@@ -158,18 +178,20 @@ def cnn(stack: torch.Tensor, W: Dict[str, np.ndarray], dtype=np.float64) -> Dict
 
 
 def forward(
-    audio: np.ndarray, W: Dict[str, np.ndarray] | None = None, dtype=np.float64, intermediates: bool = False
+    audio: np.ndarray, W: Dict[str, np.ndarray] | None = None, dtype=np.float64, intermediates: bool = False,
+    ext: bool = False,
 ) -> Dict[str, np.ndarray]:
-    """audio (B, 43844) or (B, 43844, 1) -> {"note","onset","contour"} (+ intermediates)."""
+    """audio (B, 43844) or (B, 43844, 1) -> {"note","onset","contour"} (+ intermediates).
+    ext: audio (B, 87688) at 44.1 kHz through the extended 345-bin CQT; CNN and output shapes unchanged."""
     if W is None:
         W = load_weights()
     x = np.asarray(audio)
     if x.ndim == 3:
         x = x[:, :, 0]  # nn.py:91-102 FlattenAudioCh
-    assert x.ndim == 2 and x.shape[1] == AUDIO_N_SAMPLES, x.shape
+    assert x.ndim == 2 and x.shape[1] == (EXT_AUDIO_N_SAMPLES if ext else AUDIO_N_SAMPLES), x.shape
     xt = _t(x, dtype)
     with torch.no_grad():
-        mag, levels = cqt(xt, W, dtype, return_levels=True)
+        mag, levels = cqt(xt, W, dtype, return_levels=True, ext=ext)
         norm, lp, mn, mx = normalized_log(mag, W, dtype)
         z = norm * float(W["bn_affine"][0]) + float(W["bn_affine"][1])
         stack = harmonic_stack(z)

@@ -209,6 +209,45 @@ def test_bf16_weights_mode(weights, cases):
         assert cost <= 1e-2, (k, cost)
 
 
+def test_extended_cqt_44k_mode(weights):
+    """BASELINE.json configs[4] (not a reference behaviour): 44.1 kHz windows of 87,688 samples
+    through the 10-octave / 345-bin CQT (BP_FLAG_EXT_CQT_44K), CNN unchanged.  Parity is against the re-parametrised
+    restatement in the oracle: end to end to the usual noise-aware 1e-4, and the track path (hop 72,328, lead-in 7,680)
+    against host windowing of the same samples."""
+    from basic_pitch_amd import Model
+
+    rng = np.random.default_rng(21)
+    x = rng.uniform(-1, 1, (3, O.EXT_AUDIO_N_SAMPLES)).astype(np.float32)
+    t = np.arange(O.EXT_AUDIO_N_SAMPLES) / 44100.0
+    x[2] = (0.4 * np.sin(2 * np.pi * 9000.0 * t) + 0.3 * np.sin(2 * np.pi * 440.0 * t)).astype(np.float32)
+    r64 = O.forward(x, weights, np.float64, ext=True)
+    r32 = O.forward(x, weights, np.float32, ext=True)
+    m = Model(max_windows=8, ext_cqt_44k=True)
+    assert m.audio_n_samples == 87688 and m.sample_rate == 44100
+    got = m.predict(x)
+    _noise_aware(got, r32, r64)
+    for k in ("note", "onset", "contour"):
+        assert np.abs(got[k][:2] - r64[k][:2]).max() <= 1e-4, k
+    with pytest.raises(ValueError):
+        m.predict(np.zeros((1, 43844), np.float32))
+    # whole track at 44.1 kHz: on-device windowing == host windowing + predict + unwrap with the doubled hop
+    n = 72328 * 3 + 1234
+    y = rng.uniform(-0.5, 0.5, n).astype(np.float32)
+    tr = m.predict_track(y)
+    n_win = -(-(n + 7680) // 72328)
+    pad = np.concatenate([np.zeros(7680, np.float32), y, np.zeros(n_win * 72328 + 87688, np.float32)])
+    wins = np.stack([pad[w * 72328 : w * 72328 + 87688] for w in range(n_win)])
+    pw = m.predict(wins)
+    T = int(n / 72328 * 142)
+    for k in tr:
+        ref = pw[k][:, 15:157].reshape(n_win * 142, -1)[:T]
+        assert tr[k].shape == ref.shape and np.array_equal(tr[k], ref), k
+    # 48 kHz stereo PCM is resampled to the handle's 44.1 kHz on the device
+    pcm = rng.uniform(-0.5, 0.5, (48000, 2)).astype(np.float32)
+    assert m.resample(pcm, 48000).shape == (44100,)
+    m.close()
+
+
 def _noise_aware(got, r32, r64, floor=1e-4, factor=4.0):
     """|hip - fp64| <= max(1e-4, 4 * |fp32 oracle - fp64|), per tensor.
 

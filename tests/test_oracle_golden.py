@@ -111,3 +111,21 @@ def test_c_restatement_agrees_with_torch_oracle(weights):
         assert rc[k].shape == r32[k].shape
         assert np.abs(rc[k] - r32[k]).max() <= 5e-5, k
         assert np.abs(rc[k] - r64[k]).max() <= 2 * np.abs(r32[k] - r64[k]).max() + 2e-5, k
+
+
+def test_extended_cqt_restatement_is_consistent(weights):
+    """The 44.1 kHz / 345-bin re-parametrisation (BASELINE.json configs[4]) has no reference
+    fixture; it is pinned to the pinned 22.05 kHz restatement instead: its sqrt(lengths) table continues the model's
+    (bin b + 36 == bin b), and its bins 0..308 are the 22.05 kHz CQT of its own first pyramid level up to that ratio."""
+    import torch
+
+    ext = O.ext_sqrt_len()
+    assert ext.shape == (345,) and np.array_equal(ext[36:], weights["cqt_sqrt_len"])
+    x = np.random.default_rng(4).uniform(-1, 1, (1, O.EXT_AUDIO_N_SAMPLES)).astype(np.float32)
+    r = O.forward(x, weights, np.float64, intermediates=True, ext=True)
+    assert r["mag"].shape == (1, 172, 345) and r["contour"].shape == (1, 172, 264) and len(r["levels"]) == 10
+    assert r["levels"][1].shape[1] == O.AUDIO_N_SAMPLES
+    std = O.cqt(torch.from_numpy(r["levels"][1]), weights, np.float64).numpy()
+    ratio = ext[:309].astype(np.float64) / weights["cqt_sqrt_len"].astype(np.float64)
+    assert np.abs(r["mag"][:, :, :309] - std * ratio).max() <= 1e-12
+    assert r["mag"][:, :, 309:].max() > 0  # the new top octave carries data
