@@ -12,6 +12,8 @@ from typing import Optional
 from . import build as _build
 
 BP_OK = 0
+BP_ERR_INVALID_ARG = -1
+BP_ERR_UNSUPPORTED = -6
 BP_MEM_HOST = 0
 BP_MEM_DEVICE = 1
 BP_FLAG_STAGE_TIMING = 1

@@ -340,6 +340,31 @@ def test_edge_cases():
     m.close()
 
 
+def test_new_entry_points_reject_bad_arguments():
+    """C-ABI error behaviour of the round's new entry points: invalid arguments come back as BP_ERR_INVALID_ARG /
+    BP_ERR_UNSUPPORTED (ValueError / NativeLibraryError on the Python side), never as a crash."""
+    import ctypes as C
+
+    from basic_pitch_amd import Model, _native
+    from basic_pitch_amd._native import NativeLibraryError
+
+    with pytest.raises((ValueError, NativeLibraryError)):
+        Model(exact_f32_mfma=True, ext_cqt_44k=True)  # extended range exists only on the split-precision path
+    m = Model(max_windows=4)
+    lib, h = m._lib, m._handle
+    assert lib.bp_infer_tracks(h, -1, None, None, None, None, None, 0) == _native.BP_ERR_INVALID_ARG
+    assert lib.bp_infer_tracks(h, 2, None, None, None, None, None, 0) == _native.BP_ERR_INVALID_ARG
+    assert lib.bp_infer_tracks(h, 0, None, None, None, None, None, 0) == _native.BP_OK
+    buf = np.zeros(10, np.float32)
+    assert lib.bp_resample(h, buf.ctypes.data, 10, 0, 44100, buf.ctypes.data, 0) == _native.BP_ERR_INVALID_ARG   # channels
+    assert lib.bp_resample(h, buf.ctypes.data, 10, 1, 500, buf.ctypes.data, 0) == _native.BP_ERR_INVALID_ARG     # rate
+    assert lib.bp_resample(h, buf.ctypes.data, 10, 1, 44101, buf.ctypes.data, 0) == _native.BP_ERR_INVALID_ARG   # ratio
+    assert lib.bp_infer_pcm(h, buf.ctypes.data, 10, 1, 44100, None, None, None, 7) == _native.BP_ERR_INVALID_ARG  # mem_kind
+    assert b"ratio" in lib.bp_last_error(h) or b"ingest" in lib.bp_last_error(h)
+    assert m.predict_tracks([np.zeros(0, np.float32)])[0]["note"].shape == (0, 88)
+    m.close()
+
+
 def test_track_path_equals_windowed_path_and_golden(weights, clip_22k):
     """Config 1 of BASELINE.json: the reference's test clip end to end.  The on-device windowing /
     un-overlapping path must equal the reference-structured per-window path bit for bit, and both
