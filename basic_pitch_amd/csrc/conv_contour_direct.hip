@@ -392,12 +392,20 @@ __global__ __launch_bounds__(kF1Threads, 2) void contour_conv1_folded_kernel(Con
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// conv2: a thread owns a strip of 4 adjacent bins and marches down a slab of frames.  Each input row it loads
-// (8 bins x 8 channels = 256 contiguous bytes of the zero-padded c1 row, prefetched one row ahead) feeds the 5
-// output rows it touches: 800 FMAs per 16 sixteen-byte loads, accumulators of the 5 open output rows in
-// registers, weights wave-uniform (scalar loads).  No LDS, no barriers; threads are a flat index over
-// (window, slab, strip), so any batch size fills whole waves.
-constexpr int kD2Strips = kFreqC / 4;  // 66
+// conv2: Conv2D 8->1 5x5 + sigmoid as a march down the frames with ONE OUTPUT BIN PER LANE.
+//   * a wave owns 64 consecutive bins of a flat (window, bin) index (8 windows x 264 bins = 33 waves exactly) and a
+//     slab of frames; every row it loads its own pixel (8 channels = two 16-byte loads at a 32-byte lane stride: two
+//     instructions cover 2 KB contiguous — the 4-bin-strip version before it made every load instruction touch 64
+//     cache lines and stalled at 2.9 TB/s with the memory side alone taking 0.15 ms);
+//   * the 4 neighbours (bins -2 .. +2) come from the other lanes through a per-wave LDS row (two channel-half
+//     planes, consecutive lanes = consecutive 16-byte slots), lanes 0..3 also fetch the 2 + 2 halo pixels; bins
+//     outside [0, 264) are the zero padding of "same" (a lane's neighbour in the next window is masked);
+//   * everything about rows is wave-uniform, so the 200 taps are scalar loads and operands of v_pk_fma_f32 (even /
+//     odd channels in the two halves of a float2); the 5 open output rows live in 5 float2 accumulators;
+//   * the next row's pixel is prefetched before the current row's 100 packed FMAs.
+constexpr int kD2Group = 8;                               // windows per flat index group
+constexpr int kD2Waves = kD2Group * kFreqC / 64;          // 33 waves per (group, slab)
+static_assert(kD2Group * kFreqC % 64 == 0, "a group of windows fills whole waves");
 
 struct Conv2Params {
   const float* c1;   // [n][172][kC1Row][8]
@@ -411,112 +419,116 @@ struct Conv2Params {
 
 using v2f = __attribute__((ext_vector_type(2))) float;
 
-__device__ __forceinline__ void d2_load(const float* __restrict__ src, float4 (&x)[16]) {
-#pragma unroll
-  for (int i = 0; i < 16; ++i) x[i] = reinterpret_cast<const float4*>(src)[i];
-}
+// separate __restrict__ arguments (not a struct): the taps must be provably unclobbered to become scalar loads
+__global__ __launch_bounds__(256) void contour_conv2_kernel(const float* __restrict__ c1_, const float* __restrict__ w2_,
+                                                            float bias_, float* __restrict__ out_, int n_windows_,
+                                                            int slab_rows_, int n_slabs_) {
+  const Conv2Params p{c1_, w2_, bias_, out_, n_windows_, slab_rows_, n_slabs_};
+  __shared__ __attribute__((aligned(16))) float4 xch[4][2][68];  // [wave][channel half][2 halo + 64 lanes + 2 halo]
+  const int lane = threadIdx.x & 63;
+  const int wv = wave_id();
+  const int64_t wg = (int64_t)blockIdx.x * 4 + wv;                 // wave-uniform work item
+  const int n_groups = (p.n_windows + kD2Group - 1) / kD2Group;
+  if (wg >= (int64_t)n_groups * p.n_slabs * kD2Waves) return;      // whole waves only: no barrier below
+  const int seg = (int)(wg % kD2Waves);
+  const int slab = (int)((wg / kD2Waves) % p.n_slabs);
+  const int group = (int)(wg / ((int64_t)kD2Waves * p.n_slabs));
+  const int ta = slab * p.slab_rows;
+  const int tb = ta + p.slab_rows < kFrames ? ta + p.slab_rows : kFrames;
 
-// acc[d][bin] += sum_{dw, c} W2[4 - d][dw][c] * x[bin + dw][c]   for the open output rows d with live[d].
-// Even and odd channels accumulate in the two halves of a float2: weight pairs (scalar registers) and channel pairs
-// (adjacent registers of the 16-byte loads) are both naturally packed -> v_pk_fma_f32 without operand shuffles.
-__device__ __forceinline__ void d2_fma(const float4* __restrict__ w2, const float4 (&x)[16], v2f (&acc)[5][4],
-                                       const bool (&live)[5]) {
+  const int lin = seg * 64 + lane;
+  const int wl = lin / kFreqC;                 // window inside the group
+  const int bin = lin - wl * kFreqC;
+  const int win = group * kD2Group + wl;
+  const bool wvalid = win < p.n_windows;
+  const float* src = p.c1 + (int64_t)(wvalid ? win : 0) * kC1Win + (int64_t)(kC1Pad + bin) * 8;
+  float* dst = p.out + (int64_t)(wvalid ? win : 0) * kPlaneC + bin;
+  // lanes 0..3 also fetch the halo pixels of the wave: lane 0 / 1 -> bins -2 / -1 of lane 0's pixel, lane 2 / 3 ->
+  // bins +1 / +2 of lane 63's pixel (pad columns of c1 are zero, so a halo outside the window reads zeros)
+  const int lin_h = seg * 64 + (lane < 2 ? 0 : 63);
+  const int wl_h = lin_h / kFreqC;
+  const int bin_h = lin_h - wl_h * kFreqC + (lane < 2 ? lane - 2 : lane - 1);
+  const int win_h = group * kD2Group + wl_h;
+  const float* src_h = p.c1 + (int64_t)(win_h < p.n_windows ? win_h : 0) * kC1Win + (int64_t)(kC1Pad + bin_h) * 8;
+  const int slot_h = lane < 2 ? lane : 64 + lane;  // 0, 1, 66, 67
+  // zero padding of "same": a neighbour bin outside [0, 264) contributes nothing (also masks the next window's lane)
+  bool nb_ok[5];
 #pragma unroll
-  for (int d = 0; d < 5; ++d) {
-    if (!live[d]) continue;
-    int wofs = (4 - d) * 10;  // LDS, same address in every lane: broadcast reads; opaque offset so the 50 reads
-    asm volatile("" : "+v"(wofs));  // stay inside the loop instead of being hoisted into 200 registers
-    const float4* wd = w2 + wofs;
+  for (int d = 0; d < 5; ++d) nb_ok[d] = (unsigned)(bin + d - 2) < (unsigned)kFreqC;
+
+  float4 (*xw)[68] = xch[wv];
+  v2f acc[5];  // acc[d] = output row r - 2 + d while input row r is being added
+#pragma unroll
+  for (int d = 0; d < 5; ++d) acc[d] = v2f{0.0f, 0.0f};
+
+  const int r_first = ta - 2 > 0 ? ta - 2 : 0;
+  const int r_last = tb + 1 < kFrames - 1 ? tb + 1 : kFrames - 1;
+  const int64_t rs = (int64_t)kC1Row * 8;
+  float4 own0 = *reinterpret_cast<const float4*>(src + r_first * rs);
+  float4 own1 = *reinterpret_cast<const float4*>(src + r_first * rs + 4);
+  float4 hal0 = own0, hal1 = own1;
+  if (lane < 4) {
+    hal0 = *reinterpret_cast<const float4*>(src_h + r_first * rs);
+    hal1 = *reinterpret_cast<const float4*>(src_h + r_first * rs + 4);
+  }
+  for (int r = r_first; r <= r_last; ++r) {
+    // publish this row's pixels to the wave, fetch the next row's
+    xw[0][2 + lane] = own0;
+    xw[1][2 + lane] = own1;
+    if (lane < 4) {
+      xw[0][slot_h] = hal0;
+      xw[1][slot_h] = hal1;
+    }
+    if (r < r_last) {
+      own0 = *reinterpret_cast<const float4*>(src + (r + 1) * rs);
+      own1 = *reinterpret_cast<const float4*>(src + (r + 1) * rs + 4);
+      if (lane < 4) {
+        hal0 = *reinterpret_cast<const float4*>(src_h + (r + 1) * rs);
+        hal1 = *reinterpret_cast<const float4*>(src_h + (r + 1) * rs + 4);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    v2f x[5][4];  // [dw][channel pair]
 #pragma unroll
     for (int dw = 0; dw < 5; ++dw) {
+      const float4 a = xw[0][lane + dw];
+      const float4 b4 = xw[1][lane + dw];
+      x[dw][0] = nb_ok[dw] ? v2f{a.x, a.y} : v2f{0.0f, 0.0f};
+      x[dw][1] = nb_ok[dw] ? v2f{a.z, a.w} : v2f{0.0f, 0.0f};
+      x[dw][2] = nb_ok[dw] ? v2f{b4.x, b4.y} : v2f{0.0f, 0.0f};
+      x[dw][3] = nb_ok[dw] ? v2f{b4.z, b4.w} : v2f{0.0f, 0.0f};
+    }
+    __builtin_amdgcn_wave_barrier();  // every lane has read the row before the next one overwrites it
+    // one open row after the other (the 5 accumulators side by side was measured slower: 0.130 vs 0.115 ms — the tap
+    // stream, not the dependent chain, sets the pace)
 #pragma unroll
-      for (int c4 = 0; c4 < 2; ++c4) {
-        const float4 wv = wd[dw * 2 + c4];
-        const v2f wa = {wv.x, wv.y};
-        const v2f wb = {wv.z, wv.w};
+    for (int d = 0; d < 5; ++d) {
+      const int t = r - 2 + d;
+      if (t < ta || t >= tb) continue;  // wave-uniform
+      const float* __restrict__ wd = w2_ + (4 - d) * 40;
 #pragma unroll
-        for (int bin = 0; bin < 4; ++bin) {
-          const float4 xv = x[(bin + dw) * 2 + c4];
-          acc[d][bin] = __builtin_elementwise_fma(wa, v2f{xv.x, xv.y}, acc[d][bin]);
-          acc[d][bin] = __builtin_elementwise_fma(wb, v2f{xv.z, xv.w}, acc[d][bin]);
+      for (int dw = 0; dw < 5; ++dw) {
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) {
+          const v2f wv2 = {wd[dw * 8 + 2 * c2], wd[dw * 8 + 2 * c2 + 1]};
+          acc[d] = __builtin_elementwise_fma(wv2, x[dw][c2], acc[d]);
         }
       }
     }
-  }
-}
-
-__device__ __forceinline__ void d2_emit(float* __restrict__ dst, const v2f (&a)[4], float bias) {
-  float4 o;
-  o.x = sigmoidf_exact((a[0].x + a[0].y) + bias);
-  o.y = sigmoidf_exact((a[1].x + a[1].y) + bias);
-  o.z = sigmoidf_exact((a[2].x + a[2].y) + bias);
-  o.w = sigmoidf_exact((a[3].x + a[3].y) + bias);
-  *reinterpret_cast<float4*>(dst) = o;
-}
-
-__device__ __forceinline__ void d2_shift(v2f (&acc)[5][4]) {
+    const int t_out = r - 2;
+    if (t_out >= ta && t_out < tb && wvalid) dst[(int64_t)t_out * kFreqC] = sigmoidf_exact((acc[0].x + acc[0].y) + p.bias);
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[d][i] = acc[d + 1][i];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc[4][i] = v2f{0.0f, 0.0f};
-}
-
-__global__ __launch_bounds__(256) void contour_conv2_kernel(Conv2Params p) {
-  // the 200 taps live in LDS: their reads count on lgkmcnt, so they never wait for the row prefetch (vmcnt)
-  __shared__ __attribute__((aligned(16))) float4 w2s[50];
-  if (threadIdx.x < 50) w2s[threadIdx.x] = reinterpret_cast<const float4*>(p.w2)[threadIdx.x];
-  __syncthreads();
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t total = (int64_t)p.n_windows * p.n_slabs * kD2Strips;
-  if (gid >= total) return;
-  const int strip = (int)(gid % kD2Strips);
-  const int slab = (int)((gid / kD2Strips) % p.n_slabs);
-  const int64_t b = gid / (kD2Strips * p.n_slabs);
-  const int ta = slab * p.slab_rows;
-  const int tb = ta + p.slab_rows < kFrames ? ta + p.slab_rows : kFrames;
-  const float* src = p.c1 + b * kC1Win + (int64_t)(4 * strip) * 8;  // padded bin 4 s = stack bin 4 s - 2
-  float* dst = p.out + b * kPlaneC + 4 * strip;
-
-  v2f acc[5][4];  // acc[d] = output row r - 2 + d while input row r is being added
-#pragma unroll
-  for (int d = 0; d < 5; ++d)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[d][i] = v2f{0.0f, 0.0f};
-
-  // rows outside the window are zero: the march covers input rows r_first .. r_last only
-  const int r_first = ta - 2 > 0 ? ta - 2 : 0;
-  const int r_last = tb + 1 < kFrames - 1 ? tb + 1 : kFrames - 1;
-  float4 xa[16], xb[16];
-  d2_load(src + (int64_t)r_first * kC1Row * 8, xa);
-  for (int r = r_first; r <= r_last; r += 2) {
-    // ---- row r from xa (row r + 1 prefetched into xb)
-    if (r + 1 <= r_last) d2_load(src + (int64_t)(r + 1) * kC1Row * 8, xb);
-    {
-      bool live[5];
-#pragma unroll
-      for (int d = 0; d < 5; ++d) live[d] = (r - 2 + d) >= ta && (r - 2 + d) < tb;
-      d2_fma(w2s, xa, acc, live);
-      if (live[0]) d2_emit(dst + (int64_t)(r - 2) * kFreqC, acc[0], p.bias);
-      d2_shift(acc);
-    }
-    if (r + 1 > r_last) break;
-    // ---- row r + 1 from xb (row r + 2 prefetched into xa)
-    if (r + 2 <= r_last) d2_load(src + (int64_t)(r + 2) * kC1Row * 8, xa);
-    {
-      bool live[5];
-#pragma unroll
-      for (int d = 0; d < 5; ++d) live[d] = (r - 1 + d) >= ta && (r - 1 + d) < tb;
-      d2_fma(w2s, xb, acc, live);
-      if (live[0]) d2_emit(dst + (int64_t)(r - 1) * kFreqC, acc[0], p.bias);
-      d2_shift(acc);
-    }
+    for (int d = 0; d < 4; ++d) acc[d] = acc[d + 1];
+    acc[4] = v2f{0.0f, 0.0f};
   }
   // output rows whose last input rows lie below the window (zero rows): flush what is still open
   for (int t = r_last - 1; t < tb; ++t) {
-    if (t >= ta) d2_emit(dst + (int64_t)t * kFreqC, acc[0], p.bias);
-    d2_shift(acc);
+    if (t >= ta && wvalid) dst[(int64_t)t * kFreqC] = sigmoidf_exact((acc[0].x + acc[0].y) + p.bias);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) acc[d] = acc[d + 1];
+    acc[4] = v2f{0.0f, 0.0f};
   }
 }
 
@@ -571,21 +583,21 @@ void launch_contour_conv1_folded(const uint32_t* zp, const void* wfold, const fl
 
 void launch_contour_conv2(const float* c1, const float* w2, float bias, float* contour, int n_windows, int n_cu,
                           hipStream_t stream) {
-  // Every wave of a launch should be resident at once (2 waves per SIMD at ~220 VGPRs): a second, partially filled
-  // round of waves doubles a launch's duration.  So: sub-batches of at most `per_launch` windows, each cut into as
-  // many frame slabs as fill the chip (>= 7 slabs keeps the 4-row halo re-read under 16 %).
-  const int64_t slots = (int64_t)n_cu * 4 * 2 * 64;  // resident threads
-  int per_launch = (int)(slots / (7 * kD2Strips));
-  per_launch = per_launch < 1 ? 1 : per_launch;
+  // <= 96 VGPRs: 5 waves per SIMD resident.  Sub-batches of 256 windows, each cut into as many frame slabs as keep one
+  // launch within the resident waves (4 slabs = 9 % halo re-read at 256 windows on 256 CUs).
+  const int64_t slots = (int64_t)n_cu * 4 * 5;  // resident waves (<= 96 VGPRs)
+  const int per_launch = 256;
   for (int w0 = 0; w0 < n_windows; w0 += per_launch) {
     const int n = n_windows - w0 < per_launch ? n_windows - w0 : per_launch;
-    int n_slabs = (int)(slots / ((int64_t)n * kD2Strips));
+    const int n_groups = (n + kD2Group - 1) / kD2Group;
+    int n_slabs = (int)(slots / ((int64_t)n_groups * kD2Waves));
     n_slabs = n_slabs < 1 ? 1 : (n_slabs > 16 ? 16 : n_slabs);
     const int slab_rows = (kFrames + n_slabs - 1) / n_slabs;
     n_slabs = (kFrames + slab_rows - 1) / slab_rows;
     Conv2Params p{c1 + (int64_t)w0 * kC1Win, w2, bias, contour + (int64_t)w0 * kPlaneC, n, slab_rows, n_slabs};
-    const int64_t total = (int64_t)n * n_slabs * kD2Strips;
-    hipLaunchKernelGGL(contour_conv2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+    const int64_t waves = (int64_t)n_groups * n_slabs * kD2Waves;
+    hipLaunchKernelGGL(contour_conv2_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, p.c1, p.w2, p.bias,
+                       p.out, p.n_windows, p.slab_rows, p.n_slabs);
   }
 }
 
