@@ -65,34 +65,30 @@ constexpr int kDmPos = 2 * kDmOutPerWg + 256;         // 4352 staged input posit
 constexpr int kDmUnits = (kDmPos / 32) * 6;           // 16-byte units, 32-sample rows skewed to 6 units
 constexpr int kDmSteps = 9;                           // 288 k-slots (286 used)
 
-__global__ __launch_bounds__(kDmThreads) void decimate2_mfma_kernel(const float* __restrict__ src,
-                                                                    int64_t src_stride, int len_in,
-                                                                    float* __restrict__ dst,
-                                                                    int64_t dst_stride, int len_out,
-                                                                    const uint4* __restrict__ hfrag) {
-  __shared__ __attribute__((aligned(16))) uint4 s_hi[kDmUnits];
-  __shared__ __attribute__((aligned(16))) uint4 s_lo[kDmUnits];
+// one workgroup's share of a level: outputs o0 .. o0 + kDmOutPerWg of window row x -> y
+// (x may point into LDS: the tail kernel keeps the deep levels there; y_lds, if not null, receives a copy of y)
+__device__ __forceinline__ void dm_block(const float* x, int len_in, float* __restrict__ y, int len_out, int o0,
+                                         const uint4 (&hh)[kDmSteps], const uint4 (&hl)[kDmSteps],
+                                         uint4* __restrict__ s_hi, uint4* __restrict__ s_lo, float* y_lds = nullptr) {
   const int lane = threadIdx.x & 63;
   const int wave = wave_id();
-  const int b = blockIdx.y;
-  const int o0 = blockIdx.x * kDmOutPerWg;
-  const float* x = src + (int64_t)b * src_stride;
   const int in0 = 2 * o0 - 127;  // xp[p] = xz[in0 + p]
-
-  uint4 hh[kDmSteps], hl[kDmSteps];
-#pragma unroll
-  for (int s = 0; s < kDmSteps; ++s) {
-    hh[s] = hfrag[s * 64 + lane];
-    hl[s] = hfrag[(kDmSteps + s) * 64 + lane];
-  }
-
   for (int q = threadIdx.x; q < kDmPos / 8; q += kDmThreads) {
     float v[8];
+    const int g0 = in0 + 8 * q;
+    if (g0 >= 0 && g0 + 8 <= len_in) {
+      // interior: two 16-byte loads (dword aligned is enough for global / LDS vector loads) instead of eight 4-byte
+      // ones at a 32-byte lane stride
+      const float4 a = *reinterpret_cast<const float4*>(x + g0);
+      const float4 c = *reinterpret_cast<const float4*>(x + g0 + 4);
+      v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = c.x, v[5] = c.y, v[6] = c.z, v[7] = c.w;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int g = in0 + 8 * q + e;
-      const bool ok = g >= 0 && g < len_in;
-      v[e] = ok ? x[ok ? g : 0] : 0.0f;
+      for (int e = 0; e < 8; ++e) {
+        const int g = g0 + e;
+        const bool ok = g >= 0 && g < len_in;
+        v[e] = ok ? x[ok ? g : 0] : 0.0f;
+      }
     }
     uint4 hi, lo;
     split8(v, hi, lo);
@@ -103,7 +99,6 @@ __global__ __launch_bounds__(kDmThreads) void decimate2_mfma_kernel(const float*
   __syncthreads();
 
   const int m = lane & 15, kg = lane >> 4;
-  float* y = dst + (int64_t)b * dst_stride;
   for (int tile = wave; tile < kDmTiles; tile += kDmThreads / 64) {
     const int mb = tile * 16;
     if (o0 + 16 * mb >= len_out) break;
@@ -121,8 +116,68 @@ __global__ __launch_bounds__(kDmThreads) void decimate2_mfma_kernel(const float*
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = o0 + 16 * (mb + 4 * kg + r) + m;
-      if (n < len_out) y[n] = (a_hh[r] + (a_lh[r] + a_hl[r]) * kLoUnscale) * kDmTapUnscale;
+      if (n < len_out) {
+        const float v = (a_hh[r] + (a_lh[r] + a_hl[r]) * kLoUnscale) * kDmTapUnscale;
+        y[n] = v;
+        if (y_lds) y_lds[n] = v;
+      }
     }
+  }
+}
+
+__global__ __launch_bounds__(kDmThreads) void decimate2_mfma_kernel(const float* __restrict__ src,
+                                                                    int64_t src_stride, int len_in,
+                                                                    float* __restrict__ dst,
+                                                                    int64_t dst_stride, int len_out,
+                                                                    const uint4* __restrict__ hfrag) {
+  __shared__ __attribute__((aligned(16))) uint4 s_hi[kDmUnits];
+  __shared__ __attribute__((aligned(16))) uint4 s_lo[kDmUnits];
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.y;
+  uint4 hh[kDmSteps], hl[kDmSteps];
+#pragma unroll
+  for (int s = 0; s < kDmSteps; ++s) {
+    hh[s] = hfrag[s * 64 + lane];
+    hl[s] = hfrag[(kDmSteps + s) * 64 + lane];
+  }
+  dm_block(src + (int64_t)b * src_stride, len_in, dst + (int64_t)b * dst_stride, len_out, blockIdx.x * kDmOutPerWg, hh,
+           hl, s_hi, s_lo);
+}
+
+// The deep levels (<= 2740 samples per window) are one or two blocks each: as separate launches every level pays ~12 us
+// of dispatch, load latency and ramp.  Here ONE workgroup per window runs levels `first` .. `last` back to back with the
+// same block routine; every level is written to HBM as usual AND kept in LDS, from where the next level is staged (a
+// round trip through HBM between levels costs as much as the separate launches did).
+constexpr int kDmTailMax = 2 * kDmOutPerWg;  // longest level the tail takes (samples)
+struct DmTail {
+  int first, last;
+  int len[10];
+  int off[10];
+};
+
+__global__ __launch_bounds__(kDmThreads) void decimate2_tail_kernel(float* __restrict__ pyr, int64_t pyr_stride,
+                                                                    const uint4* __restrict__ hfrag, DmTail t) {
+  __shared__ __attribute__((aligned(16))) uint4 s_hi[kDmUnits];
+  __shared__ __attribute__((aligned(16))) uint4 s_lo[kDmUnits];
+  __shared__ float sig[2][kDmTailMax];
+  const int lane = threadIdx.x & 63;
+  uint4 hh[kDmSteps], hl[kDmSteps];
+#pragma unroll
+  for (int s = 0; s < kDmSteps; ++s) {
+    hh[s] = hfrag[s * 64 + lane];
+    hl[s] = hfrag[(kDmSteps + s) * 64 + lane];
+  }
+  float* pw = pyr + (int64_t)blockIdx.x * pyr_stride;
+  const float* x = pw + t.off[t.first - 1];  // the first level still comes from HBM
+  int cur = 0;
+  for (int k = t.first; k <= t.last; ++k) {
+    const int len_in = t.len[k - 1], len_out = t.len[k];
+    for (int o0 = 0; o0 < len_out; o0 += kDmOutPerWg) {
+      dm_block(x, len_in, pw + t.off[k], len_out, o0, hh, hl, s_hi, s_lo, sig[cur]);
+      __syncthreads();  // the block's MFMAs are done with s_hi / s_lo, its outputs are in sig[cur]
+    }
+    x = sig[cur];
+    cur ^= 1;
   }
 }
 
@@ -167,8 +222,15 @@ __device__ __forceinline__ void fm_stage(const float* __restrict__ x, int L, int
     constexpr int NBLK = (15 * HOP + 256) / 8;
     for (int q = threadIdx.x; q < NBLK; q += kFmThreads) {
       float v[8];
+      const int g0 = t0 * HOP + 8 * q - 128;
+      if (g0 >= 0 && g0 + 8 <= L) {  // interior (no reflection): two 16-byte loads instead of eight 4-byte ones
+        const float4 a = *reinterpret_cast<const float4*>(x + g0);
+        const float4 c = *reinterpret_cast<const float4*>(x + g0 + 4);
+        v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = c.x, v[5] = c.y, v[6] = c.z, v[7] = c.w;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = sample(8 * q + e);
+        for (int e = 0; e < 8; ++e) v[e] = sample(8 * q + e);
+      }
       uint4 hi, lo;
       split8(v, hi, lo);
       const int unit = (HOP >= 32) ? q + 2 * ((8 * q) / HOP) : q;
@@ -393,13 +455,27 @@ FmGeo make_fm_geo(bool ext) {
 void launch_pyramid_mfma(const float* audio, float* pyr, const void* hfrag, int n_windows, bool ext,
                          hipStream_t stream) {
   const FmGeo g = make_fm_geo(ext);
-  for (int k = 1; k < g.n_levels; ++k) {
+  // levels whose input already lives in the pyramid row and that are at most two blocks long go to the tail kernel
+  int first_tail = g.n_levels;
+  for (int k = g.n_levels - 1; k >= 2 && g.len[k] <= kDmTailMax; --k) first_tail = k;
+  for (int k = 1; k < first_tail; ++k) {
     const float* src = (k == 1) ? audio : pyr + g.off[k - 1];
     const int64_t sstride = (k == 1) ? g.audio_stride : g.pyr_stride;
     const int lin = g.len[k - 1], lout = g.len[k];
     dim3 grid((lout + kDmOutPerWg - 1) / kDmOutPerWg, n_windows);
     hipLaunchKernelGGL(decimate2_mfma_kernel, grid, dim3(kDmThreads), 0, stream, src, sstride, lin,
                        pyr + g.off[k], g.pyr_stride, lout, static_cast<const uint4*>(hfrag));
+  }
+  if (first_tail < g.n_levels) {
+    DmTail t{};
+    t.first = first_tail;
+    t.last = g.n_levels - 1;
+    for (int k = 0; k < g.n_levels; ++k) {
+      t.len[k] = g.len[k];
+      t.off[k] = g.off[k];
+    }
+    hipLaunchKernelGGL(decimate2_tail_kernel, dim3(n_windows), dim3(kDmThreads), 0, stream, pyr, g.pyr_stride,
+                       static_cast<const uint4*>(hfrag), t);
   }
 }
 
