@@ -102,8 +102,9 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 // Tasks (row, slot) are dealt round-robin to the 256 threads; a thread first ISSUES the loads of all its tasks
 // (NT x 8 in flight), then splits / packs and writes them: the global-load latency is paid once per call, not once
 // per task.  Slots that are zero for every row (onset: the two padding bins of "same") are written by init_rows.
-// note branch: the staging of NROWS contour rows as two halves, so that the loads can be issued a whole phase before
-// the LDS writes (their latency then hides behind the phase's tiles)
+// note branch: the staging of NROWS contour rows as two halves (issue all loads, then split and write).  Issuing them a
+// phase (or a barrier) ahead was measured twice: with loads pending the compiler / hardware wait for them at the top of
+// every tile or at the barrier anyway, so the two halves run back to back
 template <int NROWS>
 struct NoteStage {
   static constexpr int NT = (NROWS * kFreqN + kBrThreads - 1) / kBrThreads;
@@ -279,11 +280,6 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
     for (int ph = 0; ph < n_phase; ++ph) {
       const int r0 = T0 - PH2 + kBrRows * ph;  // first conv1 row of this phase
       BR_STAMP(0);
-      // note branch: the next phase's contour rows are requested now and written to LDS after this phase's tiles
-      // (the barriers in between are lds_barrier: they do not wait for these loads)
-      NoteStage<kBrRows> early;
-      if constexpr (!Br::kOnset)
-        if (ph + 1 < n_phase) note_stage_issue<Br, kBrRows>(p, b, r0 + kBrRows + PH1, threadIdx.x, early);
 
       // ---- conv1 + projection, 12 tiles: 4 rows x 3 overlapping 32-pixel tiles (30 inner pixels each)
 #pragma unroll 1
@@ -312,11 +308,13 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
             for (int it = 0; it < kQIter; ++it) {
               const int idx = lane + 64 * it;
               const int dtq = idx / 30;
-              const int wq = wbase + 1 + idx - 30 * dtq;
-              const bool ok = idx < 30 * KH2 && wq < kFreqN;
-              nv[it][0] = (ok && wq > 0) ? note_row[wq - 1] : 0.0f;
-              nv[it][1] = ok ? note_row[wq] : 0.0f;
-              nv[it][2] = (ok && wq + 1 < kFreqN) ? note_row[wq + 1] : 0.0f;
+              int wq = wbase + 1 + idx - 30 * dtq;
+              wq = wq < 0 ? 0 : (wq > kFreqN - 1 ? kFreqN - 1 : wq);
+              // unconditional loads from clamped addresses: a select right behind a load would make this side wait for
+              // the data (measured: 1 k cycles per tile); the masks are applied where the values are used
+              nv[it][0] = note_row[wq > 0 ? wq - 1 : 0];
+              nv[it][1] = note_row[wq];
+              nv[it][2] = note_row[wq + 1 < kFreqN ? wq + 1 : kFreqN - 1];
             }
           }
 
@@ -403,7 +401,9 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
               float q = (sp[-1] + sp[kScrStride]) + sp[2 * kScrStride + 1];
               if (wq < kFreqN) {
                 if constexpr (Br::kOnset) {
-                  q += (nv[it][0] * extra[dt * 3] + nv[it][1] * extra[dt * 3 + 1]) + nv[it][2] * extra[dt * 3 + 2];
+                  const float nl = wq > 0 ? nv[it][0] : 0.0f;
+                  const float nr = wq + 1 < kFreqN ? nv[it][2] : 0.0f;
+                  q += (nl * extra[dt * 3] + nv[it][1] * extra[dt * 3 + 1]) + nr * extra[dt * 3 + 2];
                 }
                 qrow[dt * kFreqN + wq] = q;
               }
@@ -441,12 +441,7 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
         }
       }
       BR_STAMP(3);
-      if (ph + 1 < n_phase) {
-        if constexpr (Br::kOnset)
-          stage_block<Br, kBrRows>(p, b, r0 + kBrRows + PH1, img_hi, img_lo, threadIdx.x);
-        else
-          note_stage_commit<kBrRows>(early, img_hi, img_lo);
-      }
+      if (ph + 1 < n_phase) stage_block<Br, kBrRows>(p, b, r0 + kBrRows + PH1, img_hi, img_lo, threadIdx.x);
       BR_STAMP(4);
       lds_barrier();
       BR_STAMP(5);
