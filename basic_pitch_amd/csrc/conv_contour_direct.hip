@@ -152,7 +152,7 @@ __global__ __launch_bounds__(Geo::kWaves * 64, Geo::kWaves / 4) void contour_con
     float* c1b = p.c1 + (int64_t)b * kC1Win;
     const int nb = Geo::n_bins();
 
-    __syncthreads();  // the previous item is done with the ring
+    lds_barrier();  // the previous item is done with the ring
     // image rows t0 - 1 .. staged_hi of round 0
     int staged_hi = t0 + (kRound - 1) / kGroups + 1;
     staged_hi = staged_hi < t1 ? staged_hi : t1;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(Geo::kWaves * 64, Geo::kWaves / 4) void contour_con
       img[idx] = vh;
       img[idx + kLoOff] = vl;
     }
-    __syncthreads();
+    lds_barrier();
 
     for (int k = 0; k < nrounds; ++k) {
       // ---- image rows to bring in during this round: (staged_hi, need_hi]
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(Geo::kWaves * 64, Geo::kWaves / 4) void contour_con
       }
       staged_hi += n_new;
       if (pvalid) d1_store(c1b + ((int64_t)prow * kC1Row + kC1Pad + 4 * pgrp) * 8 + 4 * kh, hh, xx, bias4);
-      __syncthreads();  // the round's reads are done; the rows written for the next round are visible
+      lds_barrier();  // the round's reads are done; the rows written for the next round are visible
     }
   }
 }
@@ -322,14 +322,14 @@ __global__ __launch_bounds__(kF1Threads, 2) void contour_conv1_folded_kernel(Con
     const uint32_t* zwin = p.zp + (int64_t)b * kZWin;  // padded window: frame -1 is row 0, bin -56 is word 0
     float* c1b = p.c1 + (int64_t)b * kC1Win;
 
-    __syncthreads();
+    lds_barrier();
     int staged_hi = t0 + (kF1Round - 1) / kF1Groups + 1;
     staged_hi = staged_hi < t1 ? staged_hi : t1;
     for (int e = tid; e < (staged_hi - t0 + 2) * kTasksRow; e += kF1Threads) {
       const int ri = e / kTasksRow;
       stage_row_task(zwin, t0 - 1 + ri, e - ri * kTasksRow);
     }
-    __syncthreads();
+    lds_barrier();
 
     for (int k = 0; k < nrounds; ++k) {
       int need_hi = t0 + (kF1Round * (k + 1) + kF1Round - 1) / kF1Groups + 1;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kF1Threads, 2) void contour_conv1_folded_kernel(Con
       }
       staged_hi += n_new;
       if (pvalid) d1_store(c1b + ((int64_t)prow * kC1Row + kC1Pad + 4 * pgrp) * 8 + 4 * kh, hh, xx, bias4);
-      __syncthreads();
+      lds_barrier();
     }
   }
 }

@@ -96,7 +96,7 @@ __device__ __forceinline__ void dm_block(const float* x, int len_in, float* __re
     s_hi[unit] = hi;
     s_lo[unit] = lo;
   }
-  __syncthreads();
+  lds_barrier();
 
   const int m = lane & 15, kg = lane >> 4;
   for (int tile = wave; tile < kDmTiles; tile += kDmThreads / 64) {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kDmThreads) void decimate2_tail_kernel(float* __res
     const int len_in = t.len[k - 1], len_out = t.len[k];
     for (int o0 = 0; o0 < len_out; o0 += kDmOutPerWg) {
       dm_block(x, len_in, pw + t.off[k], len_out, o0, hh, hl, s_hi, s_lo, sig[cur]);
-      __syncthreads();  // the block's MFMAs are done with s_hi / s_lo, its outputs are in sig[cur]
+      lds_barrier();  // the block's MFMAs are done with s_hi / s_lo, its outputs are in sig[cur]
     }
     x = sig[cur];
     cur ^= 1;
@@ -311,16 +311,16 @@ __device__ __forceinline__ void fm_item(const float* __restrict__ x, int L, int 
   // out of the persistent loop costs > 100 VGPRs)
   asm volatile("" : "+v"(lane));
 
-  __syncthreads();  // previous item's epilogue is done with exch, its MFMAs with s_hi / s_lo
+  lds_barrier();  // previous item's epilogue is done with exch, its MFMAs with s_hi / s_lo
   fm_stage<HOP>(x, L, t0, s_hi, s_lo);
-  __syncthreads();
+  lds_barrier();
   switch (role) {
     case 0: fm_role_compute<0, HOP>(s_hi, s_lo, bh, bl, exch, lane); break;
     case 1: fm_role_compute<1, HOP>(s_hi, s_lo, bh, bl, exch, lane); break;
     case 2: fm_role_compute<2, HOP>(s_hi, s_lo, bh, bl, exch, lane); break;
     default: fm_role_compute<3, HOP>(s_hi, s_lo, bh, bl, exch, lane); break;
   }
-  __syncthreads();
+  lds_barrier();
 
   // epilogue: 16 frames x 36 filters -> * sqrt(len), magnitude, log-power, tile extrema
   float vmin = __int_as_float(0x7f800000), vmax = -__int_as_float(0x7f800000);
