@@ -451,7 +451,7 @@ void pack_note1(const Tensor* w, std::vector<float>& out) {
 
 // Fused branch A fragments (conv_branch.hip): [A1 hi: KS1*64][A1 lo: KS1*64][A2 hi: 2*64][A2 lo: 2*64] x 8 f16.
 // A1 lane (i = out channel = lane & 31, h = lane >> 5), element e: conv1 weight of k = 8h + e of step s.
-// A2 lane (i = conv2 tap, h), element e of step s2: conv2 weight of the channel that C-register
+// A2 lane (i = projection row, h), element e of step s2: conv2 weight of the channel that C-register
 // 8*s2 + e of half h holds: (e & 3) + 16*s2 + 8*(e >> 2) + 4h.
 void pack_branch(int ks1, const Tensor* w1, const Tensor* w2, bool onset, std::vector<uint16_t>& out) {
   const size_t a1h = 0, a1l = (size_t)ks1 * 64 * 8, a2h = 2 * a1l, a2l = a2h + 2 * 64 * 8;
@@ -471,14 +471,19 @@ void pack_branch(int ks1, const Tensor* w1, const Tensor* w2, bool onset, std::v
         }
         put_split(out, a1h, a1l, ((size_t)s * 64 + lane) * 8 + e, v, 2048.0f);
       }
+  // A2 row rho is C row rho of the projection: register r = (rho & 3) + 4 (rho >> 3) of lane half (rho >> 2) & 1.
+  // Half 0 takes frame taps 0 .. DT0-1, half 1 the rest, three dw taps in consecutive registers: the kernel's
+  // horizontal sum is then two lane shifts (conv_branch.hip, NoteBr::DT0 / OnsetBr::DT0).
+  const int dt0 = onset ? 2 : 4;
   for (int s2 = 0; s2 < 2; ++s2)
     for (int lane = 0; lane < 64; ++lane)
       for (int e = 0; e < 8; ++e) {
-        const int tap = lane & 31, hh = lane >> 5;
+        const int rho = lane & 31, hh = lane >> 5;
         const int ch = (e & 3) + 16 * s2 + 8 * (e >> 2) + 4 * hh;
+        const int r = (rho & 3) + 4 * (rho >> 3), half = (rho >> 2) & 1;
+        const int dt = dt0 * half + r / 3, dw = r % 3;
         float v = 0.f;
-        if (tap < kh2 * 3) {
-          const int dt = tap / 3, dw = tap % 3;
+        if (r < 3 * dt0 && dt < kh2) {
           v = onset ? w2->data[((1 + ch) * 3 + dt) * 3 + dw]   // channel 0 of the concat is the note map
                     : w2->data[(ch * 7 + dt) * 3 + dw];
         }

@@ -23,8 +23,9 @@
 //          P[tap (rows)][pixel] = W2[tap][channel] x relu(C1)[channel][pixel]          (K = 32 channels)
 //      with no data movement at all.
 //   3. conv2's spatial part is then only a shifted sum of P: per pixel KH2*3 adds instead of
-//      32*KH2*3 FMAs.  P goes through a per-wave LDS scratch; Q[row][dt][w] = sum_dw P[row][w+dw-1][dt,dw]
-//      is kept in a ring of rows, and out[t][w] = sigmoid(b + sum_dt Q[t+dt-PH2][dt][w]).
+//      32*KH2*3 FMAs.  The packed conv2 weights order the taps so that a lane holds the three dw projections of
+//      its pixel; Q[row][dt][w] = sum_dw P[row][w+dw-1][dt,dw] is two whole-wave DPP lane shifts in registers,
+//      kept in a ring of rows, and out[t][w] = sigmoid(b + sum_dt Q[t+dt-PH2][dt][w]).
 //   4. A workgroup walks a time chunk of one window 4 conv1-rows at a time with ring buffers for the
 //      image and for Q: no halo recompute inside a chunk (two chunks per window -> 512 work items at
 //      B = 256; 2 workgroups per CU overlap one's staging with the other's MFMAs).
@@ -46,7 +47,6 @@ constexpr int kBrRows = 4;                               // conv1 rows per phase
 constexpr int kBrChunks = 2;                             // time chunks per window
 constexpr int kBrChunkFrames = kFrames / kBrChunks;      // 86
 constexpr int kBrTilesPerRow = 3;                        // 32-pixel tiles, 30 inner pixels each
-constexpr int kScrStride = 33;
 static_assert(kFrames % kBrChunks == 0, "chunks tile the window");
 static_assert(kBrTilesPerRow * 30 >= kFreqN, "tiles cover a row");
 
@@ -67,11 +67,11 @@ struct NoteBr {
   static constexpr int PH1 = 3;             // conv1 frame padding (ONNX pads [3,2,3,2])
   static constexpr int ND = 8;              // frame offsets touched (dt = 7 is a zero-weight dummy)
   static constexpr int KH2 = 7, PH2 = 3;    // conv2 frames
-  static constexpr int NT2 = KH2 * 3;       // conv2 taps
   static constexpr int SLOTS = kFreqN;      // slot (row, w) = contour bins 3w-2 .. 3w+5
   static constexpr int RING = kBrRows + 2 * PH1;
   static constexpr int QRING = kBrRows + 2 * PH2;
   static constexpr int PIECE = 4;           // rows per staging call (2 tasks of 8 loads per thread)
+  static constexpr int DT0 = 4;             // conv2 frame taps whose projections land in lane half 0 (the rest: half 1)
   static __device__ constexpr int d_of(int s, int h) { return 2 * s + h; }
   static __device__ constexpr int x_of(int, int) { return 0; }
   static __device__ __forceinline__ int lane_slot(int wc) { return wc; }
@@ -83,11 +83,11 @@ struct OnsetBr {
   static constexpr int PH1 = 2;             // ONNX pads [2,1,2,1]
   static constexpr int ND = 6;              // tap 25 (dt = 5, dw = 0) is a zero-weight dummy
   static constexpr int KH2 = 3, PH2 = 1;
-  static constexpr int NT2 = KH2 * 3;
   static constexpr int SLOTS = kFreqC + 2;  // slot (row, s) = stack bin s-1, 8 channels; bins -1 and 264 zero
   static constexpr int RING = kBrRows + 2 * PH1;
   static constexpr int QRING = kBrRows + 2 * PH2;
   static constexpr int PIECE = 2;           // rows per staging call (3 tasks of 8 loads per thread)
+  static constexpr int DT0 = 2;
   static __device__ constexpr int d_of(int s, int h) { return (2 * s + h) / 5; }
   static __device__ constexpr int x_of(int s, int h) { return (2 * s + h) % 5; }
   static __device__ __forceinline__ int lane_slot(int wc) { return 3 * wc; }  // bin 3w+dw-1 -> slot 3w+dw
@@ -229,16 +229,14 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
     acc_t[k] += t_now - t_prev;                                    \
     t_prev = t_now;                                                \
   }
-  constexpr int KS1 = Br::KS1, KH2 = Br::KH2, PH1 = Br::PH1, PH2 = Br::PH2, NT2 = Br::NT2;
+  constexpr int KS1 = Br::KS1, KH2 = Br::KH2, PH1 = Br::PH1, PH2 = Br::PH2;
   __shared__ __attribute__((aligned(16))) uint4 img_hi[Br::RING * Br::SLOTS];
   __shared__ __attribute__((aligned(16))) uint4 img_lo[Br::RING * Br::SLOTS];
   __shared__ float qring[Br::QRING * KH2 * kFreqN];
-  __shared__ float scr_all[4 * NT2 * kScrStride];
 
   const int lane = threadIdx.x & 63;
   const int wave = wave_id();
   const int h = lane >> 5, li = lane & 31;
-  float* scr = scr_all + wave * (NT2 * kScrStride);
 
   // resident A operands (weights) and biases
   uint4 a1h[KS1], a1l[KS1], a2h[2], a2l[2];
@@ -255,9 +253,16 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
   float bias1[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) bias1[r] = p.wf32[(r & 3) + 8 * (r >> 2) + 4 * h];
-  float extra[9];
+  // onset: the 3x3 taps of the note channel (concat channel 0) for the frame taps this lane half owns
+  constexpr int DT0 = Br::DT0;
+  float extra[DT0][3];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) extra[i] = p.wf32[32 + i];
+  for (int i = 0; i < DT0; ++i)
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) {
+      const int dt = DT0 * h + i;
+      extra[i][dw] = (Br::kOnset && dt < KH2) ? p.wf32[32 + dt * 3 + dw] : 0.0f;
+    }
   const float bias2 = p.wf32[41];
 
   // slots no staging call writes (onset: the two zero bins either side of a row) are zero from here on
@@ -298,25 +303,11 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
 #pragma unroll
           for (int d = 0; d < Br::ND; ++d) rb[d] = ((row - PH1 + d + 64 * Br::RING) % Br::RING) * Br::SLOTS;
           const int lane_off = Br::lane_slot(wc);
-          // onset: the three note values each Q output needs (concat channel 0, models.py:305), fetched now so that
-          // their latency hides behind the MFMAs
-          constexpr int kQIter = (30 * KH2 + 63) / 64;
-          float nv[kQIter][3];
-          if constexpr (Br::kOnset) {
-            const float* note_row = p.note + ((int64_t)b * kFrames + row) * kFreqN;
-#pragma unroll
-            for (int it = 0; it < kQIter; ++it) {
-              const int idx = lane + 64 * it;
-              const int dtq = idx / 30;
-              int wq = wbase + 1 + idx - 30 * dtq;
-              wq = wq < 0 ? 0 : (wq > kFreqN - 1 ? kFreqN - 1 : wq);
-              // unconditional loads from clamped addresses: a select right behind a load would make this side wait for
-              // the data (measured: 1 k cycles per tile); the masks are applied where the values are used
-              nv[it][0] = note_row[wq > 0 ? wq - 1 : 0];
-              nv[it][1] = note_row[wq];
-              nv[it][2] = note_row[wq + 1 < kFreqN ? wq + 1 : kFreqN - 1];
-            }
-          }
+          // onset: the note value of this lane's pixel (concat channel 0, models.py:305), fetched now so that its
+          // latency hides behind the MFMAs; an unconditional load from a clamped address, masked where it is used (a
+          // select right behind a load would make this side wait for the data: measured 1 k cycles per tile)
+          float note_c = 0.0f;
+          if constexpr (Br::kOnset) note_c = p.note[((int64_t)b * kFrames + row) * kFreqN + wc];
 
           f32x16 acc, accc;
 #pragma unroll
@@ -375,41 +366,36 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
             ppc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b2h[s], ppc, 0, 0, 0);
             ppc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b2l[s], ppc, 0, 0, 0);
           }
-          // P[tap][pixel] -> per-wave scratch (tap = C row)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int t0 = (r & 3) + 8 * (r >> 2);  // tap for h = 0; h = 1 adds 4
-            if (t0 >= NT2) continue;
-            const float v = pp[r] + ppc[r] * kLoUnscale;
-            if (t0 + 4 < NT2) {
-              scr[(t0 + 4 * h) * kScrStride + li] = v;
-            } else if (h == 0) {
-              scr[t0 * kScrStride + li] = v;
-            }
+          // The packed conv2 weights put tap (dt, dw) in C row r = 3 (dt - DT0 h) + dw of lane half h = (dt >= DT0)
+          // (bp_api.hip pack_branch), so a lane holds all three dw projections of its pixel for its frame taps, and
+          //   Q[row][dt][w] = (P[dt,0][w-1] + P[dt,1][w]) + P[dt,2][w+1]
+          // is two whole-wave lane shifts (DPP wave_shr / wave_shl; the tile's edge pixels li = 0, 31 are halo and take
+          // garbage from the other half) - no LDS round trip.  The onset head adds the note channel of the concat.
+          auto from_left = [](float v) {  // value of lane - 1
+            return __builtin_bit_cast(float,
+                                      __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+          };
+          auto from_right = [](float v) {  // value of lane + 1
+            return __builtin_bit_cast(float,
+                                      __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+          };
+          float n_c = 0.0f, n_l = 0.0f, n_r = 0.0f;
+          if constexpr (Br::kOnset) {
+            n_c = wvalid ? note_c : 0.0f;
+            n_l = from_left(n_c);
+            n_r = from_right(n_c);
           }
-          __builtin_amdgcn_wave_barrier();
-          // Q[row][dt][w] = sum_dw P[w+dw-1][(dt,dw)]  (+ the note channel of the concat for the onset head, whose
-          // values were fetched before the MFMAs)
+          const bool store_ok = li >= 1 && li <= 30 && w < kFreqN;
 #pragma unroll
-          for (int it = 0; it < kQIter; ++it) {
-            const int idx = lane + 64 * it;
-            if (idx < 30 * KH2) {
-              const int dt = idx / 30;
-              const int l2 = 1 + idx - 30 * dt;
-              const int wq = wbase + l2;
-              const float* sp = scr + (dt * 3) * kScrStride + l2;
-              float q = (sp[-1] + sp[kScrStride]) + sp[2 * kScrStride + 1];
-              if (wq < kFreqN) {
-                if constexpr (Br::kOnset) {
-                  const float nl = wq > 0 ? nv[it][0] : 0.0f;
-                  const float nr = wq + 1 < kFreqN ? nv[it][2] : 0.0f;
-                  q += (nl * extra[dt * 3] + nv[it][1] * extra[dt * 3 + 1]) + nr * extra[dt * 3 + 2];
-                }
-                qrow[dt * kFreqN + wq] = q;
-              }
-            }
+          for (int i = 0; i < DT0; ++i) {
+            const float p0 = pp[3 * i] + ppc[3 * i] * kLoUnscale;
+            const float p1 = pp[3 * i + 1] + ppc[3 * i + 1] * kLoUnscale;
+            const float p2 = pp[3 * i + 2] + ppc[3 * i + 2] * kLoUnscale;
+            float q = (from_left(p0) + p1) + from_right(p2);
+            if constexpr (Br::kOnset) q += (n_l * extra[i][0] + n_c * extra[i][1]) + n_r * extra[i][2];
+            const int dt = DT0 * h + i;
+            if (store_ok && dt < KH2) qrow[dt * kFreqN + w] = q;
           }
-          __builtin_amdgcn_wave_barrier();
         } else {
           // conv1 row outside the window: conv2 sees zeros there
           for (int idx = lane; idx < 30 * KH2; idx += 64) {
