@@ -44,10 +44,7 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
 constexpr int kBrThreads = 256;
 constexpr int kBrRows = 4;                               // conv1 rows per phase
-constexpr int kBrChunks = 2;                             // time chunks per window
-constexpr int kBrChunkFrames = kFrames / kBrChunks;      // 86
 constexpr int kBrTilesPerRow = 3;                        // 32-pixel tiles, 30 inner pixels each
-static_assert(kFrames % kBrChunks == 0, "chunks tile the window");
 static_assert(kBrTilesPerRow * 30 >= kFreqN, "tiles cover a row");
 
 struct BranchParams {
@@ -72,6 +69,8 @@ struct NoteBr {
   static constexpr int QRING = kBrRows + 2 * PH2;
   static constexpr int PIECE = 4;           // rows per staging call (2 tasks of 8 loads per thread)
   static constexpr int DT0 = 4;             // conv2 frame taps whose projections land in lane half 0 (the rest: half 1)
+  static constexpr int CHUNKS = 2;          // time chunks per window (work items = windows x CHUNKS)
+  static constexpr int WGS = 2;             // workgroups per CU (3 x 3 measured slower: 27 spilled registers, 0.157 ms)
   static __device__ constexpr int d_of(int s, int h) { return 2 * s + h; }
   static __device__ constexpr int x_of(int, int) { return 0; }
   static __device__ __forceinline__ int lane_slot(int wc) { return wc; }
@@ -88,6 +87,8 @@ struct OnsetBr {
   static constexpr int QRING = kBrRows + 2 * PH2;
   static constexpr int PIECE = 2;           // rows per staging call (3 tasks of 8 loads per thread)
   static constexpr int DT0 = 2;
+  static constexpr int CHUNKS = 2;
+  static constexpr int WGS = 2;
   static __device__ constexpr int d_of(int s, int h) { return (2 * s + h) / 5; }
   static __device__ constexpr int x_of(int s, int h) { return (2 * s + h) % 5; }
   static __device__ __forceinline__ int lane_slot(int wc) { return 3 * wc; }  // bin 3w+dw-1 -> slot 3w+dw
@@ -96,6 +97,21 @@ struct OnsetBr {
 __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
   hi = (_Float16)v;
   lo = (_Float16)((v - (float)hi) * kLoScale);
+}
+
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+
+// Split of two values at once for the in-kernel operands (|v| < 65504): hi = v truncated to f16 (one
+// v_cvt_pkrtz_f16_f32 for the pair; any hi within an f16 ulp of v serves, the residual carries the rest exactly),
+// lo = rn_f16((v - hi) * 2^11) on the packed-f32 pipe.  4.5 VALU operations per value instead of 9.
+__device__ __forceinline__ void split_f16x2(f32x2 v, uint32_t& hi2, uint32_t& lo2) {
+  const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
+  const f32x2 hf = {(float)h.x, (float)h.y};
+  const f32x2 l = (v - hf) * f32x2{kLoScale, kLoScale};
+  const f16x2 lh = {(_Float16)l.x, (_Float16)l.y};
+  hi2 = __builtin_bit_cast(uint32_t, h);
+  lo2 = __builtin_bit_cast(uint32_t, lh);
 }
 
 // ---- image staging: `nrows` rows starting at `row_first` (absolute frame index, may be outside the window).
@@ -109,9 +125,8 @@ template <int NROWS>
 struct NoteStage {
   static constexpr int NT = (NROWS * kFreqN + kBrThreads - 1) / kBrThreads;
   float v[NT][8];
-  int dst[NT];
-  unsigned ok[NT];  // bit i: value i is inside the window (applied at commit: a select right after the load would
-                    // make the issue side wait for the data)
+  int dst[NT];   // image slot, -1: no task
+  int edge[NT];  // 0: inside, 1: w = 0 (bins -2, -1 are padding), 2: w = 87 (bins 264 .. 266 are padding), 3: row outside
 };
 
 template <class Br, int NROWS>
@@ -128,15 +143,15 @@ __device__ __forceinline__ void note_stage_issue(const BranchParams& p, int b, i
       const bool rvalid = row >= 0 && row < kFrames;
       const float* src = static_cast<const float*>(p.src) + ((int64_t)b * kFrames + (rvalid ? row : 0)) * kFreqC;
       st.dst[k] = ((row + 64 * Br::RING) % Br::RING) * Br::SLOTS + w;
-      unsigned okm = 0;
+      st.edge[k] = !rvalid ? 3 : (w == 0 ? 1 : (w == kFreqN - 1 ? 2 : 0));
+      // unconditional loads from clamped addresses; what is padding is zeroed at commit (a select right after the load
+      // would make the issue side wait for the data)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int bin = 3 * w + i - 2;
-        const bool ok = rvalid && bin >= 0 && bin < kFreqC;
-        okm |= ok ? (1u << i) : 0u;
-        st.v[k][i] = src[ok ? bin : 0];
+        int bin = 3 * w + i - 2;
+        bin = bin < 0 ? 0 : (bin > kFreqC - 1 ? kFreqC - 1 : bin);
+        st.v[k][i] = src[bin];
       }
-      st.ok[k] = okm;
     }
   }
 }
@@ -147,16 +162,20 @@ __device__ __forceinline__ void note_stage_commit(const NoteStage<NROWS>& st, ui
 #pragma unroll
   for (int k = 0; k < NoteStage<NROWS>::NT; ++k) {
     if (st.dst[k] < 0) continue;
-    f16x8 vh, vl;
+    uint4 vh{0u, 0u, 0u, 0u}, vl{0u, 0u, 0u, 0u};
+    if (st.edge[k] != 3) {
+      float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      _Float16 hi, lo;
-      split_f16(((st.ok[k] >> i) & 1u) ? st.v[k][i] : 0.0f, hi, lo);
-      vh[i] = hi;
-      vl[i] = lo;
+      for (int i = 0; i < 8; ++i) v[i] = st.v[k][i];
+      if (st.edge[k] == 1) v[0] = v[1] = 0.0f;
+      if (st.edge[k] == 2) v[5] = v[6] = v[7] = 0.0f;  // bins 264, 265 and the zero-weight dummy tap
+      split_f16x2(f32x2{v[0], v[1]}, vh.x, vl.x);
+      split_f16x2(f32x2{v[2], v[3]}, vh.y, vl.y);
+      split_f16x2(f32x2{v[4], v[5]}, vh.z, vl.z);
+      split_f16x2(f32x2{v[6], v[7]}, vh.w, vl.w);
     }
-    img_hi[st.dst[k]] = __builtin_bit_cast(uint4, vh);
-    img_lo[st.dst[k]] = __builtin_bit_cast(uint4, vl);
+    img_hi[st.dst[k]] = vh;
+    img_lo[st.dst[k]] = vl;
   }
 }
 
@@ -220,7 +239,7 @@ __device__ __forceinline__ void stage_block(const BranchParams& p, int b, int ro
 
 // WLO = false: conv1 weights without a lo part (BP_FLAG_BF16_WEIGHTS): 2 MFMAs per k-step
 template <class Br, bool WLO, bool PROF = false>
-__global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
+__global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParams p) {
   unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0};
   unsigned long long t_prev = PROF ? __builtin_readcyclecounter() : 0;
 #define BR_STAMP(k)                                                \
@@ -271,11 +290,12 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
     img_lo[i] = uint4{0u, 0u, 0u, 0u};
   }
 
-  const int n_items = p.n_windows * kBrChunks;
+  const int n_items = p.n_windows * Br::CHUNKS;
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int b = item / kBrChunks;
-    const int T0 = (item - b * kBrChunks) * kBrChunkFrames;
-    const int T1 = T0 + kBrChunkFrames;
+    const int b = item / Br::CHUNKS;
+    const int ci = item - b * Br::CHUNKS;
+    const int T0 = (ci * kFrames) / Br::CHUNKS;
+    const int T1 = ((ci + 1) * kFrames) / Br::CHUNKS;
     const int n_phase = (T1 - T0 + 2 * PH2 + kBrRows - 1) / kBrRows;
 
     __syncthreads();  // previous item finished with the rings
@@ -309,10 +329,10 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
           float note_c = 0.0f;
           if constexpr (Br::kOnset) note_c = p.note[((int64_t)b * kFrames + row) * kFreqN + wc];
 
-          f32x16 acc, accc;
+          f32x16 acc, accc;  // the hi x hi chain starts from the bias
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            acc[r] = 0.0f;
+            acc[r] = bias1[r];
             accc[r] = 0.0f;
           }
           // image fragments are read kBrPf k-steps ahead of the MFMAs that consume them (the compiler's own
@@ -341,16 +361,21 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
             __builtin_amdgcn_sched_barrier(0);
           }
 
-          // bias + ReLU (+ zero padding of conv2 outside the row), split, and the tap projection
+          // ReLU, split, and the tap projection (two values per VALU operation where the packed-f32 pipe has one)
+          uint32_t b2hw[8], b2lw[8];
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            f32x2 v = __builtin_elementwise_fma(f32x2{accc[r], accc[r + 1]}, f32x2{kLoUnscale, kLoUnscale},
+                                                f32x2{acc[r], acc[r + 1]});
+            v.x = fmaxf(v.x, 0.0f);
+            v.y = fmaxf(v.y, 0.0f);
+            split_f16x2(v, b2hw[r >> 1], b2lw[r >> 1]);
+          }
           f16x8 b2h[2], b2l[2];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = fmaxf((acc[r] + accc[r] * kLoUnscale) + bias1[r], 0.0f);
-            v = wvalid ? v : 0.0f;
-            _Float16 hi, lo;
-            split_f16(v, hi, lo);
-            b2h[r >> 3][r & 7] = hi;
-            b2l[r >> 3][r & 7] = lo;
+          for (int s = 0; s < 2; ++s) {
+            b2h[s] = __builtin_bit_cast(f16x8, uint4{b2hw[4 * s], b2hw[4 * s + 1], b2hw[4 * s + 2], b2hw[4 * s + 3]});
+            b2l[s] = __builtin_bit_cast(f16x8, uint4{b2lw[4 * s], b2lw[4 * s + 1], b2lw[4 * s + 2], b2lw[4 * s + 3]});
           }
           f32x16 pp, ppc;
 #pragma unroll
@@ -388,9 +413,12 @@ __global__ __launch_bounds__(kBrThreads, 2) void branch_kernel(BranchParams p) {
           const bool store_ok = li >= 1 && li <= 30 && w < kFreqN;
 #pragma unroll
           for (int i = 0; i < DT0; ++i) {
-            const float p0 = pp[3 * i] + ppc[3 * i] * kLoUnscale;
+            // pixels outside the row are conv2's zero padding: they only matter as the neighbours of an edge pixel
+            float p0 = pp[3 * i] + ppc[3 * i] * kLoUnscale;
             const float p1 = pp[3 * i + 1] + ppc[3 * i + 1] * kLoUnscale;
-            const float p2 = pp[3 * i + 2] + ppc[3 * i + 2] * kLoUnscale;
+            float p2 = pp[3 * i + 2] + ppc[3 * i + 2] * kLoUnscale;
+            p0 = wvalid ? p0 : 0.0f;
+            p2 = wvalid ? p2 : 0.0f;
             float q = (from_left(p0) + p1) + from_right(p2);
             if constexpr (Br::kOnset) q += (n_l * extra[i][0] + n_c * extra[i][1]) + n_r * extra[i][2];
             const int dt = DT0 * h + i;
@@ -473,8 +501,8 @@ void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, L
 
 template <class Br>
 static void launch_branch(const BranchParams& p, int n_cu, bool weights_have_lo, hipStream_t stream) {
-  const int items = p.n_windows * kBrChunks;
-  const int grid = items < 2 * n_cu ? items : 2 * n_cu;
+  const int items = p.n_windows * Br::CHUNKS;
+  const int grid = items < Br::WGS * n_cu ? items : Br::WGS * n_cu;
   static const bool prof = getenv("BP_BRANCH_PROF") != nullptr;
   if (prof) {  // tools only: phase profile of block 0 to stderr
     BranchParams q = p;
