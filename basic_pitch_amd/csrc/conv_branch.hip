@@ -70,7 +70,8 @@ struct NoteBr {
   static constexpr int PIECE = 4;           // rows per staging call (2 tasks of 8 loads per thread)
   static constexpr int DT0 = 4;             // conv2 frame taps whose projections land in lane half 0 (the rest: half 1)
   static constexpr int CHUNKS = 2;          // time chunks per window (work items = windows x CHUNKS)
-  static constexpr int WGS = 2;             // workgroups per CU (3 x 3 measured slower: 27 spilled registers, 0.157 ms)
+  static constexpr int WGS = 2;             // workgroups per CU (3 chunks x 3 resident: 0.138 vs 0.130 ms, the third
+                                            // chunk's halo and prologue cost more than the third wave per SIMD hides)
   static __device__ constexpr int d_of(int s, int h) { return 2 * s + h; }
   static __device__ constexpr int x_of(int, int) { return 0; }
   static __device__ __forceinline__ int lane_slot(int wc) { return wc; }
@@ -507,6 +508,9 @@ static void launch_branch(const BranchParams& p, int n_cu, bool weights_have_lo,
   if (prof) {  // tools only: phase profile of block 0 to stderr
     BranchParams q = p;
     unsigned long long hbuf[24];
+    int resident = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, branch_kernel<Br, true>, kBrThreads, 0);
+    fprintf(stderr, "brprof %s: %d workgroups resident per CU\n", Br::kOnset ? "onset" : "note", resident);
     if (hipMalloc(&q.prof, sizeof hbuf) != hipSuccess) return;
     (void)hipMemsetAsync(q.prof, 0, sizeof hbuf, stream);
     hipLaunchKernelGGL((branch_kernel<Br, true, true>), dim3(grid), dim3(kBrThreads), 0, stream, q);
