@@ -69,6 +69,9 @@ struct NoteBr {
   static constexpr int QRING = kBrRows + 2 * PH2;
   static constexpr int PIECE = 4;           // rows per staging call (2 tasks of 8 loads per thread)
   static constexpr int DT0 = 4;             // conv2 frame taps whose projections land in lane half 0 (the rest: half 1)
+  static constexpr int RAW_ROW = kFreqC / 4;  // 16-byte units of a source row brought in by LDS-DMA (264 floats)
+  static constexpr int RAW_PAD = 1;         // units in front of the rows (slot w = 0 reads bins -2, -1: masked)
+  static constexpr int RAW_UNITS = RAW_PAD + kBrRows * RAW_ROW + 2;
   static constexpr int CHUNKS = 2;          // time chunks per window (work items = windows x CHUNKS)
   static constexpr int WGS = 2;             // workgroups per CU (3 chunks x 3 resident: 0.138 vs 0.130 ms, the third
                                             // chunk's halo and prologue cost more than the third wave per SIMD hides)
@@ -88,6 +91,10 @@ struct OnsetBr {
   static constexpr int QRING = kBrRows + 2 * PH2;
   static constexpr int PIECE = 2;           // rows per staging call (3 tasks of 8 loads per thread)
   static constexpr int DT0 = 2;
+  static constexpr int RAW_W0 = 20;         // first zp word of a row brought in by LDS-DMA: bin -36 (= kZPadL - 36)
+  static constexpr int RAW_ROW = 101;       // 16-byte units: words 20 .. 423 (bins -36 .. 263 + 101 and the tail)
+  static constexpr int RAW_PAD = 0;
+  static constexpr int RAW_UNITS = RAW_PAD + kBrRows * RAW_ROW;
   static constexpr int CHUNKS = 2;
   static constexpr int WGS = 2;
   static __device__ constexpr int d_of(int s, int h) { return (2 * s + h) / 5; }
@@ -238,6 +245,91 @@ __device__ __forceinline__ void stage_block(const BranchParams& p, int b, int ro
   if constexpr (NROWS % P != 0) stage_rows<Br, NROWS % P>(p, b, row_first + NROWS - NROWS % P, img_hi, img_lo, tid);
 }
 
+// ---- steady-state staging: the kBrRows source rows of the NEXT phase come in by LDS-DMA (global_load_lds_dwordx4:
+// lane l's 16 bytes land at the wave's LDS base + 16 l, checked in tools/ubench/lds_dma.hip) while the tiles of this
+// phase run, and are split / gathered LDS -> LDS after the barrier: no global-load latency on the phase's critical path.
+// 16 bytes per lane, global -> LDS at `lds_wave_base` + 16 * lane (wave-uniform base), asynchronous (vmcnt)
+__device__ __forceinline__ void lds_dma16(const void* gsrc, uint4* lds_wave_base) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the builtin does not exist in the host pass
+  __builtin_amdgcn_global_load_lds(gsrc, lds_wave_base, 16, 0, 0);
+#endif
+}
+
+template <class Br>
+__device__ __forceinline__ void raw_dma_issue(const BranchParams& p, int b, int row_first, uint4* raw, int wave,
+                                              int lane) {
+  constexpr int total = kBrRows * Br::RAW_ROW;
+  for (int u0 = wave * 64; u0 < total; u0 += kBrThreads) {
+    const int u = u0 + lane;
+    if (u < total) {
+      const int rr = u / Br::RAW_ROW, cu = u - rr * Br::RAW_ROW;
+      const int row = row_first + rr;
+      if constexpr (Br::kOnset) {
+        // rows outside [-1, 172] read the all-zero pad row -1 of the padded window (bp_common.h)
+        const bool rvalid = row >= -1 && row <= kFrames;
+        const uint32_t* src = static_cast<const uint32_t*>(p.src) + (int64_t)b * kZWin +
+                              (int64_t)((rvalid ? row : -1) + 1) * kZRow + Br::RAW_W0 + 4 * cu;
+        lds_dma16(src, raw + Br::RAW_PAD + u0);
+      } else {
+        if (row >= 0 && row < kFrames) {  // rows outside the window are zeroed at the conversion
+          const float* src = static_cast<const float*>(p.src) + ((int64_t)b * kFrames + row) * kFreqC + 4 * cu;
+          lds_dma16(src, raw + Br::RAW_PAD + u0);
+        }
+      }
+    }
+  }
+}
+
+template <class Br>
+__device__ __forceinline__ void raw_convert(int row_first, const uint4* raw_, uint4* __restrict__ img_hi,
+                                            uint4* __restrict__ img_lo, int tid) {
+  // the DMA's LDS writes are invisible to the optimiser: read through a laundered pointer
+  const uint4* raw = raw_;
+  asm volatile("" : "+v"(raw)::"memory");
+  constexpr int PER_ROW = Br::kOnset ? kFreqC : kFreqN;
+  constexpr int ntask = kBrRows * PER_ROW;
+#pragma unroll 1
+  for (int e = tid; e < ntask; e += kBrThreads) {
+    const int rr = e / PER_ROW, f = e - rr * PER_ROW;
+    const int row = row_first + rr;
+    uint4 vh{0u, 0u, 0u, 0u}, vl{0u, 0u, 0u, 0u};
+    if constexpr (Br::kOnset) {
+      const uint32_t* words = reinterpret_cast<const uint32_t*>(raw + Br::RAW_PAD + rr * Br::RAW_ROW) +
+                              (kZPadL - Br::RAW_W0) + f;
+      uint32_t u[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) u[c] = words[harm_shift(c)];
+      vh.x = (u[0] & 0xffffu) | (u[1] << 16);
+      vh.y = (u[2] & 0xffffu) | (u[3] << 16);
+      vh.z = (u[4] & 0xffffu) | (u[5] << 16);
+      vh.w = (u[6] & 0xffffu) | (u[7] << 16);
+      vl.x = (u[0] >> 16) | (u[1] & 0xffff0000u);
+      vl.y = (u[2] >> 16) | (u[3] & 0xffff0000u);
+      vl.z = (u[4] >> 16) | (u[5] & 0xffff0000u);
+      vl.w = (u[6] >> 16) | (u[7] & 0xffff0000u);
+      const int dst = ((row + 64 * Br::RING) % Br::RING) * Br::SLOTS + f + 1;
+      img_hi[dst] = vh;
+      img_lo[dst] = vl;
+    } else {
+      if (row >= 0 && row < kFrames) {
+        const float* fl = reinterpret_cast<const float*>(raw + Br::RAW_PAD + rr * Br::RAW_ROW) + 3 * f - 2;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fl[i];
+        if (f == 0) v[0] = v[1] = 0.0f;
+        if (f == kFreqN - 1) v[5] = v[6] = v[7] = 0.0f;
+        split_f16x2(f32x2{v[0], v[1]}, vh.x, vl.x);
+        split_f16x2(f32x2{v[2], v[3]}, vh.y, vl.y);
+        split_f16x2(f32x2{v[4], v[5]}, vh.z, vl.z);
+        split_f16x2(f32x2{v[6], v[7]}, vh.w, vl.w);
+      }
+      const int dst = ((row + 64 * Br::RING) % Br::RING) * Br::SLOTS + f;
+      img_hi[dst] = vh;
+      img_lo[dst] = vl;
+    }
+  }
+}
+
 // WLO = false: conv1 weights without a lo part (BP_FLAG_BF16_WEIGHTS): 2 MFMAs per k-step
 template <class Br, bool WLO, bool PROF = false>
 __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParams p) {
@@ -253,6 +345,7 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
   __shared__ __attribute__((aligned(16))) uint4 img_hi[Br::RING * Br::SLOTS];
   __shared__ __attribute__((aligned(16))) uint4 img_lo[Br::RING * Br::SLOTS];
   __shared__ float qring[Br::QRING * KH2 * kFreqN];
+  __shared__ __attribute__((aligned(16))) uint4 raw[Br::RAW_UNITS];
 
   const int lane = threadIdx.x & 63;
   const int wave = wave_id();
@@ -306,6 +399,8 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
     for (int ph = 0; ph < n_phase; ++ph) {
       const int r0 = T0 - PH2 + kBrRows * ph;  // first conv1 row of this phase
       BR_STAMP(0);
+      // the next phase's source rows start their way into LDS now (raw was consumed before the last barrier)
+      if (ph + 1 < n_phase) raw_dma_issue<Br>(p, b, r0 + kBrRows + PH1, raw, wave, lane);
 
       // ---- conv1 + projection, 12 tiles: 4 rows x 3 overlapping 32-pixel tiles (30 inner pixels each)
 #pragma unroll 1
@@ -435,6 +530,7 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
         }
       }
       BR_STAMP(1);
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of the DMA has landed
       lds_barrier();
       BR_STAMP(2);
 
@@ -456,7 +552,7 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
         }
       }
       BR_STAMP(3);
-      if (ph + 1 < n_phase) stage_block<Br, kBrRows>(p, b, r0 + kBrRows + PH1, img_hi, img_lo, threadIdx.x);
+      if (ph + 1 < n_phase) raw_convert<Br>(r0 + kBrRows + PH1, raw, img_hi, img_lo, threadIdx.x);
       BR_STAMP(4);
       lds_barrier();
       BR_STAMP(5);
