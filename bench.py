@@ -364,6 +364,19 @@ def main() -> None:
             "stage_ms": stage,
             "outputs_finite": ok,
         }
+        if not args.ext_cqt_44k:
+            # the CQT stage (a7-a8: pyramid + filterbank, here with NormalizedLog's log fused in) against
+            # both of its rooflines; algorithmic 79,425,024 FLOP and 387,968 B (audio in + 172x309 fp32 out) per window
+            cqt_ms = stage["pyramid"] + stage["filterbank"]
+            cqt_rate = B / (cqt_ms * 1e-3)
+            line["cqt_stage"] = {
+                "ms": cqt_ms,
+                "windows_per_s": cqt_rate,
+                "fp32_fraction": 79_425_024 * cqt_rate / (F32_MFMA_PEAK_TFLOPS * 1e12),
+                "hbm_fraction": 387_968 * cqt_rate / (HBM_PEAK_GBS * 1e9),
+                "binding": "fp32 direct-form FLOPs (the HBM roofline of 20.6 M windows/s is out of reach of this "
+                           "algorithm in fp32: SURVEY.md 8(d))",
+            }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         elif not args.no_cpu_baseline:
