@@ -17,6 +17,7 @@ BP_ERR_UNSUPPORTED = -6
 BP_MEM_HOST = 0
 BP_MEM_DEVICE = 1
 BP_FLAG_STAGE_TIMING = 1
+BP_FLAG_TIME_DOMINANT = 16
 BP_FLAG_F32_MFMA = 2
 BP_FLAG_BF16_WEIGHTS = 4
 BP_FLAG_EXT_CQT_44K = 8

@@ -566,10 +566,24 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
               float* contour_dev) {
   hipStream_t s = h->stream;
   const bool timing = (h->flags & BP_FLAG_STAGE_TIMING) != 0;
+  // BP_FLAG_TIME_DOMINANT: events only around the dominant kernel
+  const bool dom = !timing && (h->flags & BP_FLAG_TIME_DOMINANT) && !(h->flags & BP_FLAG_F32_MFMA);
   const bool wlo = !(h->flags & BP_FLAG_BF16_WEIGHTS);  // conv weights carry an f16 lo part
   int e = 0;
   hipEvent_t* ev = h->ev[h->timed_chunks % bp_context::kTimedRing];
   if (timing) BP_HIP(hipEventRecord(ev[0], s));
+#define BP_DOM_BEGIN()                                \
+  do {                                                \
+    if (dom) BP_HIP(hipEventRecord(ev[0], s));        \
+  } while (0)
+#define BP_DOM_END(id)                                \
+  do {                                                \
+    if (dom) {                                        \
+      h->seq[0] = (id);                               \
+      BP_HIP(hipEventRecord(ev[1], s));               \
+      e = 1;                                          \
+    }                                                 \
+  } while (0)
   // closes the interval of stage `id` (the kernels launched since the previous mark)
 #define BP_MARK(id)                                \
   do {                                             \
@@ -608,17 +622,22 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
     launch_zpack(h->lp, h->mm, reinterpret_cast<uint32_t*>(h->zp), n, h->kc, h->n_bins, s);
     BP_MARK(BP_STAGE_ZPACK);
     if (h->fused_contour) {
+      BP_DOM_BEGIN();
       launch_contour_branch(reinterpret_cast<const uint32_t*>(h->zp), h->d_cb_wfrag, h->d_cb_wf32, contour_dev, n,
                             h->n_cu, s);
+      BP_DOM_END(BP_STAGE_CONTOUR);
       BP_MARK(BP_STAGE_CONTOUR);
     } else {
+      if (contour_conv1_full()) BP_DOM_BEGIN();
       launch_contour_conv1_exact(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wlds, h->d_d1_bias, h->c1s, n,
                                  h->n_cu, wlo, s);
       if (!contour_conv1_full()) {
         BP_MARK(BP_STAGE_CONTOUR_CONV1_EDGE);
+        BP_DOM_BEGIN();
         launch_contour_conv1_folded(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wfold, h->d_d1_bias, h->c1s, n,
                                     h->n_cu, wlo, s);
       }
+      BP_DOM_END(BP_STAGE_CONTOUR_CONV1);
       BP_MARK(BP_STAGE_CONTOUR_CONV1);
       launch_contour_conv2(h->c1s, h->d_d2_w, h->b_contour2, contour_dev, n, h->n_cu, s);
       BP_MARK(BP_STAGE_CONTOUR_CONV2);
@@ -630,7 +649,9 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
     BP_MARK(BP_STAGE_ONSET);
   }
 #undef BP_MARK
-  if (timing) {
+#undef BP_DOM_BEGIN
+#undef BP_DOM_END
+  if (timing || dom) {
     h->n_seq = e;
     h->timed_chunks++;
   }
@@ -860,7 +881,7 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     }
   }
   if ((rc = ensure_fb_scratch(h, cap))) return fail(rc);
-  if (flags & BP_FLAG_STAGE_TIMING) {
+  if (flags & (BP_FLAG_STAGE_TIMING | BP_FLAG_TIME_DOMINANT)) {
     for (auto& row : h->ev)
       for (auto& e : row)
         if (hipEventCreate(&e) != hipSuccess) {
@@ -1269,8 +1290,8 @@ int bp_infer_pcm(bp_handle h, const float* pcm, int64_t n_frames, int channels, 
 
 int bp_get_stage_ms(bp_handle h, float* ms, int n) {
   if (!h || !ms || n < BP_N_STAGES) return BP_ERR_INVALID_ARG;
-  if (!(h->flags & BP_FLAG_STAGE_TIMING) || h->timed_chunks == 0) {
-    h->err = "bp_get_stage_ms: handle was not created with BP_FLAG_STAGE_TIMING or nothing ran yet";
+  if (!(h->flags & (BP_FLAG_STAGE_TIMING | BP_FLAG_TIME_DOMINANT)) || h->timed_chunks == 0) {
+    h->err = "bp_get_stage_ms: handle was not created with BP_FLAG_STAGE_TIMING / BP_FLAG_TIME_DOMINANT or nothing ran yet";
     return BP_ERR_UNSUPPORTED;
   }
   BP_HIP(hipStreamSynchronize(h->stream));

@@ -70,6 +70,7 @@ class Model:
         device: int = 0,
         max_windows: int = 256,
         stage_timing: bool = False,
+        time_dominant: bool = False,
         exact_f32_mfma: bool = False,
         bf16_weights: bool = False,
         ext_cqt_44k: bool = False,
@@ -82,6 +83,8 @@ class Model:
         except OSError as e:
             raise ValueError(f"File {model_path} cannot be loaded: {e}") from e
         flags = _native.BP_FLAG_STAGE_TIMING if stage_timing else 0
+        if time_dominant:  # HIP events around the dominant kernel only (2 records per chunk instead of 16)
+            flags |= _native.BP_FLAG_TIME_DOMINANT
         if exact_f32_mfma:  # A/B reference: contour conv1 on the exact-f32 MFMA kernel
             flags |= _native.BP_FLAG_F32_MFMA
         if bf16_weights:  # BASELINE.json configs[3]: conv weights rounded to bf16, 2 matrix instructions per product

@@ -245,8 +245,11 @@ def main() -> None:
         "onset": torch.empty((B, 172, 88), device=dev),
         "contour": torch.empty((B, 172, 264), device=dev),
     }
-    model = Model(device=local_rank, max_windows=B, stage_timing=True, exact_f32_mfma=args.exact_f32,
-                  bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k)
+    # The timed steps carry HIP events around the dominant kernel only (roofline.achieved is measured live there); the
+    # full per-stage table costs 16 event records = ~25 us (2.6 %) per step and comes from a second, untimed pass.
+    # The exact-f32 A/B path has no dominant-only mode: it is timed with the full set.
+    model = Model(device=local_rank, max_windows=B, stage_timing=args.exact_f32, time_dominant=not args.exact_f32,
+                  exact_f32_mfma=args.exact_f32, bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k)
 
     def step():
         model._predict_device(audio, out=out, sync=False)
@@ -268,6 +271,25 @@ def main() -> None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     stage = model.stage_ms()  # mean per-launch ms over the timed steps (HIP events on the kernels' stream)
+    if not args.exact_f32:
+        # untimed second pass with events around every stage (same inputs, same kernels); the dominant kernel's entry
+        # stays the one measured inside the timed region
+        dom = {k: v for k, v in stage.items() if v > 0.0}
+        model.close()
+        model = Model(device=local_rank, max_windows=B, stage_timing=True, bf16_weights=args.bf16_weights,
+                      ext_cqt_44k=args.ext_cqt_44k)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        model.stage_ms()
+        for _ in range(min(args.steps, 20)):
+            step()
+        torch.cuda.synchronize()
+        stage = model.stage_ms()
+        stage_all_pass = dict(stage)
+        stage.update(dom)
+    else:
+        stage_all_pass = None
 
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -362,6 +384,10 @@ def main() -> None:
                 "hbm_frac_algorithmic": BYTES_PER_WINDOW * value / world / (HBM_PEAK_GBS * 1e9),
             },
             "stage_ms": stage,
+            "stage_ms_note": "per-stage HIP-event means from a second untimed pass (16 event records per step cost ~2.6 %); "
+                             "the dominant kernel's entry is the one measured inside the timed steps"
+                             + ("" if stage_all_pass is None or c1_key is None else
+                                f" (second pass: {stage_all_pass.get('contour_conv1', stage_all_pass.get('contour', 0.0)):.4f} ms)"),
             "outputs_finite": ok,
         }
         if not args.ext_cqt_44k:

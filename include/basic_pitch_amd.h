@@ -79,6 +79,10 @@ typedef enum bp_mem_kind {
                                  * zeros).  Parity is against the re-parametrised restatement (oracle).  Window /
                                  * track sizes of a handle: bp_handle_window_samples, bp_handle_track_n_*.
                                  * Not available with BP_FLAG_F32_MFMA. */
+#define BP_FLAG_TIME_DOMINANT 16u /* record HIP events only around the dominant kernel (stage CONTOUR_CONV1: the folded
+                                   * contour conv1, or CONTOUR for BP_CONTOUR_PATH=fused); bp_get_stage_ms then reports that
+                                   * stage alone.  Two event records per chunk instead of sixteen: the full set costs
+                                   * ~25 us (2.6 %) of a 256-window step.  Ignored with BP_FLAG_STAGE_TIMING / F32_MFMA. */
 
 /*
  * Weights blob ("BPAMDW01", little endian) — produced by tools/extract_weights.py from the
@@ -202,7 +206,7 @@ enum {
 /* Default (split-precision) path runs: PYRAMID, FILTERBANK, ZPACK, CONTOUR_CONV1_EDGE, CONTOUR_CONV1, CONTOUR_CONV2, NOTE, ONSET.
  * BP_FLAG_F32_MFMA runs:               PYRAMID, FILTERBANK, CONTOUR1, CONTOUR2, NOTE1, NOTE2, ONSET1, ONSET2. */
 
-/* With BP_FLAG_STAGE_TIMING: mean milliseconds per stage over the chunks (<= 128 most recent) run
+/* With BP_FLAG_STAGE_TIMING (or BP_FLAG_TIME_DOMINANT, one stage): mean milliseconds per stage over the chunks (<= 128 most recent) run
  * since the previous call (0 for stages the handle's path does not run); n >= BP_N_STAGES;
  * synchronises the stream and resets the accumulation. */
 int bp_get_stage_ms(bp_handle h, float* ms, int n);

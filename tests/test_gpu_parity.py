@@ -340,6 +340,34 @@ def test_edge_cases():
     m.close()
 
 
+def test_time_dominant_flag_times_one_stage_and_changes_nothing():
+    """BP_FLAG_TIME_DOMINANT (what bench.py's timed steps use): events around the folded contour conv1 only; the
+    outputs are bit-identical to an untimed and to a fully timed handle."""
+    from basic_pitch_amd import Model
+
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (3, 43844)).astype(np.float32)
+    ref = None
+    for kw in ({}, {"time_dominant": True}, {"stage_timing": True}):
+        m = Model(max_windows=4, **kw)
+        out = m.predict(x)
+        if ref is None:
+            ref = out
+            with pytest.raises(ValueError):
+                m.stage_ms()  # BP_ERR_UNSUPPORTED: no timing flag
+        else:
+            for k in ref:
+                assert np.array_equal(out[k], ref[k]), (kw, k)
+            ms = m.stage_ms()
+            assert ms["contour_conv1"] > 0.0
+            timed = {k for k, v in ms.items() if v > 0.0}
+            if "time_dominant" in kw:
+                assert timed == {"contour_conv1"}, timed
+            else:
+                assert {"pyramid", "filterbank", "zpack", "contour_conv2", "note", "onset"} <= timed
+        m.close()
+
+
 def test_new_entry_points_reject_bad_arguments():
     """C-ABI error behaviour of the round's new entry points: invalid arguments come back as BP_ERR_INVALID_ARG /
     BP_ERR_UNSUPPORTED (ValueError / NativeLibraryError on the Python side), never as a crash."""

@@ -1,9 +1,4 @@
 cd $GRAFT_REPO_ROOT
 timeout 400 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
-for i in 1 2; do
-for pl in 1 0; do
-echo "PIPELINE=$pl"
-BP_PIPELINE=$pl timeout 300 python bench.py --no-cpu-baseline --workload tracks --tracks 1000 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(' tracks', round(d['value']))"
-BP_PIPELINE=$pl timeout 300 python bench.py --no-cpu-baseline --batch 1024 --steps 10 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(' b1024', round(d['value']))"
-done
-done
+timeout 300 python bench.py > gpurun_out/bench_new.json 2> gpurun_out/bench_new.err; tail -3 gpurun_out/bench_new.err
+tail -1 gpurun_out/bench_new.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), d['ms_per_step'], d['roofline']['frac'], d['roofline']['launch_ms'], d['stage_ms_note'][-40:], {k: round(v,4) for k,v in d['stage_ms'].items() if v>0}, d.get('cqt_stage'))"
