@@ -65,6 +65,33 @@ constexpr float kLoScale = 2048.0f, kLoUnscale = 1.0f / 2048.0f;
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+
+// The same with hi rounded to nearest (the CQT operands: half the representation error of the truncating form, which
+// the log of weak bins amplifies)
+__device__ __forceinline__ void split_f16x2_rn(f32x2 v, uint32_t& hi2, uint32_t& lo2) {
+  const f16x2 h = {(_Float16)v.x, (_Float16)v.y};
+  const f32x2 hf = {(float)h.x, (float)h.y};
+  const f32x2 l = (v - hf) * f32x2{2048.0f, 2048.0f};
+  const f16x2 lh = {(_Float16)l.x, (_Float16)l.y};
+  hi2 = __builtin_bit_cast(uint32_t, h);
+  lo2 = __builtin_bit_cast(uint32_t, lh);
+}
+
+// Split of two values at once for in-kernel operands (|v| < 65504): hi = v truncated to f16 (one v_cvt_pkrtz_f16_f32
+// for the pair; any hi within an f16 ulp of v serves, the residual carries the rest exactly), lo = rn_f16((v - hi) *
+// 2^11) on the packed-f32 pipe.  ~3 VALU operations per value instead of 5.
+__device__ __forceinline__ void split_f16x2(f32x2 v, uint32_t& hi2, uint32_t& lo2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
+  const f32x2 hf = {(float)h.x, (float)h.y};
+  const f32x2 l = (v - hf) * f32x2{2048.0f, 2048.0f};
+  const f16x2 lh = {(_Float16)l.x, (_Float16)l.y};
+  hi2 = __builtin_bit_cast(uint32_t, h);
+  lo2 = __builtin_bit_cast(uint32_t, lh);
+#endif
+}
 
 // order-preserving float <-> int map so per-window min/max can use integer atomics
 __device__ __forceinline__ int f2ord(float f) {

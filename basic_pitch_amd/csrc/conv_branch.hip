@@ -107,21 +107,6 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
   lo = (_Float16)((v - (float)hi) * kLoScale);
 }
 
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
-
-// Split of two values at once for the in-kernel operands (|v| < 65504): hi = v truncated to f16 (one
-// v_cvt_pkrtz_f16_f32 for the pair; any hi within an f16 ulp of v serves, the residual carries the rest exactly),
-// lo = rn_f16((v - hi) * 2^11) on the packed-f32 pipe.  4.5 VALU operations per value instead of 9.
-__device__ __forceinline__ void split_f16x2(f32x2 v, uint32_t& hi2, uint32_t& lo2) {
-  const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
-  const f32x2 hf = {(float)h.x, (float)h.y};
-  const f32x2 l = (v - hf) * f32x2{kLoScale, kLoScale};
-  const f16x2 lh = {(_Float16)l.x, (_Float16)l.y};
-  hi2 = __builtin_bit_cast(uint32_t, h);
-  lo2 = __builtin_bit_cast(uint32_t, lh);
-}
-
 // ---- image staging: `nrows` rows starting at `row_first` (absolute frame index, may be outside the window).
 // Tasks (row, slot) are dealt round-robin to the 256 threads; a thread first ISSUES the loads of all its tasks
 // (NT x 8 in flight), then splits / packs and writes them: the global-load latency is paid once per call, not once

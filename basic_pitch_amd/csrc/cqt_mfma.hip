@@ -43,15 +43,10 @@ constexpr float kDmTapUnscale = 1.0f / 1024.0f;   // decimator taps are packed *
 constexpr float kFmTapUnscale = 1.0f / 4096.0f;   // CQT kernels are packed * 2^12
 
 __device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo) {
-  f16x8 vh, vl;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const _Float16 h = (_Float16)v[e];
-    vh[e] = h;
-    vl[e] = (_Float16)((v[e] - (float)h) * kLoScale);
-  }
-  hi = __builtin_bit_cast(uint4, vh);
-  lo = __builtin_bit_cast(uint4, vl);
+  split_f16x2_rn(f32x2{v[0], v[1]}, hi.x, lo.x);
+  split_f16x2_rn(f32x2{v[2], v[3]}, hi.y, lo.y);
+  split_f16x2_rn(f32x2{v[4], v[5]}, hi.z, lo.z);
+  split_f16x2_rn(f32x2{v[6], v[7]}, hi.w, lo.w);
 }
 
 #define BP_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0)
@@ -324,6 +319,7 @@ __device__ __forceinline__ void fm_item(const float* __restrict__ x, int L, int 
 
   // epilogue: 16 frames x 36 filters -> * sqrt(len), magnitude, log-power, tile extrema
   float vmin = __int_as_float(0x7f800000), vmax = -__int_as_float(0x7f800000);
+  const float kln2 = 0.69314718055994531f * kc.s0 * kc.s1;  // log2 -> 10 log10
   for (int idx = threadIdx.x; idx < kFmTileFrames * kBpo; idx += kFmThreads) {
     const int fr = idx / kBpo, k = idx - fr * kBpo;
     const int t = t0 + fr;
@@ -344,9 +340,11 @@ __device__ __forceinline__ void fm_item(const float* __restrict__ x, int L, int 
     const float sl = sqrt_len[bin];
     re = __fmul_rn(re, sl);  // nnaudio.py:650: scale before squaring
     im = __fmul_rn(im, sl);
-    const float mag = sqrtf(__fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)));  // nnaudio.py:661
-    const float pw = __fmul_rn(mag, mag);                                      // signal.py:174
-    const float v = __fmul_rn(__fmul_rn(logf(__fadd_rn(pw, kc.eps)), kc.s0), kc.s1);
+    // nnaudio.py:661 magnitude, signal.py:174-175 power and 10 log10: the hardware's 1-ulp sqrt and log2 (the precise
+    // library forms are ~35 VALU instructions per bin of a kernel whose pace the VALU sets; 1e-7 relative on lp)
+    const float mag = __builtin_amdgcn_sqrtf(__fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)));
+    const float pw = __fmul_rn(mag, mag);
+    const float v = __fmul_rn(__builtin_amdgcn_logf(__fadd_rn(pw, kc.eps)), kln2);
     lp[((int64_t)b * kFrames + t) * n_bins + bin] = v;
     vmin = fminf(vmin, v);
     vmax = fmaxf(vmax, v);
