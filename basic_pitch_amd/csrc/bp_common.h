@@ -68,6 +68,31 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 
+// Whole-wave min / max by DPP (row scans + row_bcast15 / row_bcast31, GFX9 controls): the result is in lane 63.
+// 6 VALU operations instead of 6 x (address + ds_bpermute + op).
+#define BP_DPP_STEP(op, v, ctrl, rmask)                                                                                \
+  v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), \
+                                                                   ctrl, rmask, 0xf, false)))
+__device__ __forceinline__ float wave_min_lane63(float v) {
+  BP_DPP_STEP(fminf, v, 0x111, 0xf);  // row_shr:1
+  BP_DPP_STEP(fminf, v, 0x112, 0xf);  // row_shr:2
+  BP_DPP_STEP(fminf, v, 0x114, 0xf);  // row_shr:4
+  BP_DPP_STEP(fminf, v, 0x118, 0xf);  // row_shr:8   -> lane 15 of every row holds the row's result
+  BP_DPP_STEP(fminf, v, 0x142, 0xa);  // row_bcast:15 into rows 1, 3
+  BP_DPP_STEP(fminf, v, 0x143, 0xc);  // row_bcast:31 into rows 2, 3
+  return v;
+}
+__device__ __forceinline__ float wave_max_lane63(float v) {
+  BP_DPP_STEP(fmaxf, v, 0x111, 0xf);
+  BP_DPP_STEP(fmaxf, v, 0x112, 0xf);
+  BP_DPP_STEP(fmaxf, v, 0x114, 0xf);
+  BP_DPP_STEP(fmaxf, v, 0x118, 0xf);
+  BP_DPP_STEP(fmaxf, v, 0x142, 0xa);
+  BP_DPP_STEP(fmaxf, v, 0x143, 0xc);
+  return v;
+}
+#undef BP_DPP_STEP
+
 // The same with hi rounded to nearest (the CQT operands: half the representation error of the truncating form, which
 // the log of weak bins amplifies)
 __device__ __forceinline__ void split_f16x2_rn(f32x2 v, uint32_t& hi2, uint32_t& lo2) {

@@ -183,8 +183,12 @@ constexpr int kFmTileFrames = 16;
 constexpr int kFmTilesPerLevel = (kFrames + kFmTileFrames - 1) / kFmTileFrames;  // 11
 constexpr int kFmSteps = 7;                       // k-steps (32 taps) per wave
 constexpr int kFmMaxUnits = (15 * 512 + 256 + 16 * 16) / 8;  // hop 512 (extended 44.1 kHz CQT): 7936 samples + 16 skews
-constexpr int kFmExRow = 17;
-constexpr int kFmExTile = kFmTileFrames * kFmExRow;
+// exchange between the role waves and the epilogue: layer 0 = re / im planes [frame][36 filters] (row 37), layer 1 =
+// the second K half of filters 32..35 [frame][4] plus a column that stays zero (row 5), so that the epilogue reads
+// re = L0re[fr][k] + L1re[fr][k >= 32 ? k - 32 : 4] without a branch
+constexpr int kFmL0Row = 37, kFmL0 = kFmTileFrames * kFmL0Row;
+constexpr int kFmL1Row = 5, kFmL1 = kFmTileFrames * kFmL1Row;
+constexpr int kFmExch = 2 * kFmL0 + 2 * kFmL1;  // floats
 
 __host__ __device__ constexpr int fm_copies(int hop) { return hop >= 8 ? 1 : 8 / hop; }
 __host__ __device__ constexpr int fm_copy_units(int hop) { return hop == 4 ? 40 : 36; }  // per shifted copy
@@ -248,14 +252,14 @@ __device__ __forceinline__ void fm_stage(const float* __restrict__ x, int L, int
   }
 }
 
-// segment A: NA steps from tap BASE_A into exchange slot SLOT_A; segment B (roles 2, 3): 2 steps of the
-// {re,im} 32..35 columns starting at tap BASE_B into slot SLOT_B
+// segment A: NA steps from tap BASE_A: 16 filters (COL_A ..) of plane PLANE (0 re, 1 im) of layer 0; segment B (roles
+// 2, 3): 2 steps of the {re,im} 32..35 columns starting at tap BASE_B, into layer LAYER_B
 template <int ROLE>
 struct FmRole;
-template <> struct FmRole<0> { static constexpr int NA = 7, BASE_A = 16, NB = 0, BASE_B = 0, SLOT_A = 0, SLOT_B = 0; };
-template <> struct FmRole<1> { static constexpr int NA = 7, BASE_A = 16, NB = 0, BASE_B = 0, SLOT_A = 1, SLOT_B = 0; };
-template <> struct FmRole<2> { static constexpr int NA = 5, BASE_A = 48, NB = 2, BASE_B = 64, SLOT_A = 2, SLOT_B = 4; };
-template <> struct FmRole<3> { static constexpr int NA = 5, BASE_A = 48, NB = 2, BASE_B = 128, SLOT_A = 3, SLOT_B = 5; };
+template <> struct FmRole<0> { static constexpr int NA = 7, BASE_A = 16, NB = 0, BASE_B = 0, PLANE = 0, COL_A = 0, LAYER_B = 0; };
+template <> struct FmRole<1> { static constexpr int NA = 7, BASE_A = 16, NB = 0, BASE_B = 0, PLANE = 1, COL_A = 0, LAYER_B = 0; };
+template <> struct FmRole<2> { static constexpr int NA = 5, BASE_A = 48, NB = 2, BASE_B = 64, PLANE = 0, COL_A = 16, LAYER_B = 0; };
+template <> struct FmRole<3> { static constexpr int NA = 5, BASE_A = 48, NB = 2, BASE_B = 128, PLANE = 1, COL_A = 16, LAYER_B = 1; };
 
 template <int ROLE, int HOP>
 __device__ __forceinline__ void fm_role_compute(const uint4* __restrict__ s_hi, const uint4* __restrict__ s_lo,
@@ -274,9 +278,9 @@ __device__ __forceinline__ void fm_role_compute(const uint4* __restrict__ s_hi, 
     a_hl = BP_MFMA16(ah, bl[s], a_hl);
   }
   // C: col = lane & 15 (filter), row = 4*kg + r (frame)
-  float* ea = exch + R::SLOT_A * kFmExTile + (kg * 4) * kFmExRow + t;
+  float* ea = exch + R::PLANE * kFmL0 + (kg * 4) * kFmL0Row + R::COL_A + t;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) ea[r * kFmExRow] = (a_hh[r] + (a_lh[r] + a_hl[r]) * kLoUnscale) * kFmTapUnscale;
+  for (int r = 0; r < 4; ++r) ea[r * kFmL0Row] = (a_hh[r] + (a_lh[r] + a_hl[r]) * kLoUnscale) * kFmTapUnscale;
   if constexpr (R::NB > 0) {
     f32x4 b_hh = z4, b_lh = z4, b_hl = z4;
 #pragma unroll
@@ -287,9 +291,15 @@ __device__ __forceinline__ void fm_role_compute(const uint4* __restrict__ s_hi, 
       b_lh = BP_MFMA16(al, bh[R::NA + s], b_lh);
       b_hl = BP_MFMA16(ah, bl[R::NA + s], b_hl);
     }
-    float* eb = exch + R::SLOT_B * kFmExTile + (kg * 4) * kFmExRow + t;
+    // columns 0..3 = re of filters 32..35, 4..7 = im; 8..15 carry zero weights
+    if (t < 8) {
+      const int plane = t >> 2, c = t & 3;
+      float* eb = R::LAYER_B == 0 ? exch + plane * kFmL0 + (kg * 4) * kFmL0Row + 32 + c
+                                  : exch + 2 * kFmL0 + plane * kFmL1 + (kg * 4) * kFmL1Row + c;
+      constexpr int row = R::LAYER_B == 0 ? kFmL0Row : kFmL1Row;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) eb[r * kFmExRow] = (b_hh[r] + (b_lh[r] + b_hl[r]) * kLoUnscale) * kFmTapUnscale;
+      for (int r = 0; r < 4; ++r) eb[r * row] = (b_hh[r] + (b_lh[r] + b_hl[r]) * kLoUnscale) * kFmTapUnscale;
+    }
   }
 }
 
@@ -317,27 +327,27 @@ __device__ __forceinline__ void fm_item(const float* __restrict__ x, int L, int 
   }
   lds_barrier();
 
-  // epilogue: 16 frames x 36 filters -> * sqrt(len), magnitude, log-power, tile extrema
+  // epilogue: 16 frames x 36 filters -> * sqrt(len), magnitude, log-power, tile extrema.  576 outputs = 2.25 passes of
+  // the workgroup (the third pass is wave 0 alone), branch-free inside a pass.
   float vmin = __int_as_float(0x7f800000), vmax = -__int_as_float(0x7f800000);
   const float kln2 = 0.69314718055994531f * kc.s0 * kc.s1;  // log2 -> 10 log10
-  for (int idx = threadIdx.x; idx < kFmTileFrames * kBpo; idx += kFmThreads) {
+  const int bin0 = (n_levels - 1 - level) * kBpo - 15;      // nnaudio.py:640-642
+  float* lp_tile = lp + ((int64_t)b * kFrames + t0) * n_bins + bin0;
+  const float* sl_tile = sqrt_len + bin0;
+  const float* l0re = exch;
+  const float* l0im = exch + kFmL0;
+  const float* l1re = exch + 2 * kFmL0;
+  const float* l1im = l1re + kFmL1;
+#pragma unroll
+  for (int pass = 0; pass < 3; ++pass) {
+    if (pass == 2 && role != 0) break;  // wave-uniform
+    const int idx = threadIdx.x + pass * kFmThreads;  // < 576 in every pass that runs
     const int fr = idx / kBpo, k = idx - fr * kBpo;
-    const int t = t0 + fr;
-    const int bin = (n_levels - 1 - level) * kBpo + k - 15;  // nnaudio.py:640-642
-    if (t >= kFrames || bin < 0) continue;
-    float re, im;
-    const float* e = exch + fr * kFmExRow;
-    if (k < 16) {
-      re = e[0 * kFmExTile + k];
-      im = e[1 * kFmExTile + k];
-    } else if (k < 32) {
-      re = e[2 * kFmExTile + k - 16];
-      im = e[3 * kFmExTile + k - 16];
-    } else {
-      re = e[4 * kFmExTile + k - 32] + e[5 * kFmExTile + k - 32];
-      im = e[4 * kFmExTile + k - 28] + e[5 * kFmExTile + k - 28];
-    }
-    const float sl = sqrt_len[bin];
+    const bool ok = t0 + fr < kFrames && bin0 + k >= 0;
+    const int c1 = k >= 32 ? k - 32 : 4;
+    float re = l0re[fr * kFmL0Row + k] + l1re[fr * kFmL1Row + c1];
+    float im = l0im[fr * kFmL0Row + k] + l1im[fr * kFmL1Row + c1];
+    const float sl = sl_tile[ok ? k : 15];
     re = __fmul_rn(re, sl);  // nnaudio.py:650: scale before squaring
     im = __fmul_rn(im, sl);
     // nnaudio.py:661 magnitude, signal.py:174-175 power and 10 log10: the hardware's 1-ulp sqrt and log2 (the precise
@@ -345,16 +355,13 @@ __device__ __forceinline__ void fm_item(const float* __restrict__ x, int L, int 
     const float mag = __builtin_amdgcn_sqrtf(__fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)));
     const float pw = __fmul_rn(mag, mag);
     const float v = __fmul_rn(__builtin_amdgcn_logf(__fadd_rn(pw, kc.eps)), kln2);
-    lp[((int64_t)b * kFrames + t) * n_bins + bin] = v;
-    vmin = fminf(vmin, v);
-    vmax = fmaxf(vmax, v);
+    if (ok) lp_tile[fr * n_bins + k] = v;
+    vmin = fminf(vmin, ok ? v : vmin);
+    vmax = fmaxf(vmax, ok ? v : vmax);
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    vmin = fminf(vmin, __shfl_xor(vmin, o));
-    vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-  }
-  if (lane == 0)
+  vmin = wave_min_lane63(vmin);
+  vmax = wave_max_lane63(vmax);
+  if (lane == 63)
     mmp[(((int64_t)b * n_levels + level) * kFmTilesPerLevel + tile) * 4 + role] = make_float2(vmin, vmax);
 }
 
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(kFmThreads, 4) void cqt_filterbank_mfma_kernel(
     LogConsts kc, FmGeo geo) {
   __shared__ __attribute__((aligned(16))) uint4 s_hi[kFmMaxUnits];
   __shared__ __attribute__((aligned(16))) uint4 s_lo[kFmMaxUnits];
-  __shared__ float exch[6 * kFmExTile];
+  __shared__ float exch[kFmExch];
   const int lane = threadIdx.x & 63;
   const int role = wave_id();
 
@@ -386,6 +393,7 @@ __global__ __launch_bounds__(kFmThreads, 4) void cqt_filterbank_mfma_kernel(
       bl[s] = bp_[(2 * s + 1) * 64];
     }
   }
+  for (int i = threadIdx.x; i < kFmExch; i += kFmThreads) exch[i] = 0.0f;  // layer 1's zero column stays zero
   const int per_window = geo.n_levels * kFmTilesPerLevel;
   const int n_items = n_windows * per_window;
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
