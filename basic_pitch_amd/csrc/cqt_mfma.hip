@@ -242,8 +242,15 @@ __device__ __forceinline__ void fm_stage(const float* __restrict__ x, int L, int
     for (int i = threadIdx.x; i < C * NBLK; i += kFmThreads) {
       const int c = i / NBLK, q = i - c * NBLK;
       float v[8];
+      const int g0 = t0 * HOP + 8 * q + c * HOP - 128;
+      if (g0 >= 0 && g0 + 8 <= L) {  // interior: two (dword-aligned) 16-byte loads
+        const float4 a = *reinterpret_cast<const float4*>(x + g0);
+        const float4 d = *reinterpret_cast<const float4*>(x + g0 + 4);
+        v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = d.x, v[5] = d.y, v[6] = d.z, v[7] = d.w;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = sample(8 * q + c * HOP + e);
+        for (int e = 0; e < 8; ++e) v[e] = sample(8 * q + c * HOP + e);
+      }
       uint4 hi, lo;
       split8(v, hi, lo);
       s_hi[c * fm_copy_units(HOP) + q] = hi;
