@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
             float s = 0.0f;
 #pragma unroll
             for (int dt = 0; dt < KH2; ++dt) s += qring[qb[dt] + w];
-            orow[w] = sigmoidf_exact(s + bias2);
+            orow[w] = sigmoidf_fast(s + bias2);
           }
         }
       }

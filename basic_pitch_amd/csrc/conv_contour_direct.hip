@@ -518,14 +518,14 @@ __global__ __launch_bounds__(256) void contour_conv2_kernel(const float* __restr
       }
     }
     const int t_out = r - 2;
-    if (t_out >= ta && t_out < tb && wvalid) dst[(int64_t)t_out * kFreqC] = sigmoidf_exact((acc[0].x + acc[0].y) + p.bias);
+    if (t_out >= ta && t_out < tb && wvalid) dst[(int64_t)t_out * kFreqC] = sigmoidf_fast((acc[0].x + acc[0].y) + p.bias);
 #pragma unroll
     for (int d = 0; d < 4; ++d) acc[d] = acc[d + 1];
     acc[4] = v2f{0.0f, 0.0f};
   }
   // output rows whose last input rows lie below the window (zero rows): flush what is still open
   for (int t = r_last - 1; t < tb; ++t) {
-    if (t >= ta && wvalid) dst[(int64_t)t * kFreqC] = sigmoidf_exact((acc[0].x + acc[0].y) + p.bias);
+    if (t >= ta && wvalid) dst[(int64_t)t * kFreqC] = sigmoidf_fast((acc[0].x + acc[0].y) + p.bias);
 #pragma unroll
     for (int d = 0; d < 4; ++d) acc[d] = acc[d + 1];
     acc[4] = v2f{0.0f, 0.0f};
