@@ -393,19 +393,20 @@ __global__ __launch_bounds__(kF1Threads, 2) void contour_conv1_folded_kernel(Con
 
 // ---------------------------------------------------------------------------------------------------------
 // conv2: Conv2D 8->1 5x5 + sigmoid as a march down the frames with ONE OUTPUT BIN PER LANE.
-//   * a wave owns 64 consecutive bins of a flat (window, bin) index (8 windows x 264 bins = 33 waves exactly) and a
-//     slab of frames; every row it loads its own pixel (8 channels = two 16-byte loads at a 32-byte lane stride: two
+//   * a wave owns 64 consecutive bins of a flat (window, PADDED bin) index (16 windows x 268 columns of c1 = 67 waves
+//     exactly; the 4 lanes per window on pad columns compute nothing that is stored) and a slab of frames; every row it loads its own pixel (8 channels = two 16-byte loads at a 32-byte lane stride: two
 //     instructions cover 2 KB contiguous — the 4-bin-strip version before it made every load instruction touch 64
 //     cache lines and stalled at 2.9 TB/s with the memory side alone taking 0.15 ms);
 //   * the 4 neighbours (bins -2 .. +2) come from the other lanes through a per-wave LDS row (two channel-half
-//     planes, consecutive lanes = consecutive 16-byte slots), lanes 0..3 also fetch the 2 + 2 halo pixels; bins
-//     outside [0, 264) are the zero padding of "same" (a lane's neighbour in the next window is masked);
+//     planes, consecutive lanes = consecutive 16-byte slots), lanes 0..3 also fetch the 2 + 2 halo pixels; the zero
+//     padding of "same" is c1's own pad columns, which sit between the windows in the flat index: no masks;
 //   * everything about rows is wave-uniform, so the 200 taps are scalar loads and operands of v_pk_fma_f32 (even /
 //     odd channels in the two halves of a float2); the 5 open output rows live in 5 float2 accumulators;
 //   * the next row's pixel is prefetched before the current row's 100 packed FMAs.
-constexpr int kD2Group = 8;                               // windows per flat index group
-constexpr int kD2Waves = kD2Group * kFreqC / 64;          // 33 waves per (group, slab)
-static_assert(kD2Group * kFreqC % 64 == 0, "a group of windows fills whole waves");
+constexpr int kD2Group = 16;                              // windows per flat index group
+constexpr int kD2Waves = kD2Group * kC1Row / 64;          // 67 waves per (group, slab)
+static_assert(kD2Group * kC1Row % 64 == 0, "a group of windows fills whole waves");
+static_assert(kC1Pad == 2, "the pad columns of c1 are the zero padding of the 5-tap rows");
 
 struct Conv2Params {
   const float* c1;   // [n][172][kC1Row][8]
@@ -437,24 +438,23 @@ __global__ __launch_bounds__(256) void contour_conv2_kernel(const float* __restr
   const int tb = ta + p.slab_rows < kFrames ? ta + p.slab_rows : kFrames;
 
   const int lin = seg * 64 + lane;
-  const int wl = lin / kFreqC;                 // window inside the group
-  const int bin = lin - wl * kFreqC;
+  const int wl = lin / kC1Row;                 // window inside the group
+  const int pb = lin - wl * kC1Row;            // padded bin: column of c1 (real bins are 2 .. 265)
   const int win = group * kD2Group + wl;
-  const bool wvalid = win < p.n_windows;
-  const float* src = p.c1 + (int64_t)(wvalid ? win : 0) * kC1Win + (int64_t)(kC1Pad + bin) * 8;
-  float* dst = p.out + (int64_t)(wvalid ? win : 0) * kPlaneC + bin;
-  // lanes 0..3 also fetch the halo pixels of the wave: lane 0 / 1 -> bins -2 / -1 of lane 0's pixel, lane 2 / 3 ->
-  // bins +1 / +2 of lane 63's pixel (pad columns of c1 are zero, so a halo outside the window reads zeros)
+  const bool wvalid = win < p.n_windows && pb >= kC1Pad && pb < kC1Pad + kFreqC;
+  const float* src = p.c1 + (int64_t)(win < p.n_windows ? win : 0) * kC1Win + (int64_t)pb * 8;
+  float* dst = p.out + (int64_t)(win < p.n_windows ? win : 0) * kPlaneC + (pb - kC1Pad);
+  // lanes 0..3 also fetch the halo pixels of the wave: lane 0 / 1 -> columns -2 / -1 of lane 0's pixel, lane 2 / 3 ->
+  // columns +1 / +2 of lane 63's pixel.  A real bin's neighbours are always columns of its own window's row (pads
+  // included); where the flat index would leave the row, the lane at the wave's edge is a pad lane whose result is not
+  // stored, and the column is clamped.
   const int lin_h = seg * 64 + (lane < 2 ? 0 : 63);
-  const int wl_h = lin_h / kFreqC;
-  const int bin_h = lin_h - wl_h * kFreqC + (lane < 2 ? lane - 2 : lane - 1);
+  const int wl_h = lin_h / kC1Row;
+  int pb_h = lin_h - wl_h * kC1Row + (lane < 2 ? lane - 2 : lane - 1);
+  pb_h = pb_h < 0 ? 0 : (pb_h > kC1Row - 1 ? kC1Row - 1 : pb_h);
   const int win_h = group * kD2Group + wl_h;
-  const float* src_h = p.c1 + (int64_t)(win_h < p.n_windows ? win_h : 0) * kC1Win + (int64_t)(kC1Pad + bin_h) * 8;
+  const float* src_h = p.c1 + (int64_t)(win_h < p.n_windows ? win_h : 0) * kC1Win + (int64_t)pb_h * 8;
   const int slot_h = lane < 2 ? lane : 64 + lane;  // 0, 1, 66, 67
-  // zero padding of "same": a neighbour bin outside [0, 264) contributes nothing (also masks the next window's lane)
-  bool nb_ok[5];
-#pragma unroll
-  for (int d = 0; d < 5; ++d) nb_ok[d] = (unsigned)(bin + d - 2) < (unsigned)kFreqC;
 
   float4 (*xw)[68] = xch[wv];
   v2f acc[5];  // acc[d] = output row r - 2 + d while input row r is being added
@@ -495,10 +495,10 @@ __global__ __launch_bounds__(256) void contour_conv2_kernel(const float* __restr
     for (int dw = 0; dw < 5; ++dw) {
       const float4 a = xw[0][lane + dw];
       const float4 b4 = xw[1][lane + dw];
-      x[dw][0] = nb_ok[dw] ? v2f{a.x, a.y} : v2f{0.0f, 0.0f};
-      x[dw][1] = nb_ok[dw] ? v2f{a.z, a.w} : v2f{0.0f, 0.0f};
-      x[dw][2] = nb_ok[dw] ? v2f{b4.x, b4.y} : v2f{0.0f, 0.0f};
-      x[dw][3] = nb_ok[dw] ? v2f{b4.z, b4.w} : v2f{0.0f, 0.0f};
+      x[dw][0] = v2f{a.x, a.y};
+      x[dw][1] = v2f{a.z, a.w};
+      x[dw][2] = v2f{b4.x, b4.y};
+      x[dw][3] = v2f{b4.z, b4.w};
     }
     __builtin_amdgcn_wave_barrier();  // every lane has read the row before the next one overwrites it
     // one open row after the other (the 5 accumulators side by side was measured slower: 0.130 vs 0.115 ms — the tap
