@@ -120,23 +120,30 @@ __device__ __forceinline__ void dm_block(const float* x, int len_in, float* __re
   }
 }
 
+// Persistent: a workgroup loads the 18 filter fragments once (73 KB per workgroup from L2 — four times the 17 KB of
+// signal a block stages) and walks (window, block) items.
 __global__ __launch_bounds__(kDmThreads) void decimate2_mfma_kernel(const float* __restrict__ src,
                                                                     int64_t src_stride, int len_in,
                                                                     float* __restrict__ dst,
                                                                     int64_t dst_stride, int len_out,
-                                                                    const uint4* __restrict__ hfrag) {
+                                                                    const uint4* __restrict__ hfrag, int n_windows) {
   __shared__ __attribute__((aligned(16))) uint4 s_hi[kDmUnits];
   __shared__ __attribute__((aligned(16))) uint4 s_lo[kDmUnits];
   const int lane = threadIdx.x & 63;
-  const int b = blockIdx.y;
   uint4 hh[kDmSteps], hl[kDmSteps];
 #pragma unroll
   for (int s = 0; s < kDmSteps; ++s) {
     hh[s] = hfrag[s * 64 + lane];
     hl[s] = hfrag[(kDmSteps + s) * 64 + lane];
   }
-  dm_block(src + (int64_t)b * src_stride, len_in, dst + (int64_t)b * dst_stride, len_out, blockIdx.x * kDmOutPerWg, hh,
-           hl, s_hi, s_lo);
+  const int blocks = (len_out + kDmOutPerWg - 1) / kDmOutPerWg;
+  const int n_items = n_windows * blocks;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int b = item / blocks, blk = item - b * blocks;
+    dm_block(src + (int64_t)b * src_stride, len_in, dst + (int64_t)b * dst_stride, len_out, blk * kDmOutPerWg, hh, hl,
+             s_hi, s_lo);
+    lds_barrier();  // the block's MFMAs are done with s_hi / s_lo
+  }
 }
 
 // The deep levels (<= 2740 samples per window) are one or two blocks each: as separate launches every level pays ~12 us
@@ -465,6 +472,18 @@ FmGeo make_fm_geo(bool ext) {
   return g;
 }
 
+// workgroups of the decimator resident on the device at once (occupancy x CUs), queried once
+static int dm_resident_workgroups() {
+  static const int n = [] {
+    int dev = 0, cus = 256, per_cu = 4;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decimate2_mfma_kernel, kDmThreads, 0);
+    return cus * (per_cu > 0 ? per_cu : 1);
+  }();
+  return n;
+}
+
 void launch_pyramid_mfma(const float* audio, float* pyr, const void* hfrag, int n_windows, bool ext,
                          hipStream_t stream) {
   const FmGeo g = make_fm_geo(ext);
@@ -475,9 +494,10 @@ void launch_pyramid_mfma(const float* audio, float* pyr, const void* hfrag, int 
     const float* src = (k == 1) ? audio : pyr + g.off[k - 1];
     const int64_t sstride = (k == 1) ? g.audio_stride : g.pyr_stride;
     const int lin = g.len[k - 1], lout = g.len[k];
-    dim3 grid((lout + kDmOutPerWg - 1) / kDmOutPerWg, n_windows);
-    hipLaunchKernelGGL(decimate2_mfma_kernel, grid, dim3(kDmThreads), 0, stream, src, sstride, lin,
-                       pyr + g.off[k], g.pyr_stride, lout, static_cast<const uint4*>(hfrag));
+    const int items = ((lout + kDmOutPerWg - 1) / kDmOutPerWg) * n_windows;
+    const int grid = items < dm_resident_workgroups() ? items : dm_resident_workgroups();
+    hipLaunchKernelGGL(decimate2_mfma_kernel, dim3(grid), dim3(kDmThreads), 0, stream, src, sstride, lin,
+                       pyr + g.off[k], g.pyr_stride, lout, static_cast<const uint4*>(hfrag), n_windows);
   }
   if (first_tail < g.n_levels) {
     DmTail t{};
