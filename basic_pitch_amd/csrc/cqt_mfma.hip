@@ -68,7 +68,13 @@ __device__ __forceinline__ void dm_block(const float* x, int len_in, float* __re
   const int lane = threadIdx.x & 63;
   const int wave = wave_id();
   const int in0 = 2 * o0 - 127;  // xp[p] = xz[in0 + p]
-  for (int q = threadIdx.x; q < kDmPos / 8; q += kDmThreads) {
+  // only the 32-sample rows this block's outputs live in (a short level or a level's last block needs a fraction of the
+  // 4352 positions).  Whole rows, because a row's out-of-band taps are zero WEIGHTS times whatever the slot holds: it
+  // must be finite.  Rows beyond them feed outputs that are not stored.
+  const int n_here = len_out - o0 < kDmOutPerWg ? len_out - o0 : kDmOutPerWg;
+  const int q_rows = 4 * ((n_here + 15) / 16) + 32;
+  const int q_end = q_rows < kDmPos / 8 ? q_rows : kDmPos / 8;
+  for (int q = threadIdx.x; q < q_end; q += kDmThreads) {
     float v[8];
     const int g0 = in0 + 8 * q;
     if (g0 >= 0 && g0 + 8 <= len_in) {
