@@ -281,17 +281,38 @@ template <> struct FmRole<1> { static constexpr int NA = 7, BASE_A = 16, NB = 0,
 template <> struct FmRole<2> { static constexpr int NA = 5, BASE_A = 48, NB = 2, BASE_B = 64, PLANE = 0, COL_A = 16, LAYER_B = 0; };
 template <> struct FmRole<3> { static constexpr int NA = 5, BASE_A = 48, NB = 2, BASE_B = 128, PLANE = 1, COL_A = 16, LAYER_B = 1; };
 
+// The unit of lane (t, kg) at tap offset B + 32 s + 8 kg as "a per-lane base + a compile-time constant": for HOP >= 32
+// the row skew adds 2 units per HOP samples crossed, and the 8 kg part crosses a row boundary only when (B + 32 s) mod
+// HOP = HOP - 16 and kg >= 2; so two bases (ua, and ub = ua + 2 for kg >= 2) and an immediate per step replace ~4 VALU
+// operations per fragment read.  B and 32 s are multiples of 16.
+template <int HOP>
+struct FmAddr {
+  int ua, ub;
+  __device__ __forceinline__ FmAddr(int t, int kg) {
+    ua = fm_unit<HOP>(t, 8 * kg);
+    ub = ua + (HOP >= 32 ? 2 * (kg >> 1) : 0);
+  }
+  // constant part of fm_unit<HOP>(t, off + 8 kg) - fm_unit<HOP>(t, 8 kg) for kg < 2 (off a multiple of 16)
+  static __device__ constexpr int delta(int off) {
+    if (HOP >= 32) return (off >> 3) + 2 * (off / HOP);
+    return off >> 3;
+  }
+  static __device__ constexpr bool cross(int off) { return HOP >= 32 && (off % HOP) == HOP - 16; }
+  __device__ __forceinline__ int unit(int off) const { return (cross(off) ? ub : ua) + delta(off); }
+};
+
 template <int ROLE, int HOP>
 __device__ __forceinline__ void fm_role_compute(const uint4* __restrict__ s_hi, const uint4* __restrict__ s_lo,
                                                 const uint4 (&bh)[kFmSteps], const uint4 (&bl)[kFmSteps],
                                                 float* __restrict__ exch, int lane) {
   using R = FmRole<ROLE>;
   const int t = lane & 15, kg = lane >> 4;
+  const FmAddr<HOP> addr(t, kg);
   f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 a_hh = z4, a_lh = z4, a_hl = z4;
 #pragma unroll
   for (int s = 0; s < R::NA; ++s) {
-    const int u = fm_unit<HOP>(t, R::BASE_A + 32 * s + 8 * kg);
+    const int u = addr.unit(R::BASE_A + 32 * s);
     const uint4 ah = s_hi[u], al = s_lo[u];
     a_hh = BP_MFMA16(ah, bh[s], a_hh);
     a_lh = BP_MFMA16(al, bh[s], a_lh);
@@ -305,7 +326,7 @@ __device__ __forceinline__ void fm_role_compute(const uint4* __restrict__ s_hi, 
     f32x4 b_hh = z4, b_lh = z4, b_hl = z4;
 #pragma unroll
     for (int s = 0; s < R::NB; ++s) {
-      const int u = fm_unit<HOP>(t, R::BASE_B + 32 * s + 8 * kg);
+      const int u = addr.unit(R::BASE_B + 32 * s);
       const uint4 ah = s_hi[u], al = s_lo[u];
       b_hh = BP_MFMA16(ah, bh[R::NA + s], b_hh);
       b_lh = BP_MFMA16(al, bh[R::NA + s], b_lh);
