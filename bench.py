@@ -271,7 +271,7 @@ def main() -> None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     stage = model.stage_ms()  # mean per-launch ms over the timed steps (HIP events on the kernels' stream)
-    if not args.exact_f32:
+    if not args.exact_f32 and rank == 0:
         # untimed second pass with events around every stage (same inputs, same kernels); the dominant kernel's entry
         # stays the one measured inside the timed region
         dom = {k: v for k, v in stage.items() if v > 0.0}
