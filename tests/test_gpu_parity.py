@@ -496,6 +496,35 @@ def test_predict_note_events_match_reference_golden(tmp_path):
     assert len(stem.with_suffix(".csv").read_text().strip().splitlines()) == 29
 
 
+def test_predict_many_equals_per_file_predict(tmp_path):
+    """predict_many (device resampling, windows packed across files, threaded note decoding) returns, in input order,
+    exactly what predict() returns file by file — and so the reference's 28 golden note events for the golden clip."""
+    import shutil
+
+    from basic_pitch_amd import Model
+    from basic_pitch_amd.inference import predict, predict_many
+
+    clip = os.path.join(GOLDEN, "vocadito_10.wav")
+    paths = []
+    for i in range(3):
+        q = tmp_path / f"clip_{i}.wav"
+        shutil.copy(clip, q)
+        paths.append(q)
+    m = Model(max_windows=8)
+    many = predict_many(paths, m, group=2, decode_threads=2)
+    assert len(many) == 3
+    ref_out, _, ref_events = predict(paths[0], m)
+    assert len(ref_events) == 28
+    for out, midi, events in many:
+        for k in ref_out:
+            assert np.array_equal(out[k], ref_out[k]), k
+        assert len(events) == len(ref_events)
+        for a, b in zip(events, ref_events):
+            assert a[:4] == b[:4] and list(a[4] or []) == list(b[4] or [])
+        assert midi.get_end_time() > 0
+    m.close()
+
+
 def test_ort_shim_session_runs_reference_call_pattern(cases):
     """The reference's ONNX leg, verbatim call pattern (inference.py:134-136, 173-180), against the shim: the session
     only accepts the reference's nmp.onnx (by SHA-256), so here the model bytes are faked by patching the expected
