@@ -243,25 +243,24 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint4* lds_wave_base
 template <class Br>
 __device__ __forceinline__ void raw_dma_issue(const BranchParams& p, int b, int row_first, uint4* raw, int wave,
                                               int lane) {
-  constexpr int total = kBrRows * Br::RAW_ROW;
-  for (int u0 = wave * 64; u0 < total; u0 += kBrThreads) {
-    const int u = u0 + lane;
-    if (u < total) {
-      const int rr = u / Br::RAW_ROW, cu = u - rr * Br::RAW_ROW;
-      const int row = row_first + rr;
-      if constexpr (Br::kOnset) {
-        // rows outside [-1, 172] read the all-zero pad row -1 of the padded window (bp_common.h)
-        const bool rvalid = row >= -1 && row <= kFrames;
-        const uint32_t* src = static_cast<const uint32_t*>(p.src) + (int64_t)b * kZWin +
-                              (int64_t)((rvalid ? row : -1) + 1) * kZRow + Br::RAW_W0 + 4 * cu;
-        lds_dma16(src, raw + Br::RAW_PAD + u0);
-      } else {
-        if (row >= 0 && row < kFrames) {  // rows outside the window are zeroed at the conversion
-          const float* src = static_cast<const float*>(p.src) + ((int64_t)b * kFrames + row) * kFreqC + 4 * cu;
-          lds_dma16(src, raw + Br::RAW_PAD + u0);
-        }
-      }
-    }
+  // one source row per wave (kBrRows = 4 waves): RAW_ROW units in ceil(RAW_ROW / 64) instructions, no per-lane
+  // division
+  static_assert(kBrRows == kBrThreads / 64, "one row per wave");
+  const int row = row_first + wave;  // wave-uniform
+  const float* src;
+  if constexpr (Br::kOnset) {
+    // rows outside [-1, 172] read the all-zero pad row -1 of the padded window (bp_common.h)
+    const bool rvalid = row >= -1 && row <= kFrames;
+    src = reinterpret_cast<const float*>(static_cast<const uint32_t*>(p.src) + (int64_t)b * kZWin +
+                                         (int64_t)((rvalid ? row : -1) + 1) * kZRow + Br::RAW_W0);
+  } else {
+    if (row < 0 || row >= kFrames) return;  // rows outside the window are zeroed at the conversion
+    src = static_cast<const float*>(p.src) + ((int64_t)b * kFrames + row) * kFreqC;
+  }
+  uint4* dst = raw + Br::RAW_PAD + wave * Br::RAW_ROW;
+#pragma unroll
+  for (int u0 = 0; u0 < Br::RAW_ROW; u0 += 64) {
+    if (u0 + 64 <= Br::RAW_ROW || u0 + lane < Br::RAW_ROW) lds_dma16(src + 4 * (u0 + lane), dst + u0);
   }
 }
 
@@ -329,7 +328,7 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
   constexpr int KS1 = Br::KS1, KH2 = Br::KH2, PH1 = Br::PH1, PH2 = Br::PH2;
   __shared__ __attribute__((aligned(16))) uint4 img_hi[Br::RING * Br::SLOTS];
   __shared__ __attribute__((aligned(16))) uint4 img_lo[Br::RING * Br::SLOTS];
-  __shared__ float qring[Br::QRING * KH2 * kFreqN];
+  __shared__ float qring[Br::QRING * KH2 * kFreqN + 64];  // + a scratch slot per lane for the stores that must not land
   __shared__ __attribute__((aligned(16))) uint4 raw[Br::RAW_UNITS];
 
   const int lane = threadIdx.x & 63;
@@ -397,12 +396,16 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
         const bool wvalid = w >= 0 && w < kFreqN;
         const int wc = w < 0 ? 0 : (w >= kFreqN ? kFreqN - 1 : w);
         const bool rvalid = row >= 0 && row < kFrames;  // wave-uniform
-        float* qrow = qring + ((row + 64 * Br::QRING) % Br::QRING) * (KH2 * kFreqN);
+        const int qoff = ((row + 64 * Br::QRING) % Br::QRING) * (KH2 * kFreqN);
+        float* qrow = qring + qoff;
 
         if (rvalid) {
           int rb[Br::ND];
 #pragma unroll
-          for (int d = 0; d < Br::ND; ++d) rb[d] = ((row - PH1 + d + 64 * Br::RING) % Br::RING) * Br::SLOTS;
+          for (int d = 0, r = (row - PH1 + 64 * Br::RING) % Br::RING; d < Br::ND; ++d) {  // one modulo, then wrap
+            rb[d] = r * Br::SLOTS;
+            r = r + 1 == Br::RING ? 0 : r + 1;
+          }
           const int lane_off = Br::lane_slot(wc);
           // onset: the note value of this lane's pixel (concat channel 0, models.py:305), fetched now so that its
           // latency hides behind the MFMAs; an unconditional load from a clamped address, masked where it is used (a
@@ -503,7 +506,10 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
             float q = (from_left(p0) + p1) + from_right(p2);
             if constexpr (Br::kOnset) q += (n_l * extra[i][0] + n_c * extra[i][1]) + n_r * extra[i][2];
             const int dt = DT0 * h + i;
-            if (store_ok && dt < KH2) qrow[dt * kFreqN + w] = q;
+            // unconditional store: lanes that must not write (halo pixels, the frame taps half 1 does not own) aim at a
+            // scratch slot — an exec-mask branch per store costs more issue slots than the select
+            const int at = (store_ok && dt < KH2) ? qoff + dt * kFreqN + w : Br::QRING * KH2 * kFreqN + lane;
+            qring[at] = q;
           }
         } else {
           // conv1 row outside the window: conv2 sees zeros there
@@ -524,9 +530,10 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
         const int t = r0 - PH2 + wave;
         if (t >= T0 && t < T1) {
           int qb[KH2];
+          int qr = (t - PH2 + 64 * Br::QRING) % Br::QRING;
 #pragma unroll
           for (int dt = 0; dt < KH2; ++dt)
-            qb[dt] = (((t + dt - PH2 + 64 * Br::QRING) % Br::QRING) * KH2 + dt) * kFreqN;
+            qb[dt] = (qr * KH2 + dt) * kFreqN, qr = qr + 1 == Br::QRING ? 0 : qr + 1;
           float* orow = p.out + ((int64_t)b * kFrames + t) * kFreqN;
           for (int w = lane; w < kFreqN; w += 64) {
             float s = 0.0f;
