@@ -1,27 +1,38 @@
-"""Geometry constants of the hot path — values of basic_pitch/constants.py:25-71 (reference v0.4.0)."""
+"""Geometry of the hot path, under the names the reference's callers import (basic_pitch/constants.py:25-71).
+
+Everything follows from five numbers — 22,050 Hz, a hop of 256 samples, 2-second windows, 88 semitones from 27.5 Hz,
+1 (notes) or 3 (contours) bins per semitone — which are also baked into the kernels (csrc/bp_common.h) and the C ABI
+(include/basic_pitch_amd.h: BP_AUDIO_N_SAMPLES, BP_N_FRAMES, BP_N_NOTE_BINS, BP_N_CONTOUR_BINS).
+"""
 import numpy as np
 
-SEMITONES_PER_OCTAVE = 12
+# ---- audio
+AUDIO_SAMPLE_RATE, AUDIO_N_CHANNELS, AUDIO_WINDOW_LENGTH = 22050, 1, 2  # Hz, mono, seconds per window
 FFT_HOP = 256
-NOTES_BINS_PER_SEMITONE = 1
-CONTOURS_BINS_PER_SEMITONE = 3
-ANNOTATIONS_BASE_FREQUENCY = 27.5  # lowest key on a piano
-ANNOTATIONS_N_SEMITONES = 88
-AUDIO_SAMPLE_RATE = 22050
-AUDIO_N_CHANNELS = 1
-N_FREQ_BINS_NOTES = ANNOTATIONS_N_SEMITONES * NOTES_BINS_PER_SEMITONE  # 88
-N_FREQ_BINS_CONTOURS = ANNOTATIONS_N_SEMITONES * CONTOURS_BINS_PER_SEMITONE  # 264
-AUDIO_WINDOW_LENGTH = 2  # seconds
-ANNOTATIONS_FPS = AUDIO_SAMPLE_RATE // FFT_HOP  # 86
+AUDIO_N_SAMPLES = AUDIO_WINDOW_LENGTH * AUDIO_SAMPLE_RATE - FFT_HOP  # a window is one hop short of 2 s
+assert AUDIO_N_SAMPLES == 43844
+
+# ---- time axis of the posteriorgrams
+ANNOTATIONS_FPS = AUDIO_SAMPLE_RATE // FFT_HOP
+ANNOT_N_FRAMES = AUDIO_WINDOW_LENGTH * ANNOTATIONS_FPS
 ANNOTATION_HOP = 1.0 / ANNOTATIONS_FPS
-ANNOT_N_FRAMES = ANNOTATIONS_FPS * AUDIO_WINDOW_LENGTH  # 172
-AUDIO_N_SAMPLES = AUDIO_SAMPLE_RATE * AUDIO_WINDOW_LENGTH - FFT_HOP  # 43844
+assert (ANNOTATIONS_FPS, ANNOT_N_FRAMES) == (86, 172)
+
+# ---- frequency axis: the piano range, geometric bins
+SEMITONES_PER_OCTAVE = 12
+ANNOTATIONS_N_SEMITONES, ANNOTATIONS_BASE_FREQUENCY = 88, 27.5
+NOTES_BINS_PER_SEMITONE, CONTOURS_BINS_PER_SEMITONE = 1, 3
+N_FREQ_BINS_NOTES = NOTES_BINS_PER_SEMITONE * ANNOTATIONS_N_SEMITONES
+N_FREQ_BINS_CONTOURS = CONTOURS_BINS_PER_SEMITONE * ANNOTATIONS_N_SEMITONES
+assert (N_FREQ_BINS_NOTES, N_FREQ_BINS_CONTOURS) == (88, 264)
 
 
-def _freq_bins(bins_per_semitone: int, base_frequency: float, n_semitones: int) -> np.ndarray:
-    d = 2.0 ** (1.0 / (SEMITONES_PER_OCTAVE * bins_per_semitone))
-    return base_frequency * d ** np.arange(bins_per_semitone * n_semitones)
+def _geometric_bins(per_semitone: int) -> np.ndarray:
+    # ratio first, then its powers: the note decoder compares against these values, so the arithmetic (not just the
+    # mathematics) is the reference's (constants.py:60-63)
+    ratio = 2.0 ** (1.0 / (SEMITONES_PER_OCTAVE * per_semitone))
+    return ANNOTATIONS_BASE_FREQUENCY * ratio ** np.arange(per_semitone * ANNOTATIONS_N_SEMITONES)
 
 
-FREQ_BINS_NOTES = _freq_bins(NOTES_BINS_PER_SEMITONE, ANNOTATIONS_BASE_FREQUENCY, ANNOTATIONS_N_SEMITONES)
-FREQ_BINS_CONTOURS = _freq_bins(CONTOURS_BINS_PER_SEMITONE, ANNOTATIONS_BASE_FREQUENCY, ANNOTATIONS_N_SEMITONES)
+FREQ_BINS_NOTES = _geometric_bins(NOTES_BINS_PER_SEMITONE)
+FREQ_BINS_CONTOURS = _geometric_bins(CONTOURS_BINS_PER_SEMITONE)
