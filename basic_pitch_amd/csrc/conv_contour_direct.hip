@@ -55,17 +55,41 @@ constexpr int kD1EdgeGroups = 5;                   // groups 0..4 and 61..65 see
 //            folded kernel position dependent; the image keeps two 60-bin windows per row instead of 304 bins.
 struct FullGeo {
   static constexpr int kWaves = 8, kGroups = 66, kQ = 76, kRing = 12, kStage = 3, kStageEvery = 20, kStageLag = 15;
+  static constexpr int kRowU4 = 4 * kQ;                                            // row stride of the image, 16-byte units
   static __device__ __forceinline__ int group_of(int gi) { return gi; }
   static __device__ __forceinline__ int q_of(int q) { return q; }                 // plane index of bin slot q
   static __device__ __forceinline__ int n_bins() { return kFreqC; }               // bins staged per row
   static __device__ __forceinline__ int bin_of(int i) { return i; }
+  // lane li of wave w in round k -> (frame offset, group index inside the frame): 32 consecutive (frame, group) pairs
+  static __device__ __forceinline__ bool locate(int k, int w, int li, int n_frames, int& frame, int& gi) {
+    const int pos = kWaves * 32 * k + 32 * w + li, npos = n_frames * kGroups;
+    const int posc = pos < npos ? pos : npos - 1;
+    frame = posc / kGroups;
+    gi = posc - frame * kGroups;
+    return pos < npos;
+  }
 };
+// The rim kernel's image: per row 4 phase planes of kQ = 31 units — the low rim's bin slots at 0..14, the high rim's at
+// 16..30 — and a row stride of 133 units.  Its lane mapping and these numbers come from enumerating the bank columns
+// (unit index mod 16) of every ds_read_b128 service group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32): lanes
+// 0..15 of a tile take 16 consecutive (frame, group) pairs of the LOW rim, lanes 16..31 the same pairs of the HIGH rim;
+// with 5 groups per frame and stride = 5 mod 16 the low lanes' columns are their lane numbers, the high lanes' are
+// lane + 16: 0.4 extra LDS cycles per group instead of 6.4 for "32 consecutive pairs of a 10-group frame, stride 120".
 struct EdgeGeo {
-  static constexpr int kWaves = 4, kGroups = 10, kQ = 30, kRing = 30, kStage = 5, kStageEvery = 12, kStageLag = 9;
+  static constexpr int kWaves = 4, kGroups = 10, kQ = 31, kRing = 30, kStage = 5, kStageEvery = 12, kStageLag = 9;
+  static constexpr int kRowU4 = 133;
   static __device__ __forceinline__ int group_of(int gi) { return gi < kD1EdgeGroups ? gi : gi + 56; }
-  static __device__ __forceinline__ int q_of(int q) { return q < 15 ? q : q - 46; }  // [0,15) U [61,76) -> [0,30)
+  static __device__ __forceinline__ int q_of(int q) { return q < 15 ? q : q - 45; }  // [0,15) U [61,76) -> [0,15) U [16,31)
   static __device__ __forceinline__ int n_bins() { return 80; }                   // bins [0,40) and [224,264)
   static __device__ __forceinline__ int bin_of(int i) { return i < 40 ? i : i + 184; }
+  static __device__ __forceinline__ bool locate(int k, int w, int li, int n_frames, int& frame, int& gi) {
+    const int side = li >> 4;
+    const int sp = 16 * kWaves * k + 16 * w + (li & 15), nside = n_frames * kD1EdgeGroups;
+    const int spc = sp < nside ? sp : nside - 1;
+    frame = spc / kD1EdgeGroups;
+    gi = spc - frame * kD1EdgeGroups + kD1EdgeGroups * side;
+    return sp < nside;
+  }
 };
 
 struct Conv1Params {
@@ -114,7 +138,8 @@ __device__ __forceinline__ void d1_store(float* __restrict__ dst, const f32x16& 
 template <class Geo, bool WLO>
 __global__ __launch_bounds__(Geo::kWaves * 64, Geo::kWaves / 4) void contour_conv1_kernel(Conv1Params p) {
   constexpr int kThreads = Geo::kWaves * 64;
-  constexpr int kQ = Geo::kQ, kSlots = 4 * Geo::kQ, kRing = Geo::kRing;
+  constexpr int kQ = Geo::kQ, kSlots = Geo::kRowU4, kRing = Geo::kRing;
+  static_assert(kSlots >= 4 * kQ, "a row holds the four phase planes");
   constexpr int kLoOff = kRing * kSlots;          // img[] = hi image, then lo image (uint4 units)
   constexpr int kRound = Geo::kWaves * 32;        // positions per round
   constexpr int kGroups = Geo::kGroups;
@@ -198,11 +223,9 @@ __global__ __launch_bounds__(Geo::kWaves * 64, Geo::kWaves / 4) void contour_con
       };
 
       // ---- this wave's tile: 32 consecutive positions of the item's (frame, group) list
-      const int pos = kRound * k + 32 * w + li;
-      const bool pvalid = pos < npos;
-      const int posc = pvalid ? pos : npos - 1;
-      const int prr = posc / kGroups;
-      const int pgrp = Geo::group_of(posc - prr * kGroups);   // four-bin group of the frame
+      int prr, pgi;
+      const bool pvalid = Geo::locate(k, w, li, t1 - t0, prr, pgi);
+      const int pgrp = Geo::group_of(pgi);                    // four-bin group of the frame
       const int pmf = Geo::q_of(pgrp);                        // its index inside a phase plane
       const int prow = t0 + prr;
       int lo_base[3], hi_base[3];
