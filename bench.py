@@ -58,10 +58,10 @@ HBM_PEAK_GBS = 8000.0
 
 def pmc_traffic(kernel_key: str, batch: int):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate passes, gfx950 x2 correction on the read side — profiles/r01_l_pmc.md).  PMC
+    WRITE_SIZE in separate passes, gfx950 x2 correction on the read side — profiles/r01_m_pmc.md).  PMC
     counters cannot be collected from inside the timed run, so this is the per-launch figure of the same
     command at the same batch, or None when no profile for this batch is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_l_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r01_m_pmc.json")
     if batch != 256 or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -372,7 +372,7 @@ def main() -> None:
                 "unit": "TFLOP/s",
                 "frac": achieved / c1_peak,
                 "traffic": pmc_traffic(c1_key, B) if c1_key else None,
-                "traffic_unit": "bytes per launch (PMC, profiles/r01_l_pmc.md)",
+                "traffic_unit": "bytes per launch (PMC, profiles/r01_m_pmc.md)",
                 "algorithmic_bytes_per_launch": c1_bytes,
                 "executed_mfma_tflops": c1_exec,  # incl. the 3-product split and Toeplitz padding
                 "executed_frac": c1_exec / c1_peak,
