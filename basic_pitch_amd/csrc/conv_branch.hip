@@ -568,18 +568,25 @@ __global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ lp
   const float* lpb = lp + (int64_t)b * kFrames * n_bins;
   uint32_t* zb = zp + (int64_t)b * kZWin;
   // the whole padded window is written every time (pad frames and pad words are zero: the zero padding of the
-  // harmonic stack, nn.py:73-85, and of the convolutions' frame halo)
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < kZWin; i += gridDim.x * 256) {
-    const int tp = i / kZRow, g = i - tp * kZRow - kZPadL;
+  // harmonic stack, nn.py:73-85, and of the convolutions' frame halo); four words per thread, one 16-byte store
+  static_assert(kZRow % 4 == 0 && kZPadL % 4 == 0, "a thread's four words stay in one row");
+  for (int i4 = blockIdx.x * 256 + threadIdx.x; i4 < kZWin / 4; i4 += gridDim.x * 256) {
+    const int tp = i4 / (kZRow / 4), g0 = 4 * (i4 - tp * (kZRow / 4)) - kZPadL;
     const int t = tp - 1;
-    uint32_t u = 0;
-    if (t >= 0 && t < kFrames && g >= 0 && g < n_bins) {
-      const float z = norm_bn(lpb[t * n_bins + g], mn, range, kc);
-      _Float16 hi, lo;
-      split_f16(z, hi, lo);
-      u = (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
+    uint32_t u[4] = {0u, 0u, 0u, 0u};
+    if (t >= 0 && t < kFrames && g0 + 3 >= 0 && g0 < n_bins) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int g = g0 + e;
+        if (g >= 0 && g < n_bins) {
+          const float z = norm_bn(lpb[t * n_bins + g], mn, range, kc);
+          _Float16 hi, lo;
+          split_f16(z, hi, lo);
+          u[e] = (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
+        }
+      }
     }
-    zb[i] = u;
+    *reinterpret_cast<uint4*>(zb + 4 * i4) = uint4{u[0], u[1], u[2], u[3]};
   }
 }
 
