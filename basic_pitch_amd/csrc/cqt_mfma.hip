@@ -437,9 +437,14 @@ __global__ __launch_bounds__(kFmThreads, 4) void cqt_filterbank_mfma_kernel(
   for (int i = threadIdx.x; i < kFmExch; i += kFmThreads) exch[i] = 0.0f;  // layer 1's zero column stays zero
   const int per_window = geo.n_levels * kFmTilesPerLevel;
   const int n_items = n_windows * per_window;
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int b = item / per_window;
-    const int rem = item - b * per_window;
+  // (window, item inside the window) advance by the grid stride without a division by the runtime per_window
+  int b = blockIdx.x / per_window, rem = blockIdx.x - b * per_window;
+  const int db = gridDim.x / per_window, drem = gridDim.x - db * per_window;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x, b += db, rem += drem) {
+    if (rem >= per_window) {
+      rem -= per_window;
+      ++b;
+    }
     const int level = rem / kFmTilesPerLevel;
     const int tile = rem - level * kFmTilesPerLevel;
     const float* x = (level == 0) ? audio + (int64_t)b * geo.audio_stride
