@@ -1,11 +1,13 @@
 """Audio ingest for the hot path: decode -> mono -> 22.05 kHz float32.
 
 Stands in for `librosa.load(path, sr=22050, mono=True)` at basic_pitch/inference.py:239 (librosa is
-a third-party dependency of the reference and is not available here).  Decode covers PCM / float WAV
-(the reference's test clips); downmix is the channel mean like librosa's `to_mono`; resampling is a
-polyphase FIR (scipy.signal.resample_poly).  librosa >= 0.10 resamples with soxr_hq, which cannot be
-reproduced bit-for-bit without libsoxr: posteriorgrams computed from a 44.1 kHz file therefore agree
-with the reference's golden file to ~4e-3 instead of 1e-4 (note events agree exactly) — see DESIGN.md.
+a third-party dependency of the reference and is not available here).  Downmix is the channel mean
+like librosa's `to_mono`.  Resampling follows the design of librosa's default `res_type="soxr_hq"`
+(libsoxr at SOXR_HQ: linear phase, pass-band to 0.9136 of the lower Nyquist, stop-band from that
+Nyquist, 126 dB, Kaiser-windowed sinc — 389 taps at the input rate for 2 : 1): with it the reference's
+golden posteriorgrams for its 44.1 kHz clip are reproduced inside its own atol = 1e-4.
+The same design runs on the device (csrc/audio_ingest.hip); this host copy serves the per-window
+path and checks the device one.
 """
 from __future__ import annotations
 
@@ -70,18 +72,69 @@ def to_mono(x: np.ndarray) -> np.ndarray:
     return x if x.ndim == 1 else x.mean(axis=1, dtype=np.float32) if x.shape[1] > 1 else x[:, 0]
 
 
+_SOXR_HQ_BITS = 20  # soxr_quality_spec(SOXR_HQ): 20-bit precision
+_BETA_FIT = (  # libsoxr lsx_kaiser_beta: cubic fits of the Kaiser beta over the attenuation, per octave of transition width
+    (-6.784957e-10, 1.02856e-05, 0.1087556, -0.8978365),
+    (-6.897885e-10, 1.027433e-05, 0.10876, -0.8974658),
+    (-1.000683e-09, 1.030092e-05, 0.1087677, -0.8977898),
+    (-3.654474e-10, 1.040631e-05, 0.1087085, -0.8917766),
+    (8.106988e-09, 6.983091e-06, 0.1091387, -0.9022048),
+    (9.519571e-09, 7.272678e-06, 0.1090068, -0.8890768),
+    (-5.626821e-09, 1.342186e-05, 0.1083999, -0.8565452),
+    (-9.965946e-08, 5.073548e-05, 0.1040967, -0.6822778),
+    (1.604808e-07, -5.856462e-05, 0.1185998, -1.24824),
+    (-1.511964e-07, 6.363034e-05, 0.1064627, -0.8076665),
+)
+
+
+def soxr_hq_taps(up: int, down: int) -> np.ndarray:
+    """The anti-alias / anti-image filter of an up : down rate change at the rate `orig_sr * up`, DC gain `up`.
+
+    libsoxr's SOXR_HQ recipe (soxr.c soxr_quality_spec, filter.c lsx_design_lpf / lsx_kaiser_beta / lsx_make_lpf):
+    pass-band end 1 - .05 / TO_3dB(20 bit) = 0.9136 and stop-band begin 1.0 of the lower Nyquist, 21 bit = 126.4 dB,
+    6 dB point half way, beta from libsoxr's fit, taps from its length formula rounded up to 1 (mod 4)."""
+    from scipy.special import i0
+
+    db = 20.0 * np.log10(2.0)
+    rej = _SOXR_HQ_BITS * db
+    fp = 1.0 - 0.05 / ((1.6e-6 * rej - 7.5e-4) * rej + 0.646)
+    att = (_SOXR_HQ_BITS + 1) * db
+    fn = float(max(up, down))  # Nyquist of the filter's rate in units of the lower Nyquist
+    tr_bw = 0.5 * (1.0 - fp) / fn
+    fc = 1.0 / fn - tr_bw
+    realm = np.log2(tr_bw * 0.5 / fc / 0.0005)
+    r0 = int(np.clip(int(realm), 0, 9))
+    r1 = int(np.clip(int(realm) + 1, 0, 9))
+    b0, b1 = (((c[0] * att + c[1]) * att + c[2]) * att + c[3] for c in (_BETA_FIT[r0], _BETA_FIT[r1]))
+    beta = b0 + (b1 - b0) * (realm - int(realm))
+    n = int(np.ceil((((0.0007528358 - 1.577737e-05 * beta) * beta + 0.6248022) * beta + 0.06186902) / tr_bw + 1))
+    n = (n + 2) // 4 * 4 + 1
+    z = np.arange(n, dtype=np.float64) - 0.5 * (n - 1)
+    sinc = np.where(z != 0, np.sin(fc * np.pi * z) / np.where(z != 0, np.pi * z, 1.0), fc)
+    y = z / (0.5 * (n - 1) + 0.5)
+    return sinc * i0(beta * np.sqrt(1.0 - y * y)) / i0(beta) * up
+
+
 def resample(x: np.ndarray, orig_sr: int, target_sr: int = AUDIO_SAMPLE_RATE) -> np.ndarray:
-    """Polyphase FIR resampling; output length ceil(n * target / orig) like librosa.resample."""
+    """`librosa.resample(x, orig_sr, target_sr)` with its default soxr_hq response: one zero-phase polyphase stage,
+    the signal zero outside the file, output length ceil(n * target / orig)."""
     if orig_sr == target_sr:
         return np.ascontiguousarray(x, dtype=np.float32)
     import scipy.signal
 
     fr = Fraction(int(target_sr), int(orig_sr))
-    y = scipy.signal.resample_poly(x.astype(np.float64), fr.numerator, fr.denominator)
+    up, down = fr.numerator, fr.denominator
+    h = soxr_hq_taps(up, down)
+    c = (len(h) - 1) // 2
     n_out = int(np.ceil(len(x) * target_sr / orig_sr))
+    # upfirdn output i = sum_j x[j] h[i * down - j * up]; output sample k sits at filter index k * down + c
+    lead = -c % down
+    y = scipy.signal.upfirdn(np.concatenate([np.zeros(lead), h]), x.astype(np.float64), up, down)
+    k0 = (c + lead) // down
+    y = y[k0 : k0 + n_out]
     if len(y) < n_out:
         y = np.pad(y, (0, n_out - len(y)))
-    return np.ascontiguousarray(y[:n_out], dtype=np.float32)
+    return np.ascontiguousarray(y, dtype=np.float32)
 
 
 def load(path: Union[str, pathlib.Path], sr: int = AUDIO_SAMPLE_RATE, mono: bool = True) -> Tuple[np.ndarray, int]:

@@ -51,31 +51,54 @@ def find_hipcc() -> str:
     raise RuntimeError("hipcc not found: the MI355X library cannot be built (there is no CPU fallback)")
 
 
+FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-Wall",
+    "-Wno-unused-function",
+    # the fully unrolled 63-k-step MFMA loops exceed clang's default size limit for `#pragma unroll`
+    "-mllvm",
+    "-pragma-unroll-threshold=400000",
+]
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into basic_pitch_amd/lib/libbasicpitch_amd.so."""
+    """Compile every HIP source for gfx950 into basic_pitch_amd/lib/libbasicpitch_amd.so.
+
+    One object per source under lib/obj/ (compiled in parallel, rebuilt only when the source or a shared header is
+    newer), then one link: a kernel edit costs one file's compile time."""
     if not force and not _stale():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [
-        find_hipcc(),
-        "--offload-arch=gfx950",
-        "-O3",
-        "-std=c++17",
-        "-fPIC",
-        "-shared",
-        "-Wall",
-        "-Wno-unused-function",
-        # the fully unrolled 63-k-step MFMA loops exceed clang's default size limit for `#pragma unroll`
-        "-mllvm",
-        "-pragma-unroll-threshold=400000",
-        "-o",
-        LIB_PATH + ".tmp",
-    ] + _sources()
-    if verbose:
-        print(" ".join(cmd))
+    from concurrent.futures import ThreadPoolExecutor
+
+    hipcc = find_hipcc()
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    headers = [os.path.join(CSRC, "bp_common.h"), HEADER]
+    t_hdr = max(os.path.getmtime(h) for h in headers if os.path.exists(h))
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), t_hdr):
+            return obj
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n" + res.stdout + res.stderr)
+        if verbose and res.stderr.strip():
+            print(res.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, _sources()))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp"] + objs
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 

@@ -188,7 +188,7 @@ struct bp_context {
   int64_t pcm_cap = 0, mono_cap = 0, res_cap = 0;
   double* taps_dev = nullptr;
   int taps_rate = 0;
-  ResamplePlan plan{1, 1, 0, 0, 0};
+  ResamplePlan plan{};
   float* track_out = nullptr;  // [T, 88+88+264] staging when outputs are host pointers
   int64_t track_out_cap = 0;
 
@@ -1235,10 +1235,6 @@ static int ingest(bp_handle h, const float* pcm, int64_t n_frames, int channels,
   if (h->taps_rate != sample_rate) {
     std::vector<double> taps;
     const ResamplePlan pl = make_resample_plan(sample_rate, h->rate, taps);
-    if (pl.up > 2000 || pl.down > 2000) {
-      h->err = "audio ingest: sample-rate ratio too irregular (reduced up / down factor > 2000)";
-      return BP_ERR_INVALID_ARG;
-    }
     if (h->taps_dev) BP_HIP(hipFree(h->taps_dev));
     h->taps_dev = nullptr;
     h->taps_rate = 0;

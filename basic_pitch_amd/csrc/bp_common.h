@@ -139,13 +139,19 @@ __device__ __forceinline__ float norm_bn(float lp, float mn, float range, const 
   return __fadd_rn(__fmul_rn(nrm, k.bn_a), k.bn_b);  // Mul then Add in the frozen graph: no FMA contraction
 }
 
-// rational polyphase resampler (audio_ingest.hip): scipy.signal.resample_poly's alignment for up / down
+// zero-phase rational polyphase resampler (audio_ingest.hip), libsoxr SOXR_HQ design at the rate source * up
 struct ResamplePlan {
   int up, down;
-  int n_taps;        // 2 * 10 * max(up, down) + 1
-  int n_pre_pad;     // zeros scipy prepends to the filter
-  int n_pre_remove;  // leading outputs scipy drops
+  int direct;       // 0: `table` holds the n_taps taps; 1: taps evaluated in the kernel, `table` holds the window
+  int64_t n_taps;   // odd, 1 (mod 4)
+  int64_t centre;   // (n_taps - 1) / 2: output k sits at filter index k * down + centre
+  double fc;        // 6 dB point as a fraction of the filter rate's Nyquist
+  double beta;      // Kaiser beta
+  double inv_half;  // 1 / (centre + .5): window argument per tap
+  double gain;      // up
 };
+constexpr int64_t kMaxTableTaps = (int64_t)1 << 22;  // 32 MB of float64 taps; beyond it the direct kernel
+constexpr int kWindowTable = 1 << 16;
 
 __device__ __forceinline__ float sigmoidf_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
 // the same on the hardware's 1-ulp exp2 / rcp (4 VALU operations instead of ~35; <= 2e-7 off on a value in [0, 1]):

@@ -386,18 +386,20 @@ def test_new_entry_points_reject_bad_arguments():
     buf = np.zeros(10, np.float32)
     assert lib.bp_resample(h, buf.ctypes.data, 10, 0, 44100, buf.ctypes.data, 0) == _native.BP_ERR_INVALID_ARG   # channels
     assert lib.bp_resample(h, buf.ctypes.data, 10, 1, 500, buf.ctypes.data, 0) == _native.BP_ERR_INVALID_ARG     # rate
-    assert lib.bp_resample(h, buf.ctypes.data, 10, 1, 44101, buf.ctypes.data, 0) == _native.BP_ERR_INVALID_ARG   # ratio
+    out = np.zeros(5, np.float32)
+    assert lib.bp_resample(h, buf.ctypes.data, 10, 1, 44101, out.ctypes.data, 0) == _native.BP_OK  # irregular ratio
     assert lib.bp_infer_pcm(h, buf.ctypes.data, 10, 1, 44100, None, None, None, 7) == _native.BP_ERR_INVALID_ARG  # mem_kind
-    assert b"ratio" in lib.bp_last_error(h) or b"ingest" in lib.bp_last_error(h)
+    assert b"ingest" in lib.bp_last_error(h)
     assert m.predict_tracks([np.zeros(0, np.float32)])[0]["note"].shape == (0, 88)
     m.close()
 
 
 def test_track_path_equals_windowed_path_and_golden(weights, clip_22k):
-    """Config 1 of BASELINE.json: the reference's test clip end to end.  The on-device windowing /
-    un-overlapping path must equal the reference-structured per-window path bit for bit, and both
-    must agree with the reference's golden posteriorgrams (5e-3: resampler-limited, see oracle test)."""
-    from basic_pitch_amd import Model, inference as inf
+    """Config 1 of BASELINE.json = the reference's own known-answer test (tests/test_inference.py:43-70): its
+    44.1 kHz clip end to end — host WAV decode, then downmix, soxr_hq-design resampling, windowing, CQT + CNN and
+    un-overlapping on the device — against its golden posteriorgrams at ITS tolerance, atol = 1e-4 on every element.
+    The on-device windowing / un-overlapping path must also equal the reference-structured per-window path."""
+    from basic_pitch_amd import Model, audio as A, inference as inf
 
     m = Model()
     wav = os.path.join(GOLDEN, "vocadito_10.wav")
@@ -406,9 +408,21 @@ def test_track_path_equals_windowed_path_and_golden(weights, clip_22k):
     g = np.load(os.path.join(GOLDEN, "vocadito_10_model_output.npz"))
     for k in ("note", "onset", "contour"):
         assert a[k].shape == g[k].shape
-        assert np.array_equal(a[k], b[k]), k
-        assert np.abs(a[k] - g[k]).max() <= 5e-3, (k, np.abs(a[k] - g[k]).max())
-        assert np.abs(a[k] - g[k]).mean() <= 1e-4
+        # device resampler (fp64 accumulate) vs host resampler (upfirdn): the same fp32 samples up to 1 ulp, which the
+        # per-window normalisation turns into <= 1e-5 on the posteriorgrams
+        assert np.abs(a[k] - b[k]).max() <= 2e-5, (k, np.abs(a[k] - b[k]).max())
+        for got in (a[k], b[k]):
+            assert np.abs(got - g[k]).max() <= 1e-4, (k, np.abs(got - g[k]).max())
+            assert np.abs(got - g[k]).mean() <= 2e-6
+    # bit-for-bit: device windowing / un-overlapping of given 22.05 kHz samples == host windowing + predict + unwrap
+    y = m.resample(*A.read_wav(wav))
+    t = m.predict_track(y)
+    wins, n_orig = O.window_track(y)
+    pw = m.predict(wins)
+    for k in t:
+        assert np.array_equal(t[k], O.unwrap_output(pw[k], n_orig)), k
+    for k in ("note", "onset", "contour"):
+        assert np.array_equal(t[k], a[k]), k
     # and tightly against the oracle on the identical 22.05 kHz samples
     r64 = O.run_track(clip_22k, weights, np.float64, batch=6)
     r32 = O.run_track(clip_22k, weights, np.float32, batch=6)
@@ -440,22 +454,26 @@ def test_multi_track_packing_is_bit_identical():
 
 
 def test_device_audio_ingest(weights):
-    """downmix + resampling on the device.  bp_resample must reproduce the host ingest
-    (basic_pitch_amd/audio.py = scipy.signal.resample_poly in float64, rounded to float32) for the rate pairs that
-    occur in practice, mono and multi-channel, and bp_infer_pcm must equal resample-then-bp_infer_track bit for bit."""
+    """downmix + resampling on the device.  bp_resample against oracle/soxr_oracle.py — the
+    direct-form float64 restatement of libsoxr's SOXR_HQ design, itself pinned by the reference's golden posteriorgrams
+    (tests/test_oracle_golden.py) — for the rate pairs that occur in practice, mono and multi-channel, including a
+    ratio irregular enough for the evaluate-in-place kernel; bp_infer_pcm must equal resample-then-bp_infer_track."""
     from basic_pitch_amd import Model, audio as A
+    from oracle import soxr_oracle as S
 
     m = Model(max_windows=8)
     rng = np.random.default_rng(3)
-    for sr, ch, n in ((44100, 2, 150001), (48000, 1, 96000), (16000, 3, 40000), (8000, 1, 9999), (22050, 2, 50000),
-                      (32000, 1, 1), (11025, 2, 30000)):
+    for sr, ch, n in ((44100, 2, 150001), (48000, 1, 9600), (16000, 3, 4000), (8000, 1, 999), (22050, 2, 50000),
+                      (32000, 1, 1), (11025, 2, 30000), (88200, 1, 40000), (10004, 1, 600)):
         pcm = rng.uniform(-1, 1, (n, ch)).astype(np.float32)
         t = np.arange(n) / sr
         pcm[:, 0] += 0.5 * np.sin(2 * np.pi * 440.0 * t).astype(np.float32)
-        ref = A.resample(np.ascontiguousarray(A.to_mono(pcm)), sr, 22050)
+        mono = pcm.mean(axis=1, dtype=np.float32) if ch > 1 else pcm[:, 0]
+        ref = S.resample(mono, sr, 22050)
         got = m.resample(pcm, sr)
         assert got.shape == ref.shape == (int(np.ceil(n * 22050 / sr)),), (sr, got.shape, ref.shape)
-        assert np.abs(got - ref).max() <= 2e-6, (sr, ch, np.abs(got - ref).max())
+        assert np.abs(got - ref).max() <= 1e-6, (sr, ch, np.abs(got - ref).max())
+        assert np.abs(got - A.resample(np.ascontiguousarray(mono), sr)).max() <= 1e-6, sr  # host copy of the design
     # whole-path equivalence on the reference's 44.1 kHz clip
     pcm, sr = A.read_wav(os.path.join(GOLDEN, "vocadito_10.wav"))
     a = m.predict_pcm(pcm, sr)
@@ -471,7 +489,7 @@ def test_device_audio_ingest(weights):
 
 def test_predict_note_events_match_reference_golden(tmp_path):
     """BASELINE.json north star: MIDI note events identical to the reference's on its test clip.
-    `predict()` end to end (decode + resample on the host, CQT + CNN on the MI355X, note decoding in C++)
+    `predict()` end to end (WAV decode on the host; downmix, resampling, CQT + CNN on the MI355X; note decoding in C++)
     against the reference's golden `note_events.npz`: all 28 events, every discrete field exact (start / end
     time, pitch, pitch-bend list), amplitude within the reference's own tolerance (tests/test_inference.py:
     73-76, atol 1e-4)."""

@@ -52,17 +52,73 @@ def test_windowing_known_answers(clip_22k):
     assert not wins[0][:3840].any()
 
 
-def test_oracle_reproduces_golden_posteriorgrams(weights, clip_22k):
-    """Reference: atol=1e-4 with its own (librosa/soxr) resampler.  Here the resampler is scipy's
-    polyphase FIR, which alone moves the posteriorgrams by up to ~4e-3 — so the pin is
-    5e-3 max-abs and 1e-4 mean-abs."""
+def _golden_distance(samples_22k, weights):
     g = np.load(os.path.join(GOLDEN, "vocadito_10_model_output.npz"))
-    r = O.run_track(clip_22k, weights, np.float32, batch=6)
+    r = O.run_track(samples_22k, weights, np.float32, batch=6)
+    out = {}
     for k in ("note", "onset", "contour"):
         assert r[k].shape == g[k].shape == ((787, 88) if k != "contour" else (787, 264))
-        d = np.abs(r[k] - g[k])
-        assert d.max() <= 5e-3, (k, d.max())
-        assert d.mean() <= 1e-4, (k, d.mean())
+        out[k] = np.abs(r[k] - g[k])
+    return out
+
+
+def test_oracle_reproduces_golden_posteriorgrams(weights):
+    """The reference's own known-answer test (tests/test_inference.py:66-70): vocadito_10.wav -> model_output.npz at
+    atol = 1e-4.  The oracle chain = WAV decode -> oracle/soxr_oracle.py (restatement of librosa's soxr_hq resampler)
+    -> oracle/bp_oracle.py in fp32.  Measured: 2.2e-5 / 4.6e-5 / 3.4e-5 max-abs (note / onset / contour)."""
+    from basic_pitch_amd import audio
+    from oracle import soxr_oracle as S
+
+    pcm, sr = audio.read_wav(os.path.join(GOLDEN, "vocadito_10.wav"))
+    assert sr == 44100 and pcm.shape == (401214, 1)
+    d = _golden_distance(S.resample(pcm[:, 0], sr), weights)
+    for k, v in d.items():
+        assert v.max() <= 1e-4, (k, v.max())  # the reference's own tolerance, every element
+        assert v.mean() <= 2e-6, (k, v.mean())
+
+
+def test_golden_residual_is_the_resampler(weights):
+    """The same graph oracle behind scipy's default polyphase design (Kaiser beta 5, the round-1 stand-in) is 1e-3 ..
+    4e-3 from the golden file, with >85 % of the elements still inside 1e-4: the only thing that changed between this
+    and the test above is the resampler, so the round-1 residual was the resampler and not the graph."""
+    import scipy.signal
+
+    from basic_pitch_amd import audio
+
+    pcm, sr = audio.read_wav(os.path.join(GOLDEN, "vocadito_10.wav"))
+    y = scipy.signal.resample_poly(pcm[:, 0].astype(np.float64), 1, 2).astype(np.float32)[:200607]
+    d = _golden_distance(y, weights)
+    assert 5e-4 <= d["note"].max() <= 5e-3 and 1e-3 <= d["onset"].max() <= 5e-3 and 1e-3 <= d["contour"].max() <= 5e-3
+    for k, v in d.items():
+        assert (v <= 1e-4).mean() >= 0.85, k
+
+
+def test_host_resampler_equals_soxr_restatement():
+    """basic_pitch_amd/audio.py (product, polyphase upfirdn) vs oracle/soxr_oracle.py (direct form) on the rate pairs
+    that occur in practice; length = ceil(n * 22050 / sr) (librosa.resample)."""
+    from basic_pitch_amd import audio
+    from oracle import soxr_oracle as S
+
+    fp, fs, att = S.hq_spec()
+    assert abs(fp - 0.913628) < 1e-6 and fs == 1.0 and abs(att - 126.4326) < 1e-4
+    h = S.design_lpf(fp, fs, 2.0, att)
+    assert len(h) == 389 and abs(h.sum() - 1.0) < 1e-6 and np.array_equal(h, h[::-1])
+    # frequency response of the 2 : 1 filter: flat pass-band to 0.9136 x 11025 Hz, >= 120 dB down from 11025 Hz
+    H = np.abs(np.fft.rfft(h, 1 << 16))
+    f = np.fft.rfftfreq(1 << 16, 1 / 44100.0)
+    assert np.abs(H[f <= fp * 11025] - 1.0).max() <= 2e-6
+    assert 20 * np.log10(H[f >= 11025].max()) <= -120.0
+    rng = np.random.default_rng(0)
+    for sr, n in ((44100, 30001), (48000, 2000), (16000, 1500), (8000, 999), (32000, 1), (11025, 700), (96000, 4000)):
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        a, b = audio.resample(x, sr), S.resample(x, sr)
+        assert a.shape == b.shape == (int(np.ceil(n * 22050 / sr)),), sr
+        assert np.abs(a - b).max() <= 1e-6, (sr, np.abs(a - b).max())
+    # a 1 kHz sine keeps its amplitude and phase (zero-phase filter, output k at input time k * down / up)
+    t = np.arange(44100) / 44100.0
+    y = audio.resample(np.sin(2 * np.pi * 1000 * t).astype(np.float32), 44100)
+    t2 = np.arange(22050) / 22050.0
+    assert np.abs(y[500:-500] - np.sin(2 * np.pi * 1000 * t2)[500:-500]).max() <= 1e-5
 
 
 @pytest.mark.parametrize("kind,bound", [("uniform", 2e-4), ("normal", 2e-5), ("tones", 2e-3)])
