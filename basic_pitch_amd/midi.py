@@ -2,11 +2,23 @@
 
 `basic_pitch/note_creation.py:222-267` builds a `pretty_midi.PrettyMIDI(initial_tempo=...)` with
 `Instrument(program=instrument_name_to_program("Electric Piano 1"))`, `Note(velocity, pitch, start, end)`
-and `PitchBend(pitch, time)` objects and later calls `.write(path)`.  pretty_midi is not installable
-here, so these classes carry the same attributes and `write()` emits a type-1 Standard MIDI File with
-pretty_midi's conventions (resolution 220 ticks per quarter note, tempo + 4/4 time signature on track 0,
-one track per instrument, channel 0..15 skipping 9, events ordered by tick).  Byte-level identity with
-pretty_midi's own writer (mido) is NOT pinned — there is no pretty_midi here to compare against.
+and `PitchBend(pitch, time)` objects and `inference.py:586` calls `.write(path)`.  pretty_midi (and mido, which
+does its byte encoding) are not installable here, so these classes carry the same attributes and `write()` follows
+pretty_midi 0.2.x `PrettyMIDI.write` + mido `MidiFile.save` step by step:
+
+  * type-1 file, resolution 220 ticks per quarter note;
+  * track 0: `set_tempo` (int(6e7 / (60 / (tick_scale * resolution))) us per quarter) then `time_signature` 4/4
+    (24 clocks per click, 8 notated 32nds) at tick 0, `end_of_track` one tick after the last event;
+  * one track per instrument, channel n mod 15 over 0..15 without 9: `program_change` at tick 0, per note a
+    `note_on` at its start and a `note_on` with velocity 0 at its end, per pitch bend a `pitchwheel`; stable sort by
+    (tick, class) with pretty_midi's class keys (program change < pitchwheel by value < note_on by
+    note * 256 + velocity), its note-off-before-note-on fix-up, `end_of_track` one tick after the last event;
+  * tick = int(round(time / tick_scale)), tick_scale = 60 / (tempo * resolution), Python's round-half-even;
+  * mido's encoding: delta times as variable-length quantities, running status within a track (a status byte equal
+    to the previous channel message's is omitted; any meta event resets it).
+
+tests/golden/midi/*.mid are those steps written out independently (tools/make_midi_fixtures.py) for the events the
+UNMODIFIED reference produced; `write()` must reproduce them byte for byte (tests/test_note_decode.py).
 """
 from __future__ import annotations
 
@@ -24,7 +36,7 @@ def instrument_name_to_program(name: str) -> int:
 
 class Note:
     def __init__(self, velocity: int, pitch: int, start: float, end: float):
-        self.velocity, self.pitch, self.start, self.end = int(velocity), int(pitch), float(start), float(end)
+        self.velocity, self.pitch, self.start, self.end = velocity, pitch, start, end
 
     def __repr__(self) -> str:
         return f"Note(start={self.start:f}, end={self.end:f}, pitch={self.pitch}, velocity={self.velocity})"
@@ -32,12 +44,12 @@ class Note:
 
 class PitchBend:
     def __init__(self, pitch: int, time: float):
-        self.pitch, self.time = int(pitch), float(time)
+        self.pitch, self.time = pitch, time
 
 
 class Instrument:
     def __init__(self, program: int, is_drum: bool = False, name: str = ""):
-        self.program, self.is_drum, self.name = int(program), bool(is_drum), name
+        self.program, self.is_drum, self.name = program, is_drum, name
         self.notes: List[Note] = []
         self.pitch_bends: List[PitchBend] = []
 
@@ -51,51 +63,85 @@ def _vlq(n: int) -> bytes:
     return bytes(reversed(out))
 
 
+def _chunk(tag: bytes, data: bytes) -> bytes:
+    return tag + struct.pack(">I", len(data)) + data
+
+
 class PrettyMIDI:
-    def __init__(self, initial_tempo: float = 120.0, resolution: int = 220):
-        self.resolution = int(resolution)
-        self.initial_tempo = float(initial_tempo)
+    def __init__(self, midi_file=None, resolution: int = 220, initial_tempo: float = 120.0):
+        if midi_file is not None:
+            raise NotImplementedError("reading MIDI files is not part of this stand-in")
+        self.resolution = resolution
+        self.initial_tempo = initial_tempo
+        self._tick_scale = 60.0 / (initial_tempo * resolution)  # seconds per tick
         self.instruments: List[Instrument] = []
 
-    def time_to_tick(self, t: float) -> int:
-        return int(round(t * self.resolution * self.initial_tempo / 60.0))
+    def time_to_tick(self, time: float) -> int:
+        """pretty_midi.PrettyMIDI.time_to_tick for a file with a single tempo."""
+        if not time > 0:
+            return 0
+        return int(round(float(time) / self._tick_scale))
 
     def get_end_time(self) -> float:
         ends = [n.end for i in self.instruments for n in i.notes] + [b.time for i in self.instruments for b in i.pitch_bends]
         return max(ends) if ends else 0.0
 
-    def _track(self, events) -> bytes:
-        # events: (tick, order, bytes); stable sort by tick then order (note-offs before note-ons at a tick)
+    @staticmethod
+    def _encode_track(events) -> bytes:
+        """events: (absolute tick, status byte or None for meta, payload) already in file order."""
         data = bytearray()
-        last = 0
-        for tick, _, payload in sorted(events, key=lambda e: (e[0], e[1])):
-            data += _vlq(tick - last) + payload
-            last = tick
-        data += _vlq(0) + b"\xff\x2f\x00"
-        return b"MTrk" + struct.pack(">I", len(data)) + bytes(data)
+        last_tick, running = 0, None
+        for tick, status, payload in events:
+            data += _vlq(tick - last_tick)
+            last_tick = tick
+            if status is None:
+                data += payload
+                running = None
+            else:
+                if status != running:
+                    data.append(status)
+                data += payload
+                running = status
+        return _chunk(b"MTrk", bytes(data))
 
-    def write(self, filename: str) -> None:
-        tempo_us = int(round(60_000_000.0 / self.initial_tempo))
-        tracks = [
-            self._track(
-                [
-                    (0, 0, b"\xff\x51\x03" + struct.pack(">I", tempo_us)[1:]),
-                    (0, 1, b"\xff\x58\x04\x04\x02\x18\x08"),
-                ]
-            )
-        ]
+    def _instrument_events(self, n: int, inst: "Instrument"):
         channels = [c for c in range(16) if c != 9]
+        ch = 9 if inst.is_drum else channels[n % len(channels)]
+        # (tick, class key, note, velocity, status, payload); classes as in pretty_midi's event_compare
+        ev = [(0, 6 << 16, -1, -1, 0xC0 | ch, bytes([inst.program]))]
+        for note in inst.notes:
+            for t, vel in ((note.start, int(note.velocity)), (note.end, 0)):
+                ev.append((self.time_to_tick(t), (10 << 16) + int(note.pitch) * 256 + vel, int(note.pitch), vel,
+                           0x90 | ch, bytes([int(note.pitch), vel])))
+        for b in inst.pitch_bends:
+            v = int(b.pitch) + 8192
+            if not 0 <= v <= 16383:
+                raise ValueError(f"pitch bend {b.pitch} outside [-8192, 8191]")
+            ev.append((self.time_to_tick(b.time), (7 << 16) + int(b.pitch), -1, -1, 0xE0 | ch, bytes([v & 0x7F, v >> 7])))
+        ev.sort(key=lambda e: (e[0], e[1]))  # stable, like sorted(cmp_to_key(event_compare))
+        # pretty_midi's fix-up pass over the ORIGINAL neighbours: a note-on directly followed by the note-off of the
+        # same pitch at the same tick is swapped
+        snap = list(ev)
+        for i in range(len(snap) - 1):
+            e1, e2 = snap[i], snap[i + 1]
+            if e1[0] == e2[0] and e1[2] >= 0 and e1[2] == e2[2] and e1[3] != 0 and e2[3] == 0:
+                ev[i], ev[i + 1] = e2, e1
+        out = [(e[0], e[4], e[5]) for e in ev]
+        out.append((out[-1][0] + 1, None, b"\xff\x2f\x00"))
+        return out
+
+    def to_bytes(self) -> bytes:
+        tempo = int(6e7 / (60.0 / (self._tick_scale * self.resolution)))
+        timing = [
+            (0, None, b"\xff\x51\x03" + struct.pack(">I", tempo)[1:]),
+            (0, None, b"\xff\x58\x04\x04\x02\x18\x08"),
+            (1, None, b"\xff\x2f\x00"),
+        ]
+        tracks = [self._encode_track(timing)]
         for n, inst in enumerate(self.instruments):
-            ch = 9 if inst.is_drum else channels[n % len(channels)]
-            ev = [(0, 0, bytes([0xC0 | ch, inst.program & 0x7F]))]
-            for b in inst.pitch_bends:
-                v = max(-8192, min(8191, b.pitch)) + 8192
-                ev.append((self.time_to_tick(b.time), 1, bytes([0xE0 | ch, v & 0x7F, (v >> 7) & 0x7F])))
-            for note in inst.notes:
-                ev.append((self.time_to_tick(note.start), 3, bytes([0x90 | ch, note.pitch & 0x7F, note.velocity & 0x7F])))
-                ev.append((self.time_to_tick(note.end), 2, bytes([0x90 | ch, note.pitch & 0x7F, 0])))
-            tracks.append(self._track(ev))
+            tracks.append(self._encode_track(self._instrument_events(n, inst)))
+        return _chunk(b"MThd", struct.pack(">hhh", 1, len(tracks), self.resolution)) + b"".join(tracks)
+
+    def write(self, filename) -> None:
         with open(filename, "wb") as f:
-            f.write(b"MThd" + struct.pack(">IHHH", 6, 1, len(tracks), self.resolution))
-            for t in tracks:
-                f.write(t)
+            f.write(self.to_bytes())

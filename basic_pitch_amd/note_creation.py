@@ -44,11 +44,16 @@ def _decode(
 ):
     """One call into bp_notes_decode; returns the filled event / bend arrays."""
     lib = _native.load_library()
+    # The reference takes any array-like (float64 arrays, sliced views, lists): coerce to what the C ABI needs.  When
+    # that makes a copy of note / onset, the constrained values are written back afterwards so the reference's
+    # in-place behaviour (note_creation.py:338-341) is kept; a read-only input is decoded from a copy and left alone.
+    given = {"note": frames, "onset": onsets}
+    frames = np.require(frames, np.float32, ["C", "W"])
+    onsets = np.require(onsets, np.float32, ["C", "W"])
+    contours = np.require(contours, np.float32, ["C"])
     for name, a, w in (("note", frames, N_FREQ_BINS_NOTES), ("onset", onsets, N_FREQ_BINS_NOTES), ("contour", contours, N_FREQ_BINS_CONTOURS)):
-        if not (isinstance(a, np.ndarray) and a.ndim == 2 and a.shape[1] == w and a.dtype == np.float32 and a.flags.c_contiguous):
-            raise ValueError(f"{name}: expected a C-contiguous float32 array of shape (T, {w})")
-    if not (frames.flags.writeable and onsets.flags.writeable):
-        raise ValueError("note / onset arrays must be writable (constrain_frequency zeroes them in place)")
+        if a.ndim != 2 or a.shape[1] != w:
+            raise ValueError(f"{name}: expected an array of shape (T, {w}), got {a.shape}")
     T = frames.shape[0]
     if onsets.shape[0] != T or contours.shape[0] != T:
         raise ValueError("note, onset and contour must have the same number of frames")
@@ -70,6 +75,10 @@ def _decode(
             cap_ev, bends.ctypes.data, cap_b, C.byref(n_ev), C.byref(n_b),
         )
         if rc == _native.BP_OK:
+            for name, used in (("note", frames), ("onset", onsets)):
+                orig = given[name]
+                if used is not orig and isinstance(orig, np.ndarray) and orig.flags.writeable:
+                    orig[...] = used
             return events, bends, n_ev.value
         if n_ev.value > cap_ev or n_b.value > cap_b:  # buffers too small: sizes were returned
             cap_ev, cap_b = max(cap_ev, n_ev.value), max(cap_b, n_b.value)

@@ -1,7 +1,11 @@
-"""Note decoding (posteriorgrams -> note events): the C++ decoder behind bp_notes_decode against
+"""Note decoding (posteriorgrams -> note events -> MIDI object): the C++ decoder behind bp_notes_decode and the numpy
+restatement (oracle/note_oracle.py) against
   (1) the reference's own known-answer vectors: golden posteriorgrams -> golden 28 note events, and
-  (2) the numpy restatement of basic_pitch/note_creation.py (oracle/note_oracle.py), bit for bit, on
-      synthetic posteriorgrams that exercise the melodia trick, the frequency constraints and the edges.
+  (2) tests/golden/note_fixtures.npz: the output of the UNMODIFIED reference `basic_pitch/note_creation.py`
+      (tools/make_note_fixtures.py) on every case of tests/note_cases.py — frequency constraints, melodia trick on /
+      off, infer_onsets off, pitch bends off, multiple_pitch_bends, overlapping notes, another tempo — bit for bit
+      (amplitudes as float32 bit patterns, times as float64), including the in-place mutation and the contents of
+      the PrettyMIDI object.
 Host-only code: no GPU needed (the decoder is plain C++ inside libbasicpitch_amd.so).
 """
 import os
@@ -9,6 +13,9 @@ import os
 import numpy as np
 import pytest
 
+import hashlib
+
+import note_cases
 from conftest import GOLDEN
 from oracle import note_oracle as NO
 
@@ -53,51 +60,70 @@ def test_decoder_reproduces_reference_golden_events():
     assert sorted(n.velocity for n in midi.instruments[0].notes) == sorted(int(np.round(127 * e[3])) for e in ev)
 
 
-def _synthetic(T, seed, density=0.02):
-    """Smooth random posteriorgrams with note-like ridges (so onsets, long notes and melodia leftovers exist)."""
-    rng = np.random.default_rng(seed)
-    note = rng.uniform(0, 0.25, (T, 88)).astype(np.float32)
-    onset = rng.uniform(0, 0.3, (T, 88)).astype(np.float32)
-    contour = rng.uniform(0, 0.2, (T, 264)).astype(np.float32)
-    for _ in range(max(1, int(T * density))):
-        f = int(rng.integers(0, 88))
-        t0 = int(rng.integers(0, max(1, T - 5)))
-        ln = int(rng.integers(3, 60))
-        t1 = min(T, t0 + ln)
-        amp = rng.uniform(0.31, 0.95)
-        note[t0:t1, f] = (amp + rng.normal(0, 0.03, t1 - t0)).clip(0, 1).astype(np.float32)
-        if rng.random() < 0.7:
-            onset[t0, f] = np.float32(rng.uniform(0.45, 0.99))
-        c = 3 * f + int(rng.integers(-1, 2))
-        contour[t0:t1, max(0, c - 1) : min(264, c + 2)] += np.float32(0.6)
-    return {"note": note, "onset": onset, "contour": contour.clip(0, 1)}
+_synthetic = note_cases.synthetic
 
 
-@pytest.mark.parametrize(
-    "T,seed,kw",
-    [
-        (787, 1, {}),
-        (1500, 2, {"melodia_trick": False}),
-        (1200, 3, {"min_freq": 80.0, "max_freq": 1500.0}),
-        (900, 4, {"infer_onsets": False, "min_note_len": 5}),
-        (600, 5, {"include_pitch_bends": False}),
-        (3000, 6, {"onset_thresh": 0.6, "frame_thresh": 0.25}),
-    ],
-)
-def test_decoder_equals_numpy_restatement(T, seed, kw):
+@pytest.fixture(scope="module")
+def fixtures():
+    return np.load(os.path.join(GOLDEN, "note_fixtures.npz"))
+
+
+def _fixture_events(fx, name):
+    off = fx[f"{name}/bend_offsets"]
+    ev = []
+    for i in range(len(fx[f"{name}/pitch"])):
+        b = [int(v) for v in fx[f"{name}/bend_values"][off[i] : off[i + 1]]] if fx[f"{name}/has_bends"][i] else None
+        ev.append((fx[f"{name}/start_s"][i], fx[f"{name}/end_s"][i], int(fx[f"{name}/pitch"][i]), fx[f"{name}/amplitude"][i], b))
+    return ev
+
+
+@pytest.mark.parametrize("name", list(note_cases.CASES))
+def test_decoder_and_restatement_equal_unmodified_reference(fixtures, name):
+    """Every branch of note_creation.py:52-116, 182-219, 222-511 against what the reference itself computes."""
     from basic_pitch_amd import note_creation as NC
 
-    base = _synthetic(T, seed)
-    args = dict(onset_thresh=0.5, frame_thresh=0.3, min_note_len=11)
-    args.update(kw)
-    a = {k: v.copy() for k, v in base.items()}
-    b = {k: v.copy() for k, v in base.items()}
-    _, ev = NC.model_output_to_notes(a, **args)
-    ref, _ = NO.model_output_to_notes(b, **args)
-    assert len(ref) > 0
-    _same_events(ev, ref)
+    out, args = note_cases.case_args(name)
+    assert bytes.fromhex(note_cases.digest(out)) == fixtures[f"{name}/input_sha256"].tobytes(), "input regenerated differently"
+    want = _fixture_events(fixtures, name)
+    assert len(want) > 0
+    # the numpy restatement (the oracle)
+    o = {k: v.copy() for k, v in out.items()}
+    okw = {k: v for k, v in args.items() if k not in ("multiple_pitch_bends", "midi_tempo")}
+    ref, _ = NO.model_output_to_notes(o, **okw)
+    _same_events(ref, want)
+    # the product: C++ decoder + host MIDI assembly
+    a = {k: v.copy() for k, v in out.items()}
+    midi, ev = NC.model_output_to_notes(a, **args)
+    _same_events(ev, want)
     # constrain_frequency mutates the caller's arrays in place, like the reference (note_creation.py:338-341)
-    assert np.array_equal(a["note"], b["note"]) and np.array_equal(a["onset"], b["onset"])
+    for arrs in (a, o):
+        assert hashlib.sha256(arrs["note"].tobytes() + arrs["onset"].tobytes()).digest() == fixtures[f"{name}/mutated_sha256"].tobytes()
+    # the PrettyMIDI object: instruments in insertion order, notes and pitch bends in append order
+    fx = fixtures
+    assert [midi.initial_tempo, midi.resolution] == list(fx[f"{name}/midi_tempo_resolution"])
+    assert [i.program for i in midi.instruments] == list(fx[f"{name}/inst_program"])
+    assert [len(i.notes) for i in midi.instruments] == list(fx[f"{name}/inst_n_notes"])
+    assert [len(i.pitch_bends) for i in midi.instruments] == list(fx[f"{name}/inst_n_bends"])
+    notes = [n for i in midi.instruments for n in i.notes]
+    pbs = [b for i in midi.instruments for b in i.pitch_bends]
+    assert [n.velocity for n in notes] == list(fx[f"{name}/note_velocity"])
+    assert [n.pitch for n in notes] == list(fx[f"{name}/note_pitch"])
+    assert np.array_equal(np.asarray([n.start for n in notes]), fx[f"{name}/note_start"])
+    assert np.array_equal(np.asarray([n.end for n in notes]), fx[f"{name}/note_end"])
+    assert [b.pitch for b in pbs] == list(fx[f"{name}/pb_pitch"])
+    assert np.array_equal(np.asarray([b.time for b in pbs], dtype=np.float64), fx[f"{name}/pb_time"])
+
+
+def test_reference_fixture_contains_the_reference_golden_events(fixtures):
+    """Sanity of the fixture builder: the unmodified reference run here (with stub third-party modules) reproduces the
+    reference's own committed golden events for the default parameters."""
+    g = np.load(os.path.join(GOLDEN, "vocadito_10_note_events.npz"))
+    ev = _fixture_events(fixtures, "clip_default")
+    assert len(ev) == 28
+    for i, e in enumerate(ev):
+        assert e[0] == g["start_s"][i] and e[1] == g["end_s"][i] and e[2] == g["pitch"][i]
+        assert abs(float(e[3]) - float(g["amplitude"][i])) <= 1e-5
+        assert list(e[4]) == list(g["bend_values"][g["bend_offsets"][i] : g["bend_offsets"][i + 1]])
 
 
 def test_decoder_edge_cases():
@@ -118,8 +144,35 @@ def test_decoder_edge_cases():
     _same_events(ev, ref)
     assert len(ev) >= 1 and ev[0][2] == 61
     with pytest.raises(ValueError):
-        NC.model_output_to_notes({"note": np.zeros((5, 88)), "onset": np.zeros((5, 88), np.float32),
+        NC.model_output_to_notes({"note": np.zeros((5, 87)), "onset": np.zeros((5, 88), np.float32),
                                   "contour": np.zeros((5, 264), np.float32)}, 0.5, 0.3)
+
+
+def test_decoder_accepts_what_the_reference_accepts(fixtures):
+    """The reference works on any array-like: float64 arrays, read-only arrays (np.load(mmap_mode="r")), strided views.
+    All decode to the fixture's events; writable inputs see constrain_frequency's zeroing in place."""
+    from basic_pitch_amd import note_creation as NC
+
+    out, args = note_cases.case_args("clip_freq_limits")
+    want = _fixture_events(fixtures, "clip_freq_limits")
+    f64 = {k: v.astype(np.float64) for k, v in out.items()}
+    _, ev = NC.model_output_to_notes(f64, **args)
+    _same_events(ev, want)
+    assert not f64["note"][:, :10].any() and f64["note"].dtype == np.float64  # zeroed below min_freq, in place
+    ro = {k: v.copy() for k, v in out.items()}
+    for v in ro.values():
+        v.setflags(write=False)
+    _, ev = NC.model_output_to_notes(ro, **args)
+    _same_events(ev, want)
+    assert np.array_equal(ro["note"], out["note"])
+    wide = {k: np.zeros((v.shape[0], 2 * v.shape[1]), np.float32) for k, v in out.items()}
+    views = {}
+    for k, v in out.items():
+        wide[k][:, ::2] = v
+        views[k] = wide[k][:, ::2]
+    _, ev = NC.model_output_to_notes(views, **args)
+    _same_events(ev, want)
+    assert not views["onset"][:, :10].any()
 
 
 def test_pairwise_mean_matches_numpy():
@@ -136,6 +189,74 @@ def test_pairwise_mean_matches_numpy():
         want = np.mean(out["note"][15 : 15 + ln, 30])
         _, ev = NC.model_output_to_notes(out, onset_thresh=0.5, frame_thresh=0.3, infer_onsets=False, melodia_trick=False)
         assert len(ev) == 1 and ev[0][3].tobytes() == np.float32(want).tobytes(), ln
+
+
+def _parse_smf(raw):
+    """Minimal SMF reader (running status aware): [(absolute tick, status, data bytes)] per track."""
+    import struct
+
+    assert raw[:4] == b"MThd" and struct.unpack(">I", raw[4:8])[0] == 6
+    fmt, ntracks, res = struct.unpack(">hhh", raw[8:14])
+    pos, tracks = 14, []
+    for _ in range(ntracks):
+        assert raw[pos : pos + 4] == b"MTrk"
+        ln = struct.unpack(">I", raw[pos + 4 : pos + 8])[0]
+        body, pos = raw[pos + 8 : pos + 8 + ln], pos + 8 + ln
+        i, tick, running, ev = 0, 0, None, []
+        while i < len(body):
+            d = 0
+            while True:
+                d = (d << 7) | (body[i] & 0x7F)
+                i += 1
+                if not body[i - 1] & 0x80:
+                    break
+            tick += d
+            if body[i] == 0xFF:
+                n = body[i + 2]
+                ev.append((tick, 0xFF00 | body[i + 1], bytes(body[i + 3 : i + 3 + n])))
+                i += 3 + n
+                running = None
+            else:
+                if body[i] & 0x80:
+                    running = body[i]
+                    i += 1
+                n = 1 if running >> 4 in (0xC, 0xD) else 2
+                ev.append((tick, running, bytes(body[i : i + n])))
+                i += n
+        tracks.append(ev)
+    assert pos == len(raw)
+    return fmt, res, tracks
+
+
+@pytest.mark.parametrize("name", ["clip_default", "clip_multi_bends", "clip_tempo_90", "syn_multi_bends", "syn_dense_overlaps"])
+def test_midi_bytes_follow_pretty_midi_layout(tmp_path, name):
+    """`PrettyMIDI.write` of the stand-in == tests/golden/midi/<case>.mid, the bytes pretty_midi + mido produce for the
+    reference's MIDI object by their documented algorithm (tools/make_midi_fixtures.py) — byte for byte; and the file
+    parses back to the object: tempo, 4/4, resolution 220, program 4, one track per instrument, every note and bend."""
+    from basic_pitch_amd import note_creation as NC
+
+    out, args = note_cases.case_args(name)
+    midi, events = NC.model_output_to_notes(out, **args)
+    path = tmp_path / f"{name}.mid"
+    midi.write(str(path))
+    raw = path.read_bytes()
+    assert raw == open(os.path.join(GOLDEN, "midi", f"{name}.mid"), "rb").read()
+    fmt, res, tracks = _parse_smf(raw)
+    assert (fmt, res, len(tracks)) == (1, 220, 1 + len(midi.instruments))
+    tempo = args.get("midi_tempo", 120)
+    assert tracks[0] == [(0, 0xFF51, int(6e7 / tempo).to_bytes(3, "big")), (0, 0xFF58, b"\x04\x02\x18\x08"), (1, 0xFF2F, b"")]
+    chans = [c for c in range(16) if c != 9]
+    for n, (inst, ev) in enumerate(zip(midi.instruments, tracks[1:])):
+        ch = chans[n % 15]
+        assert ev[0] == (0, 0xC0 | ch, b"\x04") and ev[-1][1] == 0xFF2F and ev[-1][0] == ev[-2][0] + 1
+        assert [e[0] for e in ev] == sorted(e[0] for e in ev)
+        ons = sorted((e[0], e[2][0], e[2][1]) for e in ev if e[1] == 0x90 | ch and e[2][1] > 0)
+        offs = sorted((e[0], e[2][0]) for e in ev if e[1] == 0x90 | ch and e[2][1] == 0)
+        tick = lambda t: int(round(t * 220 * tempo / 60.0))  # noqa: E731
+        assert ons == sorted((tick(x.start), x.pitch, x.velocity) for x in inst.notes)
+        assert offs == sorted((tick(x.end), x.pitch) for x in inst.notes)
+        bends = sorted((e[0], (e[2][0] | (e[2][1] << 7)) - 8192) for e in ev if e[1] == 0xE0 | ch)
+        assert bends == sorted((tick(b.time), int(b.pitch)) for b in inst.pitch_bends)
 
 
 def test_midi_writer_roundtrip(tmp_path):
