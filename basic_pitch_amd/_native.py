@@ -39,6 +39,7 @@ _ERR_NAMES = {
     -4: "BP_ERR_HIP",
     -5: "BP_ERR_OUT_OF_MEMORY",
     -6: "BP_ERR_UNSUPPORTED",
+    -7: "BP_ERR_BAD_AUDIO",
 }
 
 
@@ -130,6 +131,9 @@ EXPORTED_SYMBOLS = [
     "bp_note_params_default",
     "bp_notes_decode",
     "bp_notes_last_error",
+    "bp_flac_info",
+    "bp_flac_decode",
+    "bp_audio_last_error",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -207,6 +211,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bp_notes_decode.restype = C.c_int
     lib.bp_notes_last_error.argtypes = []
     lib.bp_notes_last_error.restype = C.c_char_p
+    pi = C.POINTER(C.c_int)
+    lib.bp_flac_info.argtypes = [C.c_char_p, C.c_size_t, pi, pi, pi, C.POINTER(i64)]
+    lib.bp_flac_info.restype = C.c_int
+    lib.bp_flac_decode.argtypes = [C.c_char_p, C.c_size_t, fp, i64, C.POINTER(i64)]
+    lib.bp_flac_decode.restype = C.c_int
+    lib.bp_audio_last_error.argtypes = []
+    lib.bp_audio_last_error.restype = C.c_char_p
     if path is None:
         _lib = lib
     return lib

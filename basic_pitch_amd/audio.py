@@ -137,13 +137,89 @@ def resample(x: np.ndarray, orig_sr: int, target_sr: int = AUDIO_SAMPLE_RATE) ->
     return np.ascontiguousarray(y, dtype=np.float32)
 
 
+def read_flac(path: Union[str, pathlib.Path]) -> Tuple[np.ndarray, int]:
+    """FLAC -> (float32 samples [n, channels] in [-1, 1), sample_rate): the native decoder (csrc/flac_decode.cpp),
+    CRC- and MD5-checked; value / 2^(bits - 1) like libsndfile's float read that librosa.load uses."""
+    import ctypes as C
+
+    from . import _native
+
+    lib = _native.load_library()
+    with open(path, "rb") as f:
+        data = f.read()
+    ch, sr, bits, n = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+    rc = lib.bp_flac_info(data, len(data), C.byref(ch), C.byref(sr), C.byref(bits), C.byref(n))
+    if rc != _native.BP_OK:
+        raise ValueError(f"{path}: {lib.bp_audio_last_error().decode(errors='replace')}")
+    pcm = np.empty((n.value, ch.value), dtype=np.float32)
+    got = C.c_int64()
+    rc = lib.bp_flac_decode(data, len(data), pcm.ctypes.data, n.value, C.byref(got))
+    if rc != _native.BP_OK or got.value != n.value:
+        raise ValueError(f"{path}: {lib.bp_audio_last_error().decode(errors='replace')}")
+    return pcm, sr.value
+
+
+def _read_with_optional_backend(path: str) -> Tuple[np.ndarray, int]:
+    """mp3 / ogg / m4a and anything else librosa.load would hand to soundfile or audioread: use whichever of those
+    decoders this installation has (soundfile, audioread, an `ffmpeg` executable); none ships with this package."""
+    try:
+        import soundfile  # type: ignore
+
+        x, sr = soundfile.read(path, dtype="float32", always_2d=True)
+        return np.ascontiguousarray(x), int(sr)
+    except ImportError:
+        pass
+    try:
+        import audioread  # type: ignore
+
+        with audioread.audio_open(path) as f:
+            sr, ch = f.samplerate, f.channels
+            buf = b"".join(f)
+        x = np.frombuffer(buf, dtype="<i2").astype(np.float32) / 32768.0
+        return x[: len(x) // ch * ch].reshape(-1, ch), int(sr)
+    except ImportError:
+        pass
+    import shutil
+    import subprocess
+
+    ffmpeg = shutil.which("ffmpeg")
+    if ffmpeg:
+        probe = subprocess.run([ffmpeg, "-i", path], capture_output=True, text=True).stderr
+        import re
+
+        m = re.search(r"Audio:.*?(\d+) Hz, (mono|stereo|(\d+) channels|[\d.]+)", probe)
+        if m:
+            sr = int(m.group(1))
+            ch = {"mono": 1, "stereo": 2}.get(m.group(2)) or (int(m.group(3)) if m.group(3) else 2)
+            raw = subprocess.run([ffmpeg, "-v", "error", "-i", path, "-f", "f32le", "-acodec", "pcm_f32le", "-ac", str(ch),
+                                  "-ar", str(sr), "-"], capture_output=True, check=True).stdout
+            x = np.frombuffer(raw, dtype="<f4")
+            return np.ascontiguousarray(x[: len(x) // ch * ch].reshape(-1, ch)), sr
+    raise ValueError(
+        f"{path}: not a WAV or FLAC file, and no decoder for other formats (mp3 / ogg / m4a) is installed: "
+        "basic_pitch_amd reads RIFF/WAVE and FLAC natively and uses soundfile, audioread or an ffmpeg executable when present"
+    )
+
+
+def read_audio(path: Union[str, pathlib.Path]) -> Tuple[np.ndarray, int]:
+    """Decode any supported file to (float32 [n, channels], sample_rate): the decode half of librosa.load
+    (inference.py:239).  Dispatch is by content, not extension: RIFF/WAVE and FLAC are read natively."""
+    with open(path, "rb") as f:
+        head = f.read(12)
+    if head[:4] == b"RIFF" and head[8:12] == b"WAVE":
+        return read_wav(path)
+    if head[:4] == b"fLaC" or (head[:3] == b"ID3" and str(path).lower().endswith(".flac")):
+        return read_flac(path)
+    return _read_with_optional_backend(str(path))
+
+
 def load(path: Union[str, pathlib.Path], sr: int = AUDIO_SAMPLE_RATE, mono: bool = True) -> Tuple[np.ndarray, int]:
-    """`librosa.load(path, sr=sr, mono=True)` replacement for WAV input."""
-    x, file_sr = read_wav(path)
+    """`librosa.load(path, sr=sr, mono=True)`: decode, channel mean, soxr_hq-design resampling."""
+    x, file_sr = read_audio(path)
     y = to_mono(x) if mono else x
     return resample(np.ascontiguousarray(y), file_sr, sr), sr
 
 
 def get_duration(filename: Union[str, pathlib.Path]) -> float:
-    x, sr = read_wav(filename)
+    x, sr = read_audio(filename)
     return x.shape[0] / float(sr)

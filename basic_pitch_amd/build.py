@@ -29,6 +29,7 @@ SOURCES = [
     "conv_branch.hip",
     "audio_ingest.hip",
     "note_decode.cpp",
+    "flac_decode.cpp",
 ]
 
 

@@ -26,6 +26,7 @@ import numpy as np
 from . import _native
 from . import audio as _audio
 from . import note_creation as infer
+from . import weights as _weights
 from .constants import (
     ANNOTATIONS_FPS,
     AUDIO_N_SAMPLES,
@@ -56,9 +57,11 @@ def _is_torch_cuda(x: Any) -> bool:
 class Model:
     """Drop-in for `basic_pitch.inference.Model`: load a serialized model, `predict(x) -> dict`.
 
-    `model_path` is the weights blob built from the reference's `nmp.onnx` by
-    tools/extract_weights.py (`ICASSP_2022_MODEL_PATH`).  Like the reference (inference.py:148-154)
-    an unloadable file raises ValueError; a missing HIP library / GPU raises NativeLibraryError.
+    `model_path` is the serialized model, as in the reference: its `saved_models/icassp_2022/nmp.onnx` (the 18
+    constants are extracted at load, basic_pitch_amd/weights.py; the `nmp/`, `nmp.tflite` and `nmp.mlpackage`
+    artifacts resolve to the `nmp.onnx` next to them), or the pre-extracted blob shipped with this package
+    (`ICASSP_2022_MODEL_PATH`, the default).  Like the reference (inference.py:148-154) an unloadable file raises
+    ValueError; a missing HIP library / GPU raises NativeLibraryError.
     """
 
     class MODEL_TYPES(enum.Enum):
@@ -78,10 +81,7 @@ class Model:
         self.model_type = Model.MODEL_TYPES.MI355X_HIP
         self._lib = _native.load_library()
         self._handle = C.c_void_p()
-        try:
-            blob = pathlib.Path(model_path).read_bytes()
-        except OSError as e:
-            raise ValueError(f"File {model_path} cannot be loaded: {e}") from e
+        blob = _weights.load_model_blob(model_path)  # ValueError if unloadable, like inference.py:148-154
         flags = _native.BP_FLAG_STAGE_TIMING if stage_timing else 0
         if time_dominant:  # HIP events around the dominant kernel only (2 records per chunk instead of 16)
             flags |= _native.BP_FLAG_TIME_DOMINANT
@@ -384,7 +384,7 @@ def run_inference(
 
     # decode on the host (container parsing), everything after it on the device: channel-mean downmix, resampling
     # to 22.05 kHz, the 3840-sample lead-in + windowing, CQT + CNN, un-overlapping (inference.py:239-244, 302-315)
-    pcm, file_sr = _audio.read_wav(str(audio_path))
+    pcm, file_sr = _audio.read_audio(str(audio_path))
     audio_original_length = int(-(-pcm.shape[0] * AUDIO_SAMPLE_RATE // file_sr))  # librosa.resample: ceil(n * sr / file_sr)
     unwrapped_output = model.predict_pcm(pcm, file_sr)
 
@@ -528,23 +528,30 @@ def predict_many(
     midi_tempo: float = DEFAULT_MINIMUM_MIDI_TEMPO,
     group: int = 64,
     decode_threads: Optional[int] = None,
+    return_exceptions: bool = False,
 ) -> List[Tuple[Dict[str, np.ndarray], "infer.pretty_midi.PrettyMIDI", List["infer.NoteEvent"]]]:
     """predict() (inference.py:431-506) over many files, results in input order and identical to per-file predict().
 
     The reference runs one file after the other and one window per runtime call.  Here the files of a group are
-    resampled on the device (bp_resample), their windows packed across file boundaries into full batches
-    (bp_infer_tracks), and the note decoding of a finished group (host C++, GIL released) runs on a thread pool while
-    the GPU works on the next group: one GPU produces posteriorgrams ~200 x faster than one host core decodes them.
+    decoded on a host thread pool (file read + container parsing; the device does downmix and resampling:
+    bp_resample), their windows packed across file boundaries into full batches (bp_infer_tracks), and the note
+    decoding of a finished group (host C++, GIL released) runs on the same pool while the GPU works on the next
+    group: one GPU produces posteriorgrams ~200 x faster than one host core decodes them.
+
+    `return_exceptions=True` isolates failures per file like the reference's per-file try / except
+    (inference.py:548-604): the entry of a file that cannot be read or decoded is the exception instead of a tuple.
     """
     import concurrent.futures as cf
     import os
 
-    model = model_or_model_path if isinstance(model_or_model_path, Model) else Model(model_or_model_path)
+    # a path loads the model like the reference does; a Model — or anything with its resample / predict_tracks — is used
+    model = Model(model_or_model_path) if isinstance(model_or_model_path, (str, os.PathLike)) else model_or_model_path
     if group < 1:
         raise ValueError("group must be >= 1")
     paths = [pathlib.Path(p) for p in audio_paths]
-    for p in paths:
-        verify_input_path(p)
+    if not return_exceptions:
+        for p in paths:
+            verify_input_path(p)
     min_note_len = int(np.round(minimum_note_length / 1000 * (AUDIO_SAMPLE_RATE / FFT_HOP)))
 
     def decode(model_output: Dict[str, np.ndarray]):
@@ -555,17 +562,40 @@ def predict_many(
         )
         return model_output, midi_data, note_events
 
+    def read(p: pathlib.Path):
+        verify_input_path(p)
+        return _audio.read_audio(str(p))
+
     workers = decode_threads if decode_threads else min(16, os.cpu_count() or 1)
-    futures: List["cf.Future"] = []
+    results: List[Any] = [None] * len(paths)
     with cf.ThreadPoolExecutor(max_workers=workers) as pool:
-        for g0 in range(0, len(paths), group):
-            signals = []
-            for p in paths[g0 : g0 + group]:
-                pcm, sr = _audio.read_wav(str(p))
-                signals.append(model.resample(pcm, sr))  # downmix + polyphase resampling on the device
-            for out in model.predict_tracks(signals):
-                futures.append(pool.submit(decode, out))
-        return [f.result() for f in futures]
+        groups = [list(range(g0, min(g0 + group, len(paths)))) for g0 in range(0, len(paths), group)]
+        pending = [pool.submit(read, paths[i]) for i in groups[0]] if groups else []
+        for gi, ids in enumerate(groups):
+            reads, pending = pending, []
+            if gi + 1 < len(groups):  # the next group's files are read while this one is on the GPU
+                pending = [pool.submit(read, paths[i]) for i in groups[gi + 1]]
+            signals, good = [], []
+            for i, fut in zip(ids, reads):
+                try:
+                    pcm, sr = fut.result()
+                    signals.append(model.resample(pcm, sr))  # downmix + resampling on the device
+                    good.append(i)
+                except Exception as e:
+                    if not return_exceptions:
+                        raise
+                    results[i] = e
+            for i, out in zip(good, model.predict_tracks(signals)):
+                results[i] = pool.submit(decode, out)
+        for i, r in enumerate(results):
+            if isinstance(r, cf.Future):
+                try:
+                    results[i] = r.result()
+                except Exception as e:
+                    if not return_exceptions:
+                        raise
+                    results[i] = e
+    return results
 
 
 def predict_and_save(

@@ -1,7 +1,8 @@
 """Minimal protobuf wire-format reader for ONNX files (no `onnx` package needed).
 
-Dev-time tool only: used by tools/extract_weights.py to pull the 18 constants of the
-frozen Basic Pitch graph out of the reference's `nmp.onnx`.  Field numbers follow the public
+Used by basic_pitch_amd/weights.py to pull the 18 constants of the frozen Basic Pitch graph out of the
+reference's serialized model `saved_models/icassp_2022/nmp.onnx` when `Model(path)` is given that file
+(basic_pitch/inference.py:78-154 takes the serialized model's path), and by tools/extract_weights.py.  Field numbers follow the public
 onnx.proto3 schema (ModelProto.graph=7, GraphProto.node=1/initializer=5, NodeProto.input=1/
 output=2/name=3/op_type=4/attribute=5, TensorProto.dims=1/data_type=2/name=8/raw_data=9, ...).
 """
@@ -151,10 +152,13 @@ def parse_node(buf: bytes) -> dict:
     return node
 
 
-def load_graph(path: str) -> Tuple[List[dict], Dict[str, np.ndarray]]:
+def load_graph(path_or_bytes) -> Tuple[List[dict], Dict[str, np.ndarray]]:
     """Return (nodes in graph order, {initializer name: array})."""
-    with open(path, "rb") as f:
-        model = f.read()
+    if isinstance(path_or_bytes, (bytes, bytearray)):
+        model = bytes(path_or_bytes)
+    else:
+        with open(path_or_bytes, "rb") as f:
+            model = f.read()
     graph = None
     for fno, wt, val in fields(model):
         if fno == 7:

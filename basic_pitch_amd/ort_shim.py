@@ -9,9 +9,10 @@ The reference's ONNX leg (basic_pitch/inference.py:130-146, 168-182) needs exact
 `install()` registers this module as `onnxruntime` in `sys.modules` (explicit opt-in, never done on import), after
 which `basic_pitch.inference.Model(ICASSP_2022_MODEL_PATH)` loads `nmp.onnx` "through" libbasicpitch_amd.so and the
 reference's `predict()` / `note_creation` run unchanged on top of it.  The session does not interpret
-the ONNX graph: it checks that the file IS the reference's `saved_models/icassp_2022/nmp.onnx` (SHA-256) and runs the
-hand-written kernels built for that graph with the constants extracted from it (assets/nmp_weights.bin,
-tools/extract_weights.py).  Any other model file is refused, like an unloadable model in the reference (ValueError).
+the ONNX graph op by op: it checks that the file has the structure of the reference's
+`saved_models/icassp_2022/nmp.onnx`, extracts its 18 constants (basic_pitch_amd/weights.py) and runs the hand-written
+kernels built for that graph with them.  Any other model file is refused, like an unloadable model in the reference
+(ValueError).  `NMP_ONNX_SHA256` is the digest of the v0.4.0 artifact (`session.is_reference_artifact`).
 """
 from __future__ import annotations
 
@@ -21,7 +22,8 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-NMP_ONNX_SHA256 = "2c3c1d144bfa61ad236e92e169c13535c880469a12a047d4e73451f2c059a0ec"  # reference v0.4.0 artifact
+from .weights import MAGIC, NMP_ONNX_SHA256, pack_blob, tensors_from_onnx  # noqa: E402
+
 PROVIDER = "MI355XExecutionProvider"
 INPUT_NAME = "serving_default_input_2:0"  # inference.py:178
 # ONNX output name -> key of the reference's output dict (inference.py:168-182)
@@ -48,14 +50,19 @@ class InferenceSession:
                  max_windows: int = 256, **_ignored):
         from .inference import Model  # the ctypes binding; raises NativeLibraryError without the library / GPU
 
+        import os
+        import tempfile
+
         data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(str(path_or_bytes), "rb").read()
-        digest = hashlib.sha256(data).hexdigest()
-        if digest != NMP_ONNX_SHA256:
-            raise ValueError(
-                "basic_pitch_amd.ort_shim only runs the reference's saved_models/icassp_2022/nmp.onnx "
-                f"(sha256 {NMP_ONNX_SHA256[:16]}...), got a file with sha256 {digest[:16]}..."
-            )
-        self._model = Model(device=device, max_windows=max_windows)
+        self.is_reference_artifact = hashlib.sha256(data).hexdigest() == NMP_ONNX_SHA256
+        # ValueError unless the bytes are the Basic Pitch graph (or this package's pre-extracted weights blob)
+        blob = bytes(data) if data[:8] == MAGIC else pack_blob(tensors_from_onnx(bytes(data)))
+        with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+            f.write(blob)
+        try:
+            self._model = Model(f.name, device=device, max_windows=max_windows)
+        finally:
+            os.unlink(f.name)
         self._providers = list(providers) if providers else [PROVIDER]
 
     def get_providers(self) -> List[str]:

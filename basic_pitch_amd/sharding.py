@@ -6,12 +6,16 @@ basic_pitch/inference.py:267-279).  So N GPUs = N processes, each with its own h
 disjoint set of files; the only "communication" is handing per-file results (or their paths) back to
 rank 0 on the host.  No RCCL collective touches the data path.
 
-`plan_shards` is the longest-processing-time-first assignment by sample count; `run_sharded` is the
-per-rank driver used under `python -m torch.distributed.run` (backend gloo or nccl: it only uses
-object gathers on the host).
+`plan_shards` is the longest-processing-time-first assignment by sample count; `run_sharded` is the generic
+per-rank driver (it only uses object gathers on the host); `predict_many_sharded` is the product entry point:
+`predict()` over a list of files on all GPUs of the node — the per-file loop of the reference's `predict_and_save`
+(inference.py:548-604) spread by file.  It runs either inside an existing `torch.distributed` job (one rank per GPU,
+`python -m torch.distributed.run ...`; results gathered on rank 0) or, from a plain single process, spawns one worker
+process per GPU itself.
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
 
@@ -100,3 +104,123 @@ def run_sharded(
     for part in bucket or []:
         merged.update(part or {})
     return merged
+
+
+def _file_costs(paths: Sequence[Any]) -> List[float]:
+    """Work estimate per file without decoding it: its size in bytes (0 for a missing file, which then fails in
+    `predict_many` on the rank that owns it and is reported per file)."""
+    out = []
+    for p in paths:
+        try:
+            out.append(float(os.path.getsize(p)))
+        except OSError:
+            out.append(0.0)
+    return out
+
+
+def _predict_shard(paths: Sequence[Any], indices: Sequence[int], device: int, model_or_model_path: Any,
+                   model_factory: Optional[Callable[[int], Any]], kwargs: Dict[str, Any]) -> Dict[int, Any]:
+    """One rank's share: a Model on its own GPU, `predict_many` over its files, {input index: result or exception}."""
+    from . import inference
+
+    if not indices:
+        return {}
+    if model_factory is not None:
+        model = model_factory(device)
+    elif isinstance(model_or_model_path, inference.Model):
+        model = model_or_model_path
+    else:
+        model = inference.Model(model_or_model_path, device=device)
+    res = inference.predict_many([paths[i] for i in indices], model, return_exceptions=True, **kwargs)
+    return dict(zip(indices, res))
+
+
+def _spawned_worker(rank: int, world: int, paths, model_path, model_factory, kwargs, queue) -> None:
+    try:
+        shards = plan_shards(_file_costs(paths), world)
+        queue.put((rank, _predict_shard(paths, shards[rank], rank, model_path, model_factory, kwargs)))
+    except BaseException as e:  # the parent must not wait forever for a rank that died early
+        queue.put((rank, e))
+
+
+def predict_many_sharded(
+    audio_paths: Sequence[Any],
+    model_or_model_path: Any = None,
+    gpus: Optional[int] = None,
+    model_factory: Optional[Callable[[int], Any]] = None,
+    **predict_kwargs: Any,
+) -> Optional[List[Any]]:
+    """`predict()` (inference.py:431-506) for every file of `audio_paths`, file-sharded over the GPUs of one node.
+
+    Returns, in input order, the `(model_output, midi_data, note_events)` tuple of each file — or the exception that
+    file raised (per-file isolation, like the try / except of inference.py:548-604) — identical to what
+    `predict_many` returns on one GPU.  Files are assigned by the LPT plan over their sizes (`plan_shards`), every
+    rank owns a `Model` on its own GPU and nothing but finished per-file results crosses rank boundaries (host side).
+
+      * inside a `torch.distributed` job (launched one rank per GPU): every rank calls this with the same list; the
+        rank's GPU is LOCAL_RANK; results are gathered with `gather_object` and returned on rank 0 (None elsewhere);
+      * otherwise `gpus` (default: all visible) worker processes are spawned from here, one per GPU, and the merged
+        list is returned; `gpus=1` runs in this process.
+
+    `model_factory(device_ordinal)` overrides how a rank builds its model (tests use it to stub the compute);
+    `predict_kwargs` are `predict_many`'s (thresholds, `group`, `decode_threads`, ...).
+    """
+    from . import inference
+
+    paths = [os.fspath(p) for p in audio_paths]
+    if model_or_model_path is None:
+        model_or_model_path = inference.ICASSP_2022_MODEL_PATH
+    dist = None
+    try:
+        import torch.distributed as dist_mod
+
+        if dist_mod.is_available() and dist_mod.is_initialized():
+            dist = dist_mod
+    except ImportError:
+        pass
+    if dist is not None:
+        rank, world = dist.get_rank(), dist.get_world_size()
+        shards = plan_shards(_file_costs(paths), world)
+        device = int(os.environ.get("LOCAL_RANK", rank))
+        mine = _predict_shard(paths, shards[rank], device, model_or_model_path, model_factory, predict_kwargs)
+        bucket: Optional[List[Any]] = [None] * world if rank == 0 else None
+        dist.gather_object(mine, bucket, dst=0)
+        if rank != 0:
+            return None
+        merged: Dict[int, Any] = {}
+        for part in bucket or []:
+            merged.update(part or {})
+        return [merged[i] for i in range(len(paths))]
+
+    if gpus is None:
+        import torch
+
+        gpus = max(1, torch.cuda.device_count())
+    if gpus < 1:
+        raise ValueError("gpus must be >= 1")
+    if gpus == 1:
+        mine = _predict_shard(paths, list(range(len(paths))), 0, model_or_model_path, model_factory, predict_kwargs)
+        return [mine[i] for i in range(len(paths))]
+    if isinstance(model_or_model_path, inference.Model):
+        raise ValueError("pass a model path (not a Model bound to one GPU) when spawning one worker per GPU")
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")  # HIP contexts do not survive fork
+    queue = ctx.Queue()
+    procs = [ctx.Process(target=_spawned_worker, args=(r, gpus, paths, os.fspath(model_or_model_path), model_factory,
+                                                        predict_kwargs, queue), daemon=True) for r in range(gpus)]
+    for p in procs:
+        p.start()
+    merged = {}
+    failed: Optional[BaseException] = None
+    for _ in procs:
+        rank, part = queue.get()
+        if isinstance(part, BaseException):
+            failed = failed or part
+        else:
+            merged.update(part)
+    for p in procs:
+        p.join()
+    if failed is not None:
+        raise RuntimeError(f"a shard worker failed: {failed!r}") from failed
+    return [merged[i] for i in range(len(paths))]

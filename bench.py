@@ -54,6 +54,7 @@ F1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 224 * 8 * 4  # zp read + interior c1
 D1_EXECUTED_FLOP_PER_WINDOW = 45 * 8 * 63 * 3 * (2 * 32 * 32 * 16)
 D1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 264 * 8 * 4  # zp read + c1 written
 HBM_PEAK_GBS = 8000.0
+PMC_PROFILE = "r01_m"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
 
 
 def pmc_traffic(kernel_key: str, batch: int):
@@ -61,7 +62,7 @@ def pmc_traffic(kernel_key: str, batch: int):
     WRITE_SIZE in separate passes, gfx950 x2 correction on the read side — profiles/r01_m_pmc.md).  PMC
     counters cannot be collected from inside the timed run, so this is the per-launch figure of the same
     command at the same batch, or None when no profile for this batch is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_m_pmc.json")
+    path = os.path.join(ROOT, "profiles", PMC_PROFILE + "_pmc.json")
     if batch != 256 or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -179,10 +180,10 @@ def run_tracks(args, torch, dist, world, rank, local_rank) -> None:
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.tracks} synthetic 3-minute tracks (110 windows each) through bp_infer_track, "
+                "workload": f"{args.tracks} synthetic 3-minute tracks (110 windows each) through bp_infer_tracks (64 tracks per call), "
                 "device-resident in/out, file-sharded (BASELINE.json configs[2])",
                 "tracks_per_s": args.tracks * args.steps / elapsed,
                 "shard_imbalance": shard_imbalance(lengths, shards),
@@ -199,6 +200,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustained-s", type=float, default=2.0, help="length of the extra steady-state measurement (0 = skip)")
     ap.add_argument("--exact-f32", action="store_true", help="contour conv1 on the exact-f32 MFMA kernel (A/B)")
     ap.add_argument("--workload", choices=["windows", "tracks"], default="windows",
                     help="windows: BASELINE.json configs[1] (the headline line); tracks: configs[2], whole synthetic "
@@ -217,8 +219,20 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, RCCL rendezvous on
+        # 127.0.0.1) and relay rank 0's JSON line
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -298,6 +312,49 @@ def main() -> None:
 
     ok = bool(torch.isfinite(out["note"]).all() and torch.isfinite(out["onset"]).all() and torch.isfinite(out["contour"]).all())
 
+    # Extra keys beside the contract's K-step number: (1) `sustained` — the same step back to back for >= 2 s, because
+    # K = 20..30 steps (~25 ms) end before the clock governor settles; all ranks run it together;
+    # (2) rank 0 only, the exact-f32 A/B path's rate on the same batch.
+    extras = {}
+    if not args.exact_f32 and args.sustained_s > 0:
+        sus_model = Model(device=local_rank, max_windows=B, bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k)
+        n_sus = max(args.steps, int(args.sustained_s / (elapsed / args.steps)) + 1)
+
+        def sus_step():
+            sus_model._predict_device(audio, out=out, sync=False)
+
+        for _ in range(3):
+            sus_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            sus_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t_sus = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([t_sus], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_sus = float(t.item())
+        sus_model.close()
+        extras["sustained"] = {"windows_per_s": B * n_sus * world / t_sus, "steps": n_sus, "seconds": t_sus,
+                               "ms_per_step": t_sus / n_sus * 1e3,
+                               "note": "same step, back to back, no event records; beside `value`, not instead of it"}
+    if not args.exact_f32 and rank == 0 and not (args.bf16_weights or args.ext_cqt_44k):
+        ex_model = Model(device=local_rank, max_windows=B, exact_f32_mfma=True)
+        for _ in range(2):
+            ex_model._predict_device(audio, out=out, sync=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(8):
+            ex_model._predict_device(audio, out=out, sync=False)
+        torch.cuda.synchronize()
+        extras["exact_f32_windows_per_s"] = B * 8 / (time.perf_counter() - t0)
+        ex_model.close()
+
     if rank == 0:
         total_windows = B * args.steps * world
         value = total_windows / elapsed
@@ -353,7 +410,9 @@ def main() -> None:
             "vs_baseline": None,
             # fp32 data and accumulation; matrix products on f16 hi+lo operand pairs (22 bits); --bf16-weights: conv
             # weights rounded to bf16 (one f16 operand), activations and CQT unchanged
-            "dtype": "bf16 weights / f32" if args.bf16_weights else "f32",
+            "dtype": ("f32 I/O + accumulate, bf16-rounded weights as single f16 MFMA operands, split-f16 activations" if args.bf16_weights
+                      else "exact f32 MFMA (A/B path)" if args.exact_f32
+                      else "f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands"),
             "data": "synthetic",
             "config": {
                 "workload": f"batch={B} synthetic uniform[-1,1) 2 s @ 22.05 kHz mono windows per GPU, "
@@ -372,7 +431,7 @@ def main() -> None:
                 "unit": "TFLOP/s",
                 "frac": achieved / c1_peak,
                 "traffic": pmc_traffic(c1_key, B) if c1_key else None,
-                "traffic_unit": "bytes per launch (PMC, profiles/r01_m_pmc.md)",
+                "traffic_unit": "bytes per launch (PMC, profiles/%s_pmc.md)" % PMC_PROFILE,
                 "algorithmic_bytes_per_launch": c1_bytes,
                 "executed_mfma_tflops": c1_exec,  # incl. the 3-product split and Toeplitz padding
                 "executed_frac": c1_exec / c1_peak,
@@ -395,18 +454,23 @@ def main() -> None:
             # both of its rooflines; algorithmic 79,425,024 FLOP and 387,968 B (audio in + 172x309 fp32 out) per window
             cqt_ms = stage["pyramid"] + stage["filterbank"]
             cqt_rate = B / (cqt_ms * 1e-3)
+            # ceilings per window: HBM 387,968 B at 8 TB/s; split-f16 MFMA = 3 products x the dense matrices the two
+            # kernels execute (decimators 22.4 MFLOP, filterbank 57.1 MFLOP clipped to the kernels' support) at the
+            # 2.5 PFLOP/s f16 peak.  The matrix ceiling is the lower (binding) one.
+            cqt_mfma_flop = 3 * (22_361_088 + 57_063_936)
             line["cqt_stage"] = {
                 "ms": cqt_ms,
                 "windows_per_s": cqt_rate,
-                "fp32_fraction": 79_425_024 * cqt_rate / (F32_MFMA_PEAK_TFLOPS * 1e12),
                 "hbm_fraction": 387_968 * cqt_rate / (HBM_PEAK_GBS * 1e9),
-                "binding": "fp32 direct-form FLOPs (the HBM roofline of 20.6 M windows/s is out of reach of this "
-                           "algorithm in fp32: SURVEY.md 8(d))",
+                "mfma_split_f16_fraction": cqt_mfma_flop * cqt_rate / (F16_MFMA_PEAK_TFLOPS * 1e12),
+                "binding": "split-f16 MFMA (3 products per multiply): its ceiling, 10.5 M windows/s, lies below the HBM "
+                           "ceiling of 20.6 M windows/s",
+                "algorithmic_bytes_per_window": 387_968,
+                "algorithmic_flop_per_window": 79_425_024,
             }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
-        elif not args.no_cpu_baseline:
-            line["cpu_baseline"] = None  # measured at N=1 only
+        line.update(extras)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()  # rank 0's host cores, after the timed region, for any N
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -49,7 +49,8 @@ typedef enum bp_status {
   BP_ERR_NO_DEVICE = -3,     /* no usable gfx950 device / HIP runtime failure at create */
   BP_ERR_HIP = -4,           /* a HIP call failed; see bp_last_error */
   BP_ERR_OUT_OF_MEMORY = -5,
-  BP_ERR_UNSUPPORTED = -6
+  BP_ERR_UNSUPPORTED = -6,
+  BP_ERR_BAD_AUDIO = -7      /* undecodable audio file (reference: librosa.load raises; inference.py:239) */
 } bp_status;
 
 /* where `audio` / output pointers live */
@@ -142,18 +143,37 @@ int bp_infer_tracks(bp_handle h, int64_t n_tracks, const float* const* samples, 
  * Replaces: the decode-side tail of librosa.load(path, sr=22050, mono=True) (inference.py:239) for PCM that is
  * already decoded: channel-mean downmix (librosa.to_mono) + rational polyphase resampling to 22.05 kHz, on the
  * device.  `pcm` = interleaved float32 [n_frames][channels] at `sample_rate` Hz (host or device per mem_kind).
- * The resampler is scipy.signal.resample_poly's default design (librosa's soxr_hq needs libsoxr: DESIGN.md §2).
+ * The resampler has the response of librosa's default res_type "soxr_hq" (libsoxr's SOXR_HQ design restated: linear
+ * phase, pass-band to 0.9136 of the lower Nyquist, 126 dB from that Nyquist on; one zero-phase polyphase stage with
+ * float64 taps and accumulation — audio_ingest.hip); with it the reference's golden posteriorgrams for
+ * its 44.1 kHz clip are met at its own atol = 1e-4.
  *   bp_resampled_length  ceil(n_frames * 22050 / sample_rate) samples (librosa.resample's output length)
  *   bp_resample          the mono 22.05 kHz signal itself -> out22k [bp_resampled_length] (host or device)
  *   bp_infer_pcm         bp_resample + bp_infer_track without the signal leaving the device; outputs as
  *                        bp_infer_track with T = bp_track_n_frames(bp_resampled_length(n_frames, sample_rate))
- * Errors: BP_ERR_INVALID_ARG for channels < 1, sample_rate < 1000 or ratios whose reduced up / down exceed 2000.
+ * Errors: BP_ERR_INVALID_ARG for channels < 1 or > 64, sample_rate outside [1000, 768000].  Any rate ratio is
+ * accepted (irregular ones evaluate the filter taps in the kernel instead of from a table).
  */
 int64_t bp_resampled_length(int64_t n_frames, int sample_rate);
 int bp_resample(bp_handle h, const float* pcm, int64_t n_frames, int channels, int sample_rate, float* out22k,
                 int mem_kind);
 int bp_infer_pcm(bp_handle h, const float* pcm, int64_t n_frames, int channels, int sample_rate, float* note,
                  float* onset, float* contour, int mem_kind);
+
+/*
+ * Replaces: the decode step of librosa.load for FLAC input (inference.py:239; README.md:182-189 lists .flac) — host
+ * code, no handle, thread-safe.  `file` = the whole file in memory.
+ *   bp_flac_info    channels, sample rate, bits per sample and frame count from STREAMINFO (frames are counted by
+ *                   decoding when STREAMINFO leaves the count at 0)
+ *   bp_flac_decode  interleaved float32 [n_frames][channels] in [-1, 1) (value / 2^(bits-1), libsndfile's float
+ *                   conversion) into pcm[capacity_frames][channels]; verifies the CRC-8 / CRC-16 of every frame
+ *                   and the MD5 of the decoded samples against STREAMINFO
+ * Errors: BP_ERR_BAD_AUDIO (message from bp_audio_last_error, thread-local), BP_ERR_INVALID_ARG.
+ */
+int bp_flac_info(const void* file, size_t nbytes, int* channels, int* sample_rate, int* bits_per_sample,
+                 int64_t* n_frames);
+int bp_flac_decode(const void* file, size_t nbytes, float* pcm, int64_t capacity_frames, int64_t* n_frames);
+const char* bp_audio_last_error(void);
 
 /* ceil((n_samples + 3840) / 36164) windows (inference.py:207,242); 0 for n_samples <= 0 */
 int64_t bp_track_n_windows(int64_t n_samples);

@@ -1,0 +1,93 @@
+"""Decode side of `librosa.load` (inference.py:239): the native FLAC decoder (csrc/flac_decode.cpp, host C++) and the
+read_audio dispatch.  CPU only.
+
+Pins: (1) the worked example of the FLAC specification itself (RFC 9639, appendix D.1: a complete one-frame file whose
+decoded samples the RFC states) — a known answer from outside this repo, with live CRC-8 / CRC-16 / MD5 checks;
+(2) WAV <-> FLAC pairs: files coded by the test-side encoder (tests/flac_writer.py, every subframe type / stereo mode /
+residual coding) decode to exactly the PCM they were made from, including an excerpt of the reference's test clip."""
+import os
+
+import numpy as np
+import pytest
+
+import flac_writer as FW
+from conftest import GOLDEN
+
+
+def test_rfc9639_example_file(tmp_path):
+    """RFC 9639 D.1 "Decoding Example 1": 16-bit stereo 44.1 kHz, one frame of one sample, verbatim subframes with
+    wasted bits; the RFC gives the decoded samples as 25588 (left) and 10416 (right)."""
+    from basic_pitch_amd import audio
+
+    data = bytes.fromhex(
+        "664c6143" "80000022" "10001000" "00000f00000f" "0ac442f000000001" "3e84b41807dc690307586a3dad1a2e0f"
+        "fff869180000bf" "0358fd03128b" "aa9a"
+    )
+    p = tmp_path / "rfc.flac"
+    p.write_bytes(data)
+    x, sr = audio.read_audio(p)
+    assert sr == 44100 and x.shape == (1, 2) and x.dtype == np.float32
+    assert (x[0] * 32768).tolist() == [25588.0, 10416.0]
+    # every integrity check is live: flip one bit anywhere in the frame or the MD5 and the file is rejected
+    for pos in (0x1A, 0x2C, 0x30, 0x33, 0x38):
+        bad = bytearray(data)
+        bad[pos] ^= 0x04
+        p.write_bytes(bytes(bad))
+        with pytest.raises(ValueError):
+            audio.read_audio(p)
+
+
+@pytest.mark.parametrize(
+    "bits,ch,sr,n,bs",
+    [(16, 1, 44100, 5000, 1152), (16, 2, 44100, 9000, 1152), (24, 2, 48000, 4000, 576), (8, 1, 8000, 3000, 192),
+     (16, 3, 22050, 2500, 1000), (16, 2, 12345, 700, 300), (20, 2, 96000, 2000, 4096), (12, 1, 16000, 1200, 256)],
+)
+def test_flac_round_trip(tmp_path, bits, ch, sr, n, bs):
+    from basic_pitch_amd import audio
+
+    rng = np.random.default_rng(bits * 100 + ch)
+    t = np.arange(n) / sr
+    x = np.stack([0.4 * np.sin(2 * np.pi * 220 * (c + 1) * t) + 0.05 * rng.standard_normal(n) for c in range(ch)], 1)
+    full = 1 << (bits - 1)
+    pcm = np.clip(np.round(x * full), -full, full - 1).astype(np.int64)
+    pcm[100:400] = 0                                   # constant subframes
+    pcm[1200:1500] = (pcm[1200:1500] >> 3) << 3        # wasted bits
+    pcm[50] = -full                                    # extreme value
+    data = FW.encode(pcm, sr, bits, blocksize=bs, id3=(ch == 3), total_in_header=(bits != 8))
+    p = tmp_path / "t.flac"
+    p.write_bytes(data)
+    y, sr2 = audio.read_audio(p)
+    assert sr2 == sr and y.shape == (n, ch)
+    assert np.array_equal(y, (pcm / float(full)).astype(np.float32))
+    assert abs(audio.get_duration(p) - n / sr) < 1e-12
+    # truncation and corruption are errors, not silence
+    p.write_bytes(data[: len(data) - 7])
+    with pytest.raises(ValueError):
+        audio.read_audio(p)
+    bad = bytearray(data)
+    bad[len(data) // 2] ^= 0x10
+    p.write_bytes(bytes(bad))
+    with pytest.raises(ValueError):
+        audio.read_audio(p)
+
+
+def test_wav_flac_pair_of_the_reference_clip():
+    """tests/golden/vocadito_10_excerpt.flac (tools/make_flac_fixture.py) == seconds 2-3 of vocadito_10.wav."""
+    from basic_pitch_amd import audio
+
+    wav, sr = audio.read_wav(os.path.join(GOLDEN, "vocadito_10.wav"))
+    fl, sr2 = audio.read_audio(os.path.join(GOLDEN, "vocadito_10_excerpt.flac"))
+    assert sr2 == sr == 44100 and fl.shape == (44100, 1)
+    assert np.array_equal(fl, wav[2 * sr : 3 * sr])
+    a, _ = audio.load(os.path.join(GOLDEN, "vocadito_10_excerpt.flac"))
+    assert a.shape == (22050,) and np.array_equal(a, audio.resample(wav[2 * sr : 3 * sr, 0], sr))
+
+
+def test_unknown_container_is_a_clear_error(tmp_path):
+    from basic_pitch_amd import audio
+
+    p = tmp_path / "x.mp3"
+    p.write_bytes(b"\xff\xfb\x90\x00" + b"\0" * 400)
+    with pytest.raises((ValueError, RuntimeError)) as e:
+        audio.read_audio(p)
+    assert "mp3" in str(e.value) or "decoder" in str(e.value) or "Error" in str(e.value)

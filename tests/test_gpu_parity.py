@@ -543,22 +543,50 @@ def test_predict_many_equals_per_file_predict(tmp_path):
     m.close()
 
 
-def test_ort_shim_session_runs_reference_call_pattern(cases):
-    """The reference's ONNX leg, verbatim call pattern (inference.py:134-136, 173-180), against the shim: the session
-    only accepts the reference's nmp.onnx (by SHA-256), so here the model bytes are faked by patching the expected
-    digest; outputs come back in the requested order with the reference's shapes."""
-    import hashlib
+def test_predict_many_sharded_on_one_gpu_and_flac_input(tmp_path):
+    """The product's multi-GPU entry point with world size 1 (this box has one GPU): same results as predict() file by
+    file, a broken file reported in place; and a FLAC copy of the reference's clip (test-side encoder, native decoder)
+    gives bit-identical posteriorgrams and the reference's 28 golden note events."""
+    import shutil
 
+    import flac_writer as FW
+    from basic_pitch_amd import Model, audio as A, predict_many_sharded
+    from basic_pitch_amd.inference import predict
+
+    clip = os.path.join(GOLDEN, "vocadito_10.wav")
+    pcm, sr = A.read_wav(clip)
+    flac = tmp_path / "clip.flac"
+    flac.write_bytes(FW.encode(np.round(pcm * 32768.0).astype(np.int64), sr, 16, blocksize=4096))
+    wav2 = tmp_path / "clip_copy.wav"
+    shutil.copy(clip, wav2)
+    broken = tmp_path / "broken.wav"
+    broken.write_bytes(b"RIFF\x00\x00\x00\x00WAVEjunk")
+    paths = [clip, str(flac), str(broken), str(wav2)]
+    res = predict_many_sharded(paths, gpus=1, group=2, decode_threads=2)
+    assert len(res) == 4 and isinstance(res[2], Exception)
+    m = Model(max_windows=8)
+    ref_out, _, ref_events = predict(clip, m)
+    assert len(ref_events) == 28
+    for i in (0, 1, 3):
+        out, midi, events = res[i]
+        for k in ref_out:
+            assert np.array_equal(out[k], ref_out[k]), (i, k)
+        assert [(e[0], e[1], e[2], list(e[4] or [])) for e in events] == [(e[0], e[1], e[2], list(e[4] or [])) for e in ref_events]
+    m.close()
+
+
+def test_ort_shim_session_runs_reference_call_pattern(cases):
+    """The reference's ONNX leg, verbatim call pattern (inference.py:134-136, 173-180), against the shim.  The session
+    takes the reference's nmp.onnx (structure-checked, constants extracted at load — covered on CPU where the
+    reference checkout exists, tests/test_host_cpu.py) or this package's pre-extracted blob; the GPU box has no
+    reference checkout, so the blob stands in here.  Outputs come back in the requested order."""
     import basic_pitch_amd.ort_shim as ort
+    from basic_pitch_amd.inference import ICASSP_2022_MODEL_PATH
 
     x, r32, r64 = cases
-    fake = b"stand-in for saved_models/icassp_2022/nmp.onnx (absent on the GPU box)"
-    old = ort.NMP_ONNX_SHA256
-    ort.NMP_ONNX_SHA256 = hashlib.sha256(fake).hexdigest()
-    try:
-        sess = ort.InferenceSession(fake, providers=ort.get_available_providers())
-    finally:
-        ort.NMP_ONNX_SHA256 = old
+    with pytest.raises(ValueError):
+        ort.InferenceSession(b"not a model at all", providers=ort.get_available_providers())
+    sess = ort.InferenceSession(str(ICASSP_2022_MODEL_PATH), providers=ort.get_available_providers())
     res = sess.run(
         ["StatefulPartitionedCall:1", "StatefulPartitionedCall:2", "StatefulPartitionedCall:0"],
         {"serving_default_input_2:0": x[:, :, None]},

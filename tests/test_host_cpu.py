@@ -208,3 +208,43 @@ def test_ort_shim_contract_cpu(tmp_path):
     import sys
 
     assert "onnxruntime" not in sys.modules or sys.modules["onnxruntime"] is not shim  # never installed implicitly
+
+
+REF_ONNX = "/root/reference/basic_pitch/saved_models/icassp_2022/nmp.onnx"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_ONNX), reason="needs the reference checkout (dev container only)")
+def test_model_blob_is_extracted_from_the_reference_onnx_at_load(tmp_path):
+    """`Model(path)` takes the serialized model like the reference (inference.py:78-154): nmp.onnx is structure-checked
+    and its 18 constants extracted at load (basic_pitch_amd/weights.py) — byte-identical to the shipped blob; the other
+    artifacts of the same model resolve to the nmp.onnx next to them; anything else is a ValueError."""
+    import hashlib
+    import shutil
+
+    from basic_pitch_amd import weights
+    from basic_pitch_amd.inference import ICASSP_2022_MODEL_PATH
+
+    shipped = open(ICASSP_2022_MODEL_PATH, "rb").read()
+    assert hashlib.sha256(open(REF_ONNX, "rb").read()).hexdigest() == weights.NMP_ONNX_SHA256
+    assert weights.load_model_blob(REF_ONNX) == shipped
+    assert weights.load_model_blob(ICASSP_2022_MODEL_PATH) == shipped
+    d = os.path.dirname(REF_ONNX)
+    for other in ("nmp", "nmp.tflite", "nmp.mlpackage"):  # what basic_pitch.ICASSP_2022_MODEL_PATH may point at
+        assert weights.load_model_blob(os.path.join(d, other)) == shipped, other
+    bad = tmp_path / "x.onnx"
+    bad.write_bytes(b"\x08\x07\x12\x04abcd")
+    with pytest.raises(ValueError):
+        weights.load_model_blob(bad)
+    with pytest.raises(ValueError):
+        weights.load_model_blob(tmp_path / "missing.onnx")
+    (tmp_path / "lonely.tflite").write_bytes(b"x")
+    with pytest.raises(ValueError):
+        weights.load_model_blob(tmp_path / "lonely.tflite")
+    # a model with the right structure but other weights (fine-tuned) is accepted; a truncated file is not
+    data = bytearray(open(REF_ONNX, "rb").read())
+    trunc = tmp_path / "t.onnx"
+    trunc.write_bytes(bytes(data[: len(data) // 2]))
+    with pytest.raises(ValueError):
+        weights.load_model_blob(trunc)
+    shutil.copy(REF_ONNX, tmp_path / "nmp.onnx")
+    assert weights.load_model_blob(tmp_path / "nmp.onnx") == shipped
