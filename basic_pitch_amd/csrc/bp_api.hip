@@ -674,6 +674,13 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     return BP_ERR_INVALID_ARG;
   }
   *out = nullptr;
+  // windows per chunk: the per-window kernels put the window index in gridDim.y (<= 65535) and several launch helpers
+  // count items in 32-bit; 16384 windows (3 GB of workspace) is far beyond where a larger chunk still helps
+  if (max_windows_hint > BP_MAX_WINDOWS_PER_CHUNK) {
+    g_create_error = "bp_create: max_windows_hint exceeds BP_MAX_WINDOWS_PER_CHUNK (16384); larger batches are chunked "
+                     "inside bp_infer, pass 0 for the default of 256";
+    return BP_ERR_INVALID_ARG;
+  }
   Blob blob;
   std::string err;
   if (!parse_blob(weights, nbytes, blob, err)) {
@@ -904,7 +911,18 @@ void bp_destroy(bp_handle h) {
 
 int bp_set_stream(bp_handle h, void* hip_stream) {
   if (!h) return BP_ERR_INVALID_ARG;
-  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  hipStream_t next = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  if (next == h->stream) return BP_OK;
+  // One workspace per handle (pyr, lp, zp, c1s, staging buffers): work still queued on the previous stream must
+  // finish before work on the new stream may touch it.  Order the two streams with an event instead of a host sync.
+  BP_HIP(hipSetDevice(h->device));
+  hipEvent_t ev;
+  BP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, h->stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(next, ev, 0);
+  (void)hipEventDestroy(ev);  // released once the recorded work completes
+  BP_HIP(e);
+  h->stream = next;
   return BP_OK;
 }
 
@@ -1054,6 +1072,7 @@ static int track_core(bp_handle h, const float* d_samples, int64_t n_samples, fl
 
 static int grow(bp_handle h, float** buf, int64_t* cap, int64_t need) {
   if (need <= *cap) return BP_OK;
+  // hipFree waits for the whole device, so work of an earlier call that still reads the old buffer has finished
   if (*buf) BP_HIP(hipFree(*buf));
   *buf = nullptr;
   *cap = 0;

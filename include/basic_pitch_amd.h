@@ -86,8 +86,9 @@ typedef enum bp_mem_kind {
                                    * ~25 us (2.6 %) of a 256-window step.  Ignored with BP_FLAG_STAGE_TIMING / F32_MFMA. */
 
 /*
- * Weights blob ("BPAMDW01", little endian) — produced by tools/extract_weights.py from the
- * reference's nmp.onnx (basic_pitch/saved_models/icassp_2022/):
+ * Weights blob ("BPAMDW01", little endian) — produced from the reference's nmp.onnx
+ * (basic_pitch/saved_models/icassp_2022/) by basic_pitch_amd/weights.py (at load time when Model() is given
+ * the .onnx, ahead of time by tools/extract_weights.py for the shipped assets/nmp_weights.bin):
  *   char magic[8]="BPAMDW01"; u32 version=1; u32 n_tensors;
  *   n_tensors x { char name[24]; u32 ndim; u32 dims[4]; u32 offset_in_floats; u32 count; }
  *   float32 data[]
@@ -96,8 +97,12 @@ typedef enum bp_mem_kind {
  *
  * Replaces: inference.Model.__init__(model_path) (inference.py:78-154) — load a serialized model.
  * `max_windows_hint` sizes the resident HBM workspace (about 5.8 MB per window); larger batches
- * are processed in chunks of that size.  0 selects the default (256).
+ * are processed in chunks of that size.  0 selects the default (256); values above
+ * BP_MAX_WINDOWS_PER_CHUNK are rejected with BP_ERR_INVALID_ARG.
+ * A handle serves one stream at a time: bp_set_stream orders the new stream after the work already
+ * queued on the previous one (the workspace is shared), concurrent calls on one handle are not supported.
  */
+#define BP_MAX_WINDOWS_PER_CHUNK 16384
 int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned flags,
               int64_t max_windows_hint, bp_handle* out);
 

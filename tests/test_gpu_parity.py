@@ -3,7 +3,7 @@
 Tolerances (floating point path; north-star bar: posteriorgrams within 1e-4 fp32):
   * stage tests feed the ORACLE's fp32 tensors into one HIP stage and compare with the oracle's fp32
     output of that stage: what remains is summation-order noise, bounds stated per stage below;
-  * end-to-end: |hip - fp64 oracle| <= max(1e-4, 2 * |fp32 oracle - fp64 oracle|) per tensor — the
+  * end-to-end: |hip - fp64 oracle| <= max(1e-4, 2 * |fp32 oracle - fp64 oracle|) per tensor (profiles/r02_parity.md) — the
     reference's own fp32 execution is only defined up to that noise (SURVEY.md §7 hard part 1), and
     plainly <= 1e-4 on the noise-like synthetic inputs BASELINE.json's configs use.
 """
@@ -248,19 +248,45 @@ def test_extended_cqt_44k_mode(weights):
     m.close()
 
 
-def _noise_aware(got, r32, r64, floor=1e-4, factor=4.0):
-    """|hip - fp64| <= max(1e-4, 4 * |fp32 oracle - fp64|), per tensor.
+def _noise_aware(got, r32, r64, floor=1e-4, factor=2.0):
+    """|hip - fp64| <= max(1e-4, 2 * |fp32 oracle - fp64|), per tensor (SURVEY.md §8c Tier A).
 
-    Two fp32 evaluations of this graph (different summation orders) are two draws of the same
-    heavy-tailed noise: the per-window MINIMUM of the log-power (signal.py:177) sits on a
-    cancellation-noise bin for tonal input and shifts every output of the window.  Measured on
-    MI355X: noise-like windows 5e-6..2e-5 (oracle fp32: 1.4e-5..3.5e-5), tonal window 1.9e-4
-    (oracle fp32: 0.9e-4) — same distribution, so the bound is a multiple of the oracle's own
-    distance to fp64, with the north-star's 1e-4 as the floor."""
+    Two fp32-class evaluations of this graph are two draws of the same heavy-tailed noise: the per-window MINIMUM of
+    the log-power (signal.py:177) sits on a cancellation-noise bin for tonal input and shifts every output of the
+    window.  Measured distribution on MI355X, profiles/r02_parity.md (46 windows: |hip - fp64|, |hip - fp32 oracle|,
+    |fp32 oracle - fp64| per window): noise-like windows 3e-6..4e-5 (fp32 oracle: 3e-6..7e-5), the reference clip's
+    windows <= 2.7e-5 (fp32 oracle <= 1.4e-4), 32 tonal windows median 1.0e-4 / max 1.5e-3 (fp32 oracle: median 2.6e-4 /
+    max 2.3e-3) — the HIP path is the CLOSER of the two to fp64, and all 46 windows sit inside the factor-2 bound."""
     for k in ("note", "onset", "contour"):
         ours = np.abs(got[k] - r64[k]).max()
         orc = np.abs(r32[k] - r64[k]).max()
         assert ours <= max(floor, factor * orc), (k, ours, orc)
+
+
+def test_tonal_windows_distribution(weights):
+    """Tonal input (music) is where fp32 evaluations of this graph scatter most.  Over 32 tonal windows + a loud and a
+    quiet 440 Hz sine: every window within max(1e-4, 2 x the fp32 oracle's own distance to fp64), and the path's median
+    distance to fp64 not above the fp32 oracle's.  |hip - fp32 oracle| is printed (SURVEY.md §8c asks for it) — it is
+    the sum of two independent noises and not a parity criterion."""
+    from basic_pitch_amd import Model
+
+    t = np.arange(43844) / 22050.0
+    x = np.concatenate([make_windows("tones", 32, 2), (0.5 * np.sin(2 * np.pi * 440.0 * t))[None].astype(np.float32),
+                        (0.01 * np.sin(2 * np.pi * 440.0 * t))[None].astype(np.float32)])
+    m = Model(max_windows=64)
+    got = m.predict(x)
+    m.close()
+    r32 = O.forward(x, weights, np.float32)
+    r64 = O.forward(x, weights, np.float64)
+    d = lambda a, b, i: max(float(np.abs(a[k][i] - b[k][i]).max()) for k in ("note", "onset", "contour"))  # noqa: E731
+    h64 = np.asarray([d(got, r64, i) for i in range(len(x))])
+    o64 = np.asarray([d(r32, r64, i) for i in range(len(x))])
+    h32 = np.asarray([d(got, r32, i) for i in range(len(x))])
+    print(f"tonal: |hip-fp64| median {np.median(h64):.2e} max {h64.max():.2e}; |fp32-fp64| median {np.median(o64):.2e} "
+          f"max {o64.max():.2e}; |hip-fp32| median {np.median(h32):.2e} max {h32.max():.2e}")
+    assert (h64 <= np.maximum(1e-4, 2.0 * o64)).all(), (h64, o64)
+    assert np.median(h64) <= np.median(o64)
+    assert h64[33] <= 1e-4  # the quiet sine: no cancellation floor, plain 1e-4
 
 
 def test_end_to_end_synthetic(runner, cases):
@@ -285,6 +311,28 @@ def test_device_path_equals_host_path(runner, cases):
     b = runner.model.predict(torch.from_numpy(x).cuda())
     for k in a:
         assert b[k].is_cuda and np.array_equal(a[k], b[k].cpu().numpy())
+
+
+def test_stream_switch_orders_the_shared_workspace(cases):
+    """One handle, asynchronous calls issued alternately on two torch streams without synchronising in between: the
+    workspace is shared, so bp_set_stream has to order the new stream after the old one's queued work."""
+    from basic_pitch_amd import Model
+
+    m = Model(max_windows=4)
+    xs = [torch.from_numpy(np.roll(cases[0], i, axis=0).copy()).cuda() for i in range(4)]
+    refs = [{k: v.clone() for k, v in m.predict(x).items()} for x in xs]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(3):
+        for i, x in enumerate(xs):
+            with torch.cuda.stream(s1 if (i + rep) % 2 else s2):
+                outs.append((i, m._predict_device(x, sync=False)))
+    torch.cuda.synchronize()
+    for i, o in outs:
+        for k in o:
+            assert torch.equal(o[k], refs[i][k]), (i, k)
+    m.close()
 
 
 def test_batch_invariance_and_chunking(weights):
@@ -378,6 +426,8 @@ def test_new_entry_points_reject_bad_arguments():
 
     with pytest.raises((ValueError, NativeLibraryError)):
         Model(exact_f32_mfma=True, ext_cqt_44k=True)  # extended range exists only on the split-precision path
+    with pytest.raises(ValueError):
+        Model(max_windows=1 << 20)  # above BP_MAX_WINDOWS_PER_CHUNK: a clear error instead of a failed launch later
     m = Model(max_windows=4)
     lib, h = m._lib, m._handle
     assert lib.bp_infer_tracks(h, -1, None, None, None, None, None, 0) == _native.BP_ERR_INVALID_ARG
