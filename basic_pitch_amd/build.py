@@ -27,6 +27,7 @@ SOURCES = [
     "conv_stride3.hip",
     "conv_heads.hip",
     "conv_branch.hip",
+    "note_march.hip",
     "audio_ingest.hip",
     "note_decode.cpp",
     "flac_decode.cpp",

@@ -59,6 +59,8 @@ void launch_contour_conv2(const float* c1, const float* w2, float bias, float* c
                           hipStream_t stream);
 void launch_note_branch(const float* contour, const void* wfrag, const float* wf32, float* note,
                         int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
+void launch_note_march(const float* contour, const void* wfrag, const float* wf32, float* note, int n_windows,
+                       bool weights_have_lo, hipStream_t stream);
 void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32,
                          float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
 }  // namespace bp
@@ -169,7 +171,8 @@ struct bp_context {
   // contour branch, two-kernel form (conv_contour_direct.hip): LDS weight image, bias[8], conv2 taps [5][5][8]
   float *d_d1_wlds = nullptr, *d_d1_wfold = nullptr, *d_d1_bias = nullptr, *d_d2_w = nullptr;
   float* c1s = nullptr;  // [cap][172][kC1Row][8] relu(conv1); pad bins zeroed once at allocation
-  bool fused_contour = false;  // BP_CONTOUR_PATH=fused: the single-kernel contour branch (A/B comparisons)
+  bool fused_contour = false;
+  bool note_ring = false;  // BP_CONTOUR_PATH=fused: the single-kernel contour branch (A/B comparisons)
   float *d_dec_hfrag = nullptr, *d_fbh_bfrag = nullptr;  // cqt_mfma.hip f16 hi/lo fragments (raw bytes)
   float *d_c1_bfrag = nullptr, *d_c1_bias = nullptr, *d_o1_bfrag = nullptr, *d_o1_bias = nullptr;
   float *d_n1_bfrag = nullptr, *d_n1_bias = nullptr, *d_w_contour2 = nullptr, *d_w_note2 = nullptr,
@@ -642,7 +645,10 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
       launch_contour_conv2(h->c1s, h->d_d2_w, h->b_contour2, contour_dev, n, h->n_cu, s);
       BP_MARK(BP_STAGE_CONTOUR_CONV2);
     }
-    launch_note_branch(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, h->n_cu, wlo, s);
+    if (h->note_ring)
+      launch_note_branch(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, h->n_cu, wlo, s);
+    else
+      launch_note_march(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, wlo, s);
     BP_MARK(BP_STAGE_NOTE);
     launch_onset_branch(reinterpret_cast<const uint32_t*>(h->zp), note_dev, h->d_onset_wfrag, h->d_onset_wf32,
                         onset_dev, n, h->n_cu, wlo, s);
@@ -825,6 +831,8 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     {
       const char* e = std::getenv("BP_CONTOUR_PATH");
       h->fused_contour = e && std::strcmp(e, "fused") == 0;
+      const char* en = std::getenv("BP_NOTE_PATH");  // "ring": the round-1 workgroup kernel (A/B runs)
+      h->note_ring = en && std::strcmp(en, "ring") == 0;
     }
     for (int br = 0; br < 2; ++br) {
       pack_branch(br ? 13 : 4, br ? o1w : n1w, br ? o2w : n2w, br == 1, frag);
@@ -1402,7 +1410,10 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
       break;
     case BP_STAGE_NOTE:
       if ((ok = need(bf->contour) && need(bf->note)))
-        launch_note_branch(bf->contour, h->d_note_wfrag, h->d_note_wf32, bf->note, n, h->n_cu, wlo, s);
+        if (h->note_ring)
+          launch_note_branch(bf->contour, h->d_note_wfrag, h->d_note_wf32, bf->note, n, h->n_cu, wlo, s);
+        else
+          launch_note_march(bf->contour, h->d_note_wfrag, h->d_note_wf32, bf->note, n, wlo, s);
       break;
     case BP_STAGE_ONSET:
       if ((ok = need(bf->zp) && need(bf->note) && need(bf->onset)))
