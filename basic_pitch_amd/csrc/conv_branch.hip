@@ -233,10 +233,17 @@ __device__ __forceinline__ void stage_block(const BranchParams& p, int b, int ro
 // ---- steady-state staging: the kBrRows source rows of the NEXT phase come in by LDS-DMA (global_load_lds_dwordx4:
 // lane l's 16 bytes land at the wave's LDS base + 16 l, checked in tools/ubench/lds_dma.hip) while the tiles of this
 // phase run, and are split / gathered LDS -> LDS after the barrier: no global-load latency on the phase's critical path.
-// 16 bytes per lane, global -> LDS at `lds_wave_base` + 16 * lane (wave-uniform base), asynchronous (vmcnt)
+// 16 bytes per lane, global -> LDS at `lds_wave_base` + 16 * lane (wave-uniform base), asynchronous (vmcnt).
+// Issued as inline assembly on purpose: through the builtin the compiler's wait-count pass knows an LDS-writing VMEM
+// operation is in flight and, unable to prove that `raw` does not alias the image, puts s_waitcnt vmcnt(0) in front of
+// the next LDS read — the first tile of every phase then waited for the whole DMA (the latency this staging exists to
+// hide).  The kernel orders the DMA itself: s_waitcnt vmcnt(0) + barrier before raw_convert reads `raw`.  (Compiler
+// generated vmcnt(N) waits for its own loads stay correct: VMEM returns in issue order, an extra outstanding operation
+// only makes them wait longer.)
 __device__ __forceinline__ void lds_dma16(const void* gsrc, uint4* lds_wave_base) {
-#if defined(__HIP_DEVICE_COMPILE__)  // the builtin does not exist in the host pass
-  __builtin_amdgcn_global_load_lds(gsrc, lds_wave_base, 16, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(lds_wave_base));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(base) : "memory");
 #endif
 }
 
@@ -330,7 +337,6 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
   __shared__ __attribute__((aligned(16))) uint4 img_lo[Br::RING * Br::SLOTS];
   __shared__ float qring[Br::QRING * KH2 * kFreqN + 64];  // + a scratch slot per lane for the stores that must not land
   __shared__ __attribute__((aligned(16))) uint4 raw[Br::RAW_UNITS];
-
   const int lane = threadIdx.x & 63;
   const int wave = wave_id();
   const int h = lane >> 5, li = lane & 31;
@@ -361,6 +367,9 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
       extra[i][dw] = (Br::kOnset && dt < KH2) ? p.wf32[32 + dt * 3 + dw] : 0.0f;
     }
   const float bias2 = p.wf32[41];
+  // every load above has landed before the loops: with loads pending from the preheader the wait-count pass puts a
+  // conservative s_waitcnt vmcnt(1) in front of each tile's first MFMA, which also waits for the (untracked) LDS-DMA
+  __builtin_amdgcn_s_waitcnt(0x0F70);
 
   // slots no staging call writes (onset: the two zero bins either side of a row) are zero from here on
   for (int i = threadIdx.x; i < Br::RING * Br::SLOTS; i += kBrThreads) {
@@ -378,6 +387,25 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
 
     __syncthreads();  // previous item finished with the rings
     stage_block<Br, Br::RING>(p, b, T0 - PH2 - PH1, img_hi, img_lo, threadIdx.x);
+    // onset: the note values (concat channel 0, models.py:305) of this lane's pixels in the phase's three tiles are
+    // fetched one phase ahead into registers, right in front of a vmcnt(0) wait that exists anyway: no global load is
+    // left inside the tile loop (one there makes the compiler wait on vmcnt in front of every tile's MFMAs, and with
+    // it on the LDS-DMA in flight).  Unconditional loads from clamped addresses, masked where they are used.
+    float note_nx[kBrTilesPerRow] = {0.0f, 0.0f, 0.0f};
+    auto fetch_notes = [&](int r_first) {
+      if constexpr (Br::kOnset) {
+#pragma unroll
+        for (int j = 0; j < kBrTilesPerRow; ++j) {
+          const int tile = wave + 4 * j;
+          int row = r_first + tile / kBrTilesPerRow;
+          row = row < 0 ? 0 : (row > kFrames - 1 ? kFrames - 1 : row);
+          int w = (tile % kBrTilesPerRow) * 30 - 1 + li;
+          w = w < 0 ? 0 : (w > kFreqN - 1 ? kFreqN - 1 : w);
+          note_nx[j] = p.note[((int64_t)b * kFrames + row) * kFreqN + w];
+        }
+      }
+    };
+    fetch_notes(T0 - PH2);
     __syncthreads();
 
     for (int ph = 0; ph < n_phase; ++ph) {
@@ -385,6 +413,9 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
       BR_STAMP(0);
       // the next phase's source rows start their way into LDS now (raw was consumed before the last barrier)
       if (ph + 1 < n_phase) raw_dma_issue<Br>(p, b, r0 + kBrRows + PH1, raw, wave, lane);
+      float note_cur[kBrTilesPerRow];
+#pragma unroll
+      for (int j = 0; j < kBrTilesPerRow; ++j) note_cur[j] = note_nx[j];
 
       // ---- conv1 + projection, 12 tiles: 4 rows x 3 overlapping 32-pixel tiles (30 inner pixels each)
 #pragma unroll 1
@@ -407,11 +438,8 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
             r = r + 1 == Br::RING ? 0 : r + 1;
           }
           const int lane_off = Br::lane_slot(wc);
-          // onset: the note value of this lane's pixel (concat channel 0, models.py:305), fetched now so that its
-          // latency hides behind the MFMAs; an unconditional load from a clamped address, masked where it is used (a
-          // select right behind a load would make this side wait for the data: measured 1 k cycles per tile)
           float note_c = 0.0f;
-          if constexpr (Br::kOnset) note_c = p.note[((int64_t)b * kFrames + row) * kFreqN + wc];
+          if constexpr (Br::kOnset) note_c = j == 0 ? note_cur[0] : (j == 1 ? note_cur[1] : note_cur[2]);
 
           f32x16 acc, accc;  // the hi x hi chain starts from the bias
 #pragma unroll
@@ -521,7 +549,8 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
         }
       }
       BR_STAMP(1);
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of the DMA has landed
+      if (ph + 1 < n_phase) fetch_notes(r0 + kBrRows);
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of the DMA (and the note values) has landed
       lds_barrier();
       BR_STAMP(2);
 
