@@ -54,7 +54,7 @@ F1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 224 * 8 * 4  # zp read + interior c1
 D1_EXECUTED_FLOP_PER_WINDOW = 45 * 8 * 63 * 3 * (2 * 32 * 32 * 16)
 D1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 264 * 8 * 4  # zp read + c1 written
 HBM_PEAK_GBS = 8000.0
-PMC_PROFILE = "r01_m"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
+PMC_PROFILE = "r02_a"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
 
 
 def pmc_traffic(kernel_key: str, batch: int):
@@ -201,6 +201,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustained-s", type=float, default=2.0, help="length of the extra steady-state measurement (0 = skip)")
+    ap.add_argument("--no-exact-f32", action="store_true", help="skip the extra exact-f32 A/B rate (profiling runs)")
     ap.add_argument("--exact-f32", action="store_true", help="contour conv1 on the exact-f32 MFMA kernel (A/B)")
     ap.add_argument("--workload", choices=["windows", "tracks"], default="windows",
                     help="windows: BASELINE.json configs[1] (the headline line); tracks: configs[2], whole synthetic "
@@ -343,7 +344,7 @@ def main() -> None:
         extras["sustained"] = {"windows_per_s": B * n_sus * world / t_sus, "steps": n_sus, "seconds": t_sus,
                                "ms_per_step": t_sus / n_sus * 1e3,
                                "note": "same step, back to back, no event records; beside `value`, not instead of it"}
-    if not args.exact_f32 and rank == 0 and not (args.bf16_weights or args.ext_cqt_44k):
+    if not args.exact_f32 and not args.no_exact_f32 and rank == 0 and not (args.bf16_weights or args.ext_cqt_44k):
         ex_model = Model(device=local_rank, max_windows=B, exact_f32_mfma=True)
         for _ in range(2):
             ex_model._predict_device(audio, out=out, sync=False)
