@@ -44,6 +44,9 @@ void launch_pyramid_mfma(const float* audio, float* pyr, const void* hfrag, int 
 void launch_filterbank_mfma(const float* audio, const float* pyr, const void* bfrag, const float* sqrt_len,
                             float* lp, int* mm, float* scratch, int n_windows, LogConsts kc, int n_cu, bool ext,
                             hipStream_t stream);
+void launch_zpack_partials(const float* lp, const float* scratch, int n_partials, uint32_t* zp, int n_windows,
+                           LogConsts kc, int n_bins, hipStream_t stream);
+int filterbank_mfma_partials(bool ext);
 void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc, int n_bins,
                   hipStream_t s);
 ResamplePlan make_resample_plan(int source_rate, int target_rate, std::vector<double>& taps);
@@ -55,6 +58,8 @@ void launch_contour_conv1_exact(const uint32_t* zp, const void* wlds, const floa
 void launch_contour_conv1_folded(const uint32_t* zp, const void* wfold, const float* bias, float* c1, int n_windows,
                                  int n_cu, bool weights_have_lo, hipStream_t stream);
 bool contour_conv1_full();
+void launch_contour_conv1_rim(const uint32_t* zp, const void* afrag, const float* bias, float* c1, int n_windows,
+                              bool weights_have_lo, hipStream_t stream);
 void launch_contour_conv2(const float* c1, const float* w2, float bias, float* contour, int n_windows, int n_cu,
                           hipStream_t stream);
 void launch_note_branch(const float* contour, const void* wfrag, const float* wf32, float* note,
@@ -169,7 +174,8 @@ struct bp_context {
   float *d_note_wfrag = nullptr, *d_note_wf32 = nullptr, *d_onset_wfrag = nullptr, *d_onset_wf32 = nullptr;
   float* zp = nullptr;  // uint32 [cap][kZRowsP][kZRow] pre-split z, zero padded (bp_common.h)
   // contour branch, two-kernel form (conv_contour_direct.hip): LDS weight image, bias[8], conv2 taps [5][5][8]
-  float *d_d1_wlds = nullptr, *d_d1_wfold = nullptr, *d_d1_bias = nullptr, *d_d2_w = nullptr;
+  float *d_d1_wlds = nullptr, *d_d1_wfold = nullptr, *d_d1_wrim = nullptr, *d_d1_bias = nullptr, *d_d2_w = nullptr;
+  bool rim_exact = false;
   float* c1s = nullptr;  // [cap][172][kC1Row][8] relu(conv1); pad bins zeroed once at allocation
   bool fused_contour = false;
   bool note_ring = false;  // BP_CONTOUR_PATH=fused: the single-kernel contour branch (A/B comparisons)
@@ -412,6 +418,49 @@ void pack_contour_folded(const Tensor* w1, std::vector<uint16_t>& out) {
       }
 }
 
+// Rim of the contour conv1 as a dense GEMM (conv_contour_rim.hip): per side (low rim f in [0, 20), high rim
+// f in [244, 264)) the position-dependent folded kernel K[(f, o)][dt][j] over the z bins j0 + [0, 144):
+//   K = sum over (c, df) with stack bin f + df - 19 inside [0, 264) (nn.py:87 crops the stack to 264 bins, the
+//   convolution zero-pads THAT) and z bin f + df - 19 + shift_c == j0 + j of W1[o][c][dt][df].
+// A fragments [side][M block 5][k-step 27 = dt * 9 + e][hi|lo][64 lanes][8]: lane (i = lane & 31 = 8 (f % 4) + o,
+// kh = lane >> 5), element el: j = 16 e + 8 kh + el.
+void pack_contour_rim(const Tensor* w1, std::vector<uint16_t>& out) {
+  static const int shifts[8] = {-36, 0, 36, 57, 72, 84, 93, 101};
+  constexpr int kJ = 144, kStepsDt = kJ / 16;
+  out.assign((size_t)2 * 5 * 3 * kStepsDt * 2 * 64 * 8, 0);
+  for (int side = 0; side < 2; ++side) {
+    const int f0 = side ? 244 : 0, j0 = side ? 184 : 0;
+    std::vector<double> k((size_t)20 * 8 * 3 * kJ, 0.0);  // [f_local][o][dt][j]
+    for (int fl = 0; fl < 20; ++fl)
+      for (int o = 0; o < 8; ++o)
+        for (int c = 0; c < 8; ++c)
+          for (int dt = 0; dt < 3; ++dt)
+            for (int df = 0; df < 39; ++df) {
+              const int sb = f0 + fl + df - 19;  // stack bin this tap reads
+              if (sb < 0 || sb >= 264) continue;
+              const int j = sb + shifts[c] - j0;  // z bin (zero outside [0, 309): nothing to add there)
+              const int zb = sb + shifts[c];
+              if (zb < 0 || zb >= 309) continue;
+              if (j < 0 || j >= kJ) {  // cannot happen with the windows above; guard the table
+                continue;
+              }
+              k[(((size_t)fl * 8 + o) * 3 + dt) * kJ + j] += (double)w1->data[((o * 8 + c) * 3 + dt) * 39 + df];
+            }
+    for (int mb = 0; mb < 5; ++mb)
+      for (int dt = 0; dt < 3; ++dt)
+        for (int e = 0; e < kStepsDt; ++e)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int kh = lane >> 5, i = lane & 31, fl = 4 * mb + (i >> 3), o = i & 7;
+            const size_t step = ((size_t)(side * 5 + mb) * 3 * kStepsDt + dt * kStepsDt + e);
+            const size_t base_hi = ((step * 2 + 0) * 64 + lane) * 8, base_lo = ((step * 2 + 1) * 64 + lane) * 8;
+            for (int el = 0; el < 8; ++el) {
+              const int j = 16 * e + 8 * kh + el;
+              put_split(out, base_hi, base_lo, el, (float)k[(((size_t)fl * 8 + o) * 3 + dt) * kJ + j], 2048.0f);
+            }
+          }
+  }
+}
+
 // contour conv1 Toeplitz B fragments [4 waves][126][64] (conv_contour1.hip).
 void pack_contour1(const Tensor* w, std::vector<float>& out) {
   static const int chan[4][2] = {{0, 1}, {2, 4}, {5, 3}, {6, 7}};
@@ -540,7 +589,7 @@ void pack_filterbank_f16(const Tensor* re, const Tensor* im, std::vector<uint16_
 }
 
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_bias, h->d_d2_w, h->d_cb_wfrag, h->d_cb_wf32, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wrim, h->d_d1_bias, h->d_d2_w, h->d_cb_wfrag, h->d_cb_wf32, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->fb_scratch, h->pcm_dev, h->mono_dev, h->res_dev, reinterpret_cast<float*>(h->taps_dev)};
@@ -604,7 +653,8 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
   } else {
     launch_pyramid_mfma(audio_dev, h->pyr, h->d_dec_hfrag, n, h->ext, s);
     BP_MARK(BP_STAGE_PYRAMID);
-    launch_filterbank_mfma(audio_dev, h->pyr, h->d_fbh_bfrag, h->d_sqrt_len, h->lp, h->mm, h->fb_scratch, n,
+    // the per-window extrema are folded from the partials inside zpack (one launch and one boundary fewer)
+    launch_filterbank_mfma(audio_dev, h->pyr, h->d_fbh_bfrag, h->d_sqrt_len, h->lp, nullptr, h->fb_scratch, n,
                            h->kc, h->n_cu, h->ext, s);
     BP_MARK(BP_STAGE_FILTERBANK);
   }
@@ -622,7 +672,8 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
     launch_onset2(note_dev, h->o1, h->d_w_onset2, h->b_onset2, onset_dev, n, s);
     BP_MARK(BP_STAGE_ONSET2);
   } else {
-    launch_zpack(h->lp, h->mm, reinterpret_cast<uint32_t*>(h->zp), n, h->kc, h->n_bins, s);
+    launch_zpack_partials(h->lp, h->fb_scratch, filterbank_mfma_partials(h->ext), reinterpret_cast<uint32_t*>(h->zp), n,
+                          h->kc, h->n_bins, s);
     BP_MARK(BP_STAGE_ZPACK);
     if (h->fused_contour) {
       BP_DOM_BEGIN();
@@ -632,8 +683,12 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
       BP_MARK(BP_STAGE_CONTOUR);
     } else {
       if (contour_conv1_full()) BP_DOM_BEGIN();
-      launch_contour_conv1_exact(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wlds, h->d_d1_bias, h->c1s, n,
-                                 h->n_cu, wlo, s);
+      if (contour_conv1_full() || h->rim_exact)
+        launch_contour_conv1_exact(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wlds, h->d_d1_bias, h->c1s, n,
+                                   h->n_cu, wlo, s);
+      else
+        launch_contour_conv1_rim(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wrim, h->d_d1_bias, h->c1s, n, wlo,
+                                 s);
       if (!contour_conv1_full()) {
         BP_MARK(BP_STAGE_CONTOUR_CONV1_EDGE);
         BP_DOM_BEGIN();
@@ -828,6 +883,14 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       return fail(rc);
     pack_contour_folded(c1w, frag);
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wfold))) return fail(rc);
+    pack_contour_rim(c1w, frag);
+    if ((rc = upload(h, raw_of(frag), &h->d_d1_wrim))) return fail(rc);
+    {
+      const char* er = std::getenv("BP_RIM");  // "exact": the round-1 rim kernel on the 8-channel form (A/B runs)
+      // the extended 345-bin CQT (BP_FLAG_EXT_CQT_44K) feeds bins 309..344 into the high rim: its GEMM table is built for
+      // the model's 309 bins, so that mode stays on the exact kernel
+      h->rim_exact = (er && std::strcmp(er, "exact") == 0) || (flags & BP_FLAG_EXT_CQT_44K);
+    }
     {
       const char* e = std::getenv("BP_CONTOUR_PATH");
       h->fused_contour = e && std::strcmp(e, "fused") == 0;
@@ -1402,7 +1465,10 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
           h->err = "bp_run_stage: contour needs n_windows <= max_windows (internal c1 buffer)";
           return BP_ERR_INVALID_ARG;
         } else {
-          launch_contour_conv1_exact(bf->zp, h->d_d1_wlds, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
+          if (contour_conv1_full() || h->rim_exact)
+            launch_contour_conv1_exact(bf->zp, h->d_d1_wlds, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
+          else
+            launch_contour_conv1_rim(bf->zp, h->d_d1_wrim, h->d_d1_bias, h->c1s, n, wlo, s);
           launch_contour_conv1_folded(bf->zp, h->d_d1_wfold, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
           launch_contour_conv2(h->c1s, h->d_d2_w, h->b_contour2, bf->contour, n, h->n_cu, s);
         }
@@ -1428,7 +1494,8 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
     return BP_ERR_INVALID_ARG;
   }
   BP_HIP(hipGetLastError());
-  BP_HIP(hipStreamSynchronize(s));
+  static const bool nosync = std::getenv("BP_STAGE_NOSYNC") != nullptr;  // tools only: overlap experiments
+  if (!nosync) BP_HIP(hipStreamSynchronize(s));
   return BP_OK;
 }
 

@@ -589,11 +589,36 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
 // ---- z pack: NormalizedLog tail + BatchNorm affine, stored pre-split as (f16 hi | f16 lo << 16) ----
 // (signal.py:177-183, models.py:187-189).  One pass over lp; consumers gather these words straight
 // into MFMA operand slots with no further arithmetic.
+// The window's extrema come either from mm (the FILTERBANK stage's output, test hook) or — the production path — from
+// the filterbank's per-tile partial extrema, folded here by every workgroup for itself (n_partials float2 per window,
+// 3 KB from L2): a separate reduction kernel costs a launch boundary (~5 us) for 5 us of work.
 __global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ lp, const int* __restrict__ mm,
+                                                    const float2* __restrict__ mmp, int n_partials,
                                                     uint32_t* __restrict__ zp, LogConsts kc, int n_bins) {
   const int b = blockIdx.y;
-  const float mn = ord2f(mm[2 * b]);
-  const float range = ord2f(mm[2 * b + 1]) - mn;
+  float mn, mx;
+  if (mmp) {
+    __shared__ float2 red[4];
+    float vmin = __int_as_float(0x7f800000), vmax = -__int_as_float(0x7f800000);
+    for (int i = threadIdx.x; i < n_partials; i += 256) {
+      const float2 pr = mmp[(int64_t)b * n_partials + i];
+      vmin = fminf(vmin, pr.x);
+      vmax = fmaxf(vmax, pr.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      vmin = fminf(vmin, __shfl_xor(vmin, o));
+      vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_float2(vmin, vmax);
+    __syncthreads();
+    mn = fminf(fminf(red[0].x, red[1].x), fminf(red[2].x, red[3].x));
+    mx = fmaxf(fmaxf(red[0].y, red[1].y), fmaxf(red[2].y, red[3].y));
+  } else {
+    mn = ord2f(mm[2 * b]);
+    mx = ord2f(mm[2 * b + 1]);
+  }
+  const float range = mx - mn;
   const float* lpb = lp + (int64_t)b * kFrames * n_bins;
   uint32_t* zb = zp + (int64_t)b * kZWin;
   // the whole padded window is written every time (pad frames and pad words are zero: the zero padding of the
@@ -621,7 +646,14 @@ __global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ lp
 
 void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc, int n_bins,
                   hipStream_t stream) {
-  hipLaunchKernelGGL(zpack_kernel, dim3(16, n_windows), dim3(256), 0, stream, lp, mm, zp, kc, n_bins);
+  hipLaunchKernelGGL(zpack_kernel, dim3(16, n_windows), dim3(256), 0, stream, lp, mm, nullptr, 0, zp, kc, n_bins);
+}
+
+// production path: extrema folded from the filterbank's partials (`scratch` of launch_filterbank_mfma(..., mm = null))
+void launch_zpack_partials(const float* lp, const float* scratch, int n_partials, uint32_t* zp, int n_windows,
+                           LogConsts kc, int n_bins, hipStream_t stream) {
+  hipLaunchKernelGGL(zpack_kernel, dim3(16, n_windows), dim3(256), 0, stream, lp, nullptr,
+                     reinterpret_cast<const float2*>(scratch), n_partials, zp, kc, n_bins);
 }
 
 template <class Br>

@@ -553,7 +553,10 @@ void launch_filterbank_mfma(const float* audio, const float* pyr, const void* bf
   const int grid = items < 4 * n_cu ? items : 4 * n_cu;
   hipLaunchKernelGGL(cqt_filterbank_mfma_kernel, dim3(grid), dim3(kFmThreads), 0, stream, audio, pyr,
                      static_cast<const uint4*>(bfrag), sqrt_len, lp, mmp, n_windows, kc, g);
-  launch_mm_reduce(scratch, mm, n_windows, g.n_levels * kFmTilesPerLevel * 4, stream);
+  // mm == null: the caller folds the partial extrema itself (launch_zpack_partials)
+  if (mm) launch_mm_reduce(scratch, mm, n_windows, g.n_levels * kFmTilesPerLevel * 4, stream);
 }
+
+int filterbank_mfma_partials(bool ext) { return make_fm_geo(ext).n_levels * kFmTilesPerLevel * 4; }
 
 }  // namespace bp
