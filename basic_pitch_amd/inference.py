@@ -617,9 +617,7 @@ def predict_and_save(
     sonification_samplerate: int = DEFAULT_SONIFICATION_SAMPLERATE,
     midi_tempo: float = DEFAULT_MINIMUM_MIDI_TEMPO,
 ) -> None:
-    """inference.py:509-618 (MIDI sonification — pretty_midi.synthesize — is out of scope and raises)."""
-    if sonify_midi:
-        raise NotImplementedError("MIDI sonification (pretty_midi.synthesize) is not part of this backend")
+    """inference.py:509-618: model output (.npz), MIDI (.mid), sonified MIDI (.wav), note events (.csv) per file."""
     model = model_or_model_path if isinstance(model_or_model_path, Model) else Model(model_or_model_path)
     for audio_path in audio_path_list:
         model_output, midi_data, note_events = predict(
@@ -631,5 +629,8 @@ def predict_and_save(
                      basic_pitch_model_output=model_output)
         if save_midi:
             midi_data.write(str(build_output_path(audio_path, output_directory, OutputExtensions.MIDI)))
+        if sonify_midi:
+            infer.sonify_midi(midi_data, build_output_path(audio_path, output_directory, OutputExtensions.MIDI_SONIFICATION),
+                              sr=sonification_samplerate)
         if save_notes:
             save_note_events(note_events, build_output_path(audio_path, output_directory, OutputExtensions.NOTE_EVENTS))

@@ -17,6 +17,10 @@ pretty_midi 0.2.x `PrettyMIDI.write` + mido `MidiFile.save` step by step:
   * mido's encoding: delta times as variable-length quantities, running status within a track (a status byte equal
     to the previous channel message's is omitted; any meta event resets it).
 
+`synthesize()` restates pretty_midi's sine sonification (what `note_creation.sonify_midi`, note_creation.py:119-128,
+renders and `inference.py:588-594` saves as `*_basic_pitch.wav`); no pretty_midi output exists to pin its samples, the
+test checks the spectrum.
+
 tests/golden/midi/*.mid are those steps written out independently (tools/make_midi_fixtures.py) for the events the
 UNMODIFIED reference produced; `write()` must reproduce them byte for byte (tests/test_note_decode.py).
 """
@@ -47,11 +51,63 @@ class PitchBend:
         self.pitch, self.time = pitch, time
 
 
+def note_number_to_hz(note_number: float) -> float:
+    """pretty_midi.note_number_to_hz: A4 = 440 Hz, 12-tone equal temperament."""
+    return 440.0 * (2.0 ** ((note_number - 69) / 12.0))
+
+
+def pitch_bend_to_semitones(pitch_bend: int, semitone_range: float = 2.0) -> float:
+    """pretty_midi.pitch_bend_to_semitones: +-8192 <-> +-semitone_range."""
+    return semitone_range * pitch_bend / 8192.0
+
+
 class Instrument:
     def __init__(self, program: int, is_drum: bool = False, name: str = ""):
         self.program, self.is_drum, self.name = program, is_drum, name
         self.notes: List[Note] = []
         self.pitch_bends: List[PitchBend] = []
+
+    def get_end_time(self) -> float:
+        ends = [n.end for n in self.notes] + [b.time for b in self.pitch_bends]
+        return max(ends) if ends else 0.0
+
+    def synthesize(self, fs: int = 44100, wave=None):
+        """pretty_midi.Instrument.synthesize restated: every note a `wave` (default np.sin) oscillator at its pitch,
+        frequency multiplied by the instrument's pitch bends (with a phase offset at each bend so the waveform stays
+        continuous), an exp(-t) envelope with a 0.1 s linear fade-out, scaled by the note's velocity."""
+        import numpy as np
+
+        wave = np.sin if wave is None else wave
+        synthesized = np.zeros(int(fs * (self.get_end_time() + 1)))
+        if self.is_drum:
+            return synthesized
+        fade_out = np.linspace(1, 0, int(0.1 * fs))
+        bend_multiplier = np.ones(synthesized.shape)
+        ordered_bends = sorted(self.pitch_bends, key=lambda bend: bend.time)
+        end_bend = PitchBend(0, self.get_end_time())
+        for start_bend, stop_bend in zip(ordered_bends, ordered_bends[1:] + [end_bend]):
+            start, end = int(start_bend.time * fs), int(stop_bend.time * fs)
+            bend_multiplier[start:end] = 2 ** (pitch_bend_to_semitones(start_bend.pitch) / 12.0)
+        for note in self.notes:
+            start, end = int(fs * note.start), int(fs * note.end)
+            frequency = note_number_to_hz(note.pitch)
+            offsets = np.zeros(end - start)
+            for bend in ordered_bends:
+                bend_sample = int(bend.time * fs)
+                if start < bend_sample < end:
+                    bend_so_far = bend_multiplier[start:bend_sample].mean()
+                    bend_amount = bend_multiplier[bend_sample]
+                    offsets[bend_sample - start :] = (bend_so_far - bend_amount) * (bend_sample - start)
+            frequencies = 2 * np.pi * frequency * (bend_multiplier[start:end]) / fs
+            note_waveform = wave(frequencies * np.arange(end - start) + 2 * np.pi * frequency * offsets / fs)
+            envelope = np.exp(-np.arange(end - start) / (1.0 * fs))
+            if envelope.shape[0] > fade_out.shape[0]:
+                envelope[-fade_out.shape[0] :] *= fade_out
+            else:
+                envelope *= np.linspace(1, 0, envelope.shape[0])
+            envelope *= note.velocity
+            synthesized[start:end] += envelope * note_waveform
+        return synthesized
 
 
 def _vlq(n: int) -> bytes:
@@ -85,6 +141,20 @@ class PrettyMIDI:
     def get_end_time(self) -> float:
         ends = [n.end for i in self.instruments for n in i.notes] + [b.time for i in self.instruments for b in i.pitch_bends]
         return max(ends) if ends else 0.0
+
+    def synthesize(self, fs: int = 44100, wave=None):
+        """pretty_midi.PrettyMIDI.synthesize restated: the instruments' waveforms summed (zero padded to the longest)
+        and normalised to a peak of 1."""
+        import numpy as np
+
+        if len(self.instruments) == 0:
+            return np.array([])
+        waveforms = [i.synthesize(fs=fs, wave=wave) for i in self.instruments]
+        synthesized = np.zeros(np.max([w.shape[0] for w in waveforms]))
+        for waveform in waveforms:
+            synthesized[: waveform.shape[0]] += waveform
+        peak = np.abs(synthesized).max()
+        return synthesized / peak if peak > 0 else synthesized
 
     @staticmethod
     def _encode_track(events) -> bytes:

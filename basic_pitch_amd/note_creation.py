@@ -37,6 +37,14 @@ PITCH_BEND_SCALE = 4096
 NoteEvent = Tuple[float, float, int, float, Optional[List[int]]]
 
 
+def sonify_midi(midi: "pretty_midi.PrettyMIDI", save_path, sr: Optional[int] = 44100) -> None:
+    """note_creation.py:119-128: render the MIDI object with sine oscillators and save it as a WAV file."""
+    from scipy.io import wavfile
+
+    y = midi.synthesize(sr)
+    wavfile.write(save_path, sr, y)
+
+
 def _decode(
     frames: np.ndarray, onsets: np.ndarray, contours: np.ndarray, onset_thresh: float, frame_thresh: float,
     min_note_len: int, infer_onsets: bool, max_freq: Optional[float], min_freq: Optional[float],

@@ -193,6 +193,49 @@ def run_tracks(args, torch, dist, world, rank, local_rank) -> None:
         print(json.dumps(line), flush=True)
 
 
+def run_files(args) -> None:
+    """End-to-end `predict()` over FILES on one GPU (not the headline metric: host decode, H2D of the PCM, device
+    resampling, CQT + CNN, D2H of the posteriorgrams and C++ note decoding on host threads are all inside the timed
+    region): `--files` synthetic 16-bit stereo 44.1 kHz WAV files of `--file-seconds` each in a temporary directory,
+    through basic_pitch_amd.predict_many.  Reports files/s and audio-seconds per second."""
+    import tempfile
+    import wave
+
+    from basic_pitch_amd.inference import Model, predict_many
+
+    rng = np.random.default_rng(7)
+    n = int(args.file_seconds * 44100)
+    t = np.arange(n) / 44100.0
+    with tempfile.TemporaryDirectory() as d:
+        paths = []
+        for i in range(args.files):
+            f0 = 110.0 * 2 ** (rng.integers(0, 36) / 12.0)
+            x = 0.3 * np.sin(2 * np.pi * f0 * t) * (np.sin(2 * np.pi * 1.5 * t) > 0) + 0.01 * rng.standard_normal(n)
+            pcm = (np.clip(np.stack([x, x[::-1]], 1), -1, 1) * 32767).astype("<i2")
+            p = os.path.join(d, f"f{i}.wav")
+            with wave.open(p, "wb") as w:
+                w.setnchannels(2)
+                w.setsampwidth(2)
+                w.setframerate(44100)
+                w.writeframes(pcm.tobytes())
+            paths.append(p)
+        model = Model(max_windows=256)
+        predict_many(paths[: min(4, len(paths))], model)  # warm-up
+        t0 = time.perf_counter()
+        res = predict_many(paths, model, group=32)
+        el = time.perf_counter() - t0
+    n_events = sum(len(r[2]) for r in res)
+    windows = sum(int(model._lib.bp_track_n_windows(int(np.ceil(n / 2)))) for _ in paths)
+    print(json.dumps({
+        "metric": "files/sec end-to-end predict() (decode + resample + CQT + CNN + note decoding), 1 MI355X",
+        "value": len(paths) / el, "unit": "files/s", "n_gpus": 1, "higher_is_better": True, "data": "synthetic",
+        "audio_seconds_per_s": len(paths) * args.file_seconds / el, "windows_per_s": windows / el,
+        "config": {"workload": f"{len(paths)} synthetic 16-bit stereo 44.1 kHz WAV files of {args.file_seconds:g} s through "
+                   "predict_many (host WAV read on a thread pool, PCM over PCIe, device resampling, note decoding on host "
+                   "threads)", "host_threads": min(16, os.cpu_count() or 1), "note_events": n_events},
+    }), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,7 +246,9 @@ def main() -> None:
     ap.add_argument("--sustained-s", type=float, default=2.0, help="length of the extra steady-state measurement (0 = skip)")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the extra exact-f32 A/B rate (profiling runs)")
     ap.add_argument("--exact-f32", action="store_true", help="contour conv1 on the exact-f32 MFMA kernel (A/B)")
-    ap.add_argument("--workload", choices=["windows", "tracks"], default="windows",
+    ap.add_argument("--files", type=int, default=64, help="files in the job (--workload files)")
+    ap.add_argument("--file-seconds", type=float, default=180.0, help="length of each file (--workload files)")
+    ap.add_argument("--workload", choices=["windows", "tracks", "files"], default="windows",
                     help="windows: BASELINE.json configs[1] (the headline line); tracks: configs[2], whole synthetic "
                     "3-minute tracks through bp_infer_track, file-sharded over the ranks")
     ap.add_argument("--tracks", type=int, default=1000, help="tracks in the whole job (--workload tracks)")
@@ -243,6 +288,9 @@ def main() -> None:
 
     from basic_pitch_amd.inference import Model
 
+    if args.workload == "files":
+        run_files(args)
+        return
     if args.workload == "tracks":
         run_tracks(args, torch, dist, world, rank, local_rank)
         if world > 1:

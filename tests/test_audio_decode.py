@@ -91,3 +91,15 @@ def test_unknown_container_is_a_clear_error(tmp_path):
     with pytest.raises((ValueError, RuntimeError)) as e:
         audio.read_audio(p)
     assert "mp3" in str(e.value) or "decoder" in str(e.value) or "Error" in str(e.value)
+
+
+def test_second_clip_flac_decodes_and_has_the_expected_length():
+    """tests/golden/vocadito_14.flac (the reference's second recording, LPC / fixed subframes from the test-side
+    encoder): MD5-verified decode, 537,924 frames at 44.1 kHz -> ceil(n / 2) samples at 22.05 kHz."""
+    from basic_pitch_amd import audio
+
+    x, sr = audio.read_audio(os.path.join(GOLDEN, "vocadito_14.flac"))
+    assert sr == 44100 and x.shape == (537924, 1) and np.abs(x).max() <= 1.0
+    g = np.load(os.path.join(GOLDEN, "vocadito_14_expected.npz"))
+    y, _ = audio.load(os.path.join(GOLDEN, "vocadito_14.flac"))
+    assert y.shape == (int(g["n_samples_22k"][0]),) == (268962,)

@@ -555,13 +555,35 @@ def test_predict_note_events_match_reference_golden(tmp_path):
         assert list(e[4]) == list(g["bend_values"][g["bend_offsets"][i] : g["bend_offsets"][i + 1]]), i
     assert set(model_output) == {"note", "onset", "contour"}
     assert len(midi.instruments) == 1 and len(midi.instruments[0].notes) == 28
-    # predict_and_save writes the reference's three artefacts (inference.py:565-602)
-    inf.predict_and_save([wav], tmp_path, True, False, True, True)
+    # predict_and_save writes the reference's four artefacts (inference.py:565-602)
+    inf.predict_and_save([wav], tmp_path, True, True, True, True)
     stem = tmp_path / "vocadito_10_basic_pitch"
-    assert stem.with_suffix(".mid").read_bytes()[:4] == b"MThd"
+    assert stem.with_suffix(".mid").read_bytes() == open(os.path.join(GOLDEN, "midi", "clip_default.mid"), "rb").read()
+    assert stem.with_suffix(".wav").read_bytes()[:4] == b"RIFF"  # the sonified MIDI (inference.py:588-594)
     saved = np.load(stem.with_suffix(".npz"), allow_pickle=True)["basic_pitch_model_output"].item()
     assert saved["note"].shape == (787, 88)
     assert len(stem.with_suffix(".csv").read_text().strip().splitlines()) == 29
+
+
+def test_second_clip_note_events(weights):
+    """A second recording (the reference's tests/resources/vocadito_14.wav, stored losslessly as FLAC): predict() on the
+    MI355X — native FLAC decode, device resampling, CQT + CNN, C++ note decoding — against the note events the
+    unmodified reference note_creation produces from the fp64 oracle chain (tools/make_second_clip_fixture.py; the fp32
+    oracle decodes to the same events, so none of them sits on a threshold): every discrete field equal, amplitudes
+    within 1e-4, posteriorgram statistics within 1e-4."""
+    from basic_pitch_amd import inference as inf
+
+    g = np.load(os.path.join(GOLDEN, "vocadito_14_expected.npz"))
+    assert bool(g["fp32_oracle_agrees"][0])
+    out, midi, events = inf.predict(os.path.join(GOLDEN, "vocadito_14.flac"))
+    assert len(events) == len(g["pitch"]) == 26
+    for i, e in enumerate(events):
+        assert e[0] == g["start_s"][i] and e[1] == g["end_s"][i] and e[2] == g["pitch"][i], i
+        assert abs(float(e[3]) - float(g["amplitude"][i])) <= 1e-4, i
+        assert list(e[4]) == list(g["bend_values"][g["bend_offsets"][i] : g["bend_offsets"][i + 1]]), i
+    for k in ("note", "onset", "contour"):
+        assert np.abs(out[k].mean(axis=0) - g[f"{k}_colmean"]).max() <= 1e-4, k
+        assert np.abs(out[k].max(axis=1) - g[f"{k}_rowmax"]).max() <= 1e-4, k
 
 
 def test_predict_many_equals_per_file_predict(tmp_path):

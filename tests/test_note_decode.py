@@ -277,3 +277,28 @@ def test_midi_writer_roundtrip(tmp_path):
     notes = mid.instruments[0].notes
     assert [n.velocity for n in notes] == [64, 127] and [n.pitch for n in notes] == [60, 64]
     assert [b.pitch for b in mid.instruments[0].pitch_bends] == [0, 1365, 2731, 1365]
+
+
+def test_sonification_renders_the_notes(tmp_path):
+    """note_creation.sonify_midi (note_creation.py:119-128): pretty_midi's sine rendering restated.  No pretty_midi
+    output exists to compare samples with; checked here: length = end time + 1 s, peak normalised to 1, the spectrum
+    of each note's span peaks at its pitch, and the WAV file round-trips."""
+    from scipy.io import wavfile
+
+    from basic_pitch_amd import note_creation as NC
+
+    events = [(0.5, 1.5, 69, np.float32(0.8), None), (2.0, 3.0, 60, np.float32(0.5), [0, 0, 3, 3])]
+    midi = NC.note_events_to_midi(events)
+    y = midi.synthesize(22050)
+    assert y.shape == (int(22050 * 4.0),) and abs(np.abs(y).max() - 1.0) < 1e-12
+    for (t0, t1, pitch, _, bends) in events:
+        seg = y[int((t0 + 0.05) * 22050) : int((t0 + 0.45) * 22050)]
+        f = np.fft.rfftfreq(len(seg), 1 / 22050.0)[np.argmax(np.abs(np.fft.rfft(seg * np.hanning(len(seg)))))]
+        assert abs(f - 440.0 * 2 ** ((pitch - 69) / 12)) < 3.0, (pitch, f)
+    late = y[int(2.6 * 22050) : int(2.95 * 22050)]  # after the bend of +1 semitone (3 thirds) took effect
+    f = np.fft.rfftfreq(len(late), 1 / 22050.0)[np.argmax(np.abs(np.fft.rfft(late * np.hanning(len(late)))))]
+    assert abs(f - 440.0 * 2 ** ((61 - 69) / 12)) < 4.0, f
+    assert not y[: int(0.49 * 22050)].any() and not y[int(3.01 * 22050) :].any()
+    NC.sonify_midi(midi, tmp_path / "s.wav", sr=22050)
+    sr, back = wavfile.read(tmp_path / "s.wav")
+    assert sr == 22050 and np.array_equal(back, y)
