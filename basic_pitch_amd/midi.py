@@ -39,6 +39,8 @@ def instrument_name_to_program(name: str) -> int:
 
 
 class Note:
+    __slots__ = ("velocity", "pitch", "start", "end")
+
     def __init__(self, velocity: int, pitch: int, start: float, end: float):
         self.velocity, self.pitch, self.start, self.end = velocity, pitch, start, end
 
@@ -47,6 +49,8 @@ class Note:
 
 
 class PitchBend:
+    __slots__ = ("pitch", "time")
+
     def __init__(self, pitch: int, time: float):
         self.pitch, self.time = pitch, time
 
