@@ -54,7 +54,7 @@ F1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 224 * 8 * 4  # zp read + interior c1
 D1_EXECUTED_FLOP_PER_WINDOW = 45 * 8 * 63 * 3 * (2 * 32 * 32 * 16)
 D1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 264 * 8 * 4  # zp read + c1 written
 HBM_PEAK_GBS = 8000.0
-PMC_PROFILE = "r02_a"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
+PMC_PROFILE = "r02_b"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
 
 
 def pmc_traffic(kernel_key: str, batch: int):

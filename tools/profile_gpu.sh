@@ -4,11 +4,13 @@
 # (--pmc passes are separate runs with no other tracing, as gpurun requires.)
 set -u
 TAG=${1:-x}
+STEPS=${2:-10}     # 10 = the burst regime of the default bench; ~300 = steady state (clocks settled)
+WARM=${3:-3}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --sustained-s 0 --no-exact-f32"
+CMD="python $ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --sustained-s 0 --no-exact-f32"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o bench -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o bench -- $CMD > $OUT/write.log 2>&1
