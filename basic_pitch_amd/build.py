@@ -25,6 +25,7 @@ SOURCES = [
     "conv_contour.hip",
     "conv_contour_direct.hip",
     "conv_contour_rim.hip",
+    "conv_contour_fold_mx.hip",
     "conv_stride3.hip",
     "conv_heads.hip",
     "conv_branch.hip",

@@ -60,6 +60,8 @@ void launch_contour_conv1_folded(const uint32_t* zp, const void* wfold, const fl
 bool contour_conv1_full();
 void launch_contour_conv1_rim(const uint32_t* zp, const void* afrag, const float* bias, float* c1, int n_windows,
                               bool weights_have_lo, hipStream_t stream);
+void launch_contour_conv1_fold_mx(const uint32_t* zp, const void* a16, const void* amx, const void* ascale,
+                                  const float* bias, float* c1, int n_windows, int n_cu, hipStream_t stream);
 void launch_contour_conv2(const float* c1, const float* w2, float bias, float* contour, int n_windows, int n_cu,
                           hipStream_t stream);
 void launch_note_branch(const float* contour, const void* wfrag, const float* wf32, float* note,
@@ -174,8 +176,10 @@ struct bp_context {
   float *d_note_wfrag = nullptr, *d_note_wf32 = nullptr, *d_onset_wfrag = nullptr, *d_onset_wf32 = nullptr;
   float* zp = nullptr;  // uint32 [cap][kZRowsP][kZRow] pre-split z, zero padded (bp_common.h)
   // contour branch, two-kernel form (conv_contour_direct.hip): LDS weight image, bias[8], conv2 taps [5][5][8]
-  float *d_d1_wlds = nullptr, *d_d1_wfold = nullptr, *d_d1_wrim = nullptr, *d_d1_bias = nullptr, *d_d2_w = nullptr;
-  bool rim_exact = false;
+  float *d_d1_wlds = nullptr, *d_d1_wfold = nullptr, *d_d1_wrim = nullptr, *d_d1_bias = nullptr,
+        *d_d2_w = nullptr;
+  bool rim_exact = false, fold_mx = false;
+  float* d_d1_wfold_mx = nullptr;
   float* c1s = nullptr;  // [cap][172][kC1Row][8] relu(conv1); pad bins zeroed once at allocation
   bool fused_contour = false;
   bool note_ring = false;  // BP_CONTOUR_PATH=fused: the single-kernel contour branch (A/B comparisons)
@@ -461,6 +465,84 @@ void pack_contour_rim(const Tensor* w1, std::vector<uint16_t>& out) {
   }
 }
 
+// ---- block-scaled fp8 (OCP e4m3fn, as gfx950's v_mfma_scale_f32_*_f8f6f4 reads it) for correction products ----
+// encode v / 2^e to e4m3fn, round to nearest even, saturating at +-448 (no infinities in the format)
+static uint8_t f32_to_e4m3(double v) {
+  const uint8_t sign = v < 0 ? 0x80 : 0;
+  double a = std::fabs(v);
+  if (!(a > 0)) return sign;
+  if (a >= 448.0) return sign | 0x7E;
+  int ex;
+  (void)std::frexp(a, &ex);  // a = m * 2^ex, m in [0.5, 1)
+  int e = ex - 1;             // a = 1.x * 2^e
+  if (e < -6) e = -6;         // subnormal range shares the exponent of the smallest normal
+  const double q = std::nearbyint(a / std::ldexp(1.0, e - 3));  // units of 2^(e-3): 8..15 normal, 0..7 subnormal
+  int m = (int)q;
+  if (m >= 16) {
+    m = 8;
+    ++e;
+  }
+  if (e > 8) return sign | 0x7E;
+  if (m < 8) return sign | (uint8_t)m;  // subnormal (e == -6)
+  return sign | (uint8_t)(((e + 7) << 3) | (m - 8));
+}
+
+// Folded conv1 with fp8 corrections (conv_contour_fold_mx.hip, the default).  The Toeplitz-expanded folded kernel of
+// pack_contour_folded — row i = (j = i >> 3, o = i & 7), tap' = 16 e + 8 kh + el  ->  keff[o][dt][tap' - j - 1] — as
+//   a16     [36 steps][64 lanes][8] f16: the hi part;
+//   mx      [18 steps][64 lanes][32 B]: for the 16 taps tap' = 32 e + 16 kh .. + 15 of step S = 6 dt + e:
+//           bytes 0..15 fp8(lo_w) (K block 0 of the instruction), bytes 16..31 fp8(hi_w) (K block 1); lo_w = w - f16(w);
+//   scales  [64 lanes]: the E8M0 exponent of the block that lane half supplies (kh = 0: lo_w, 1: hi_w), one per row.
+void pack_contour_folded_mx(const Tensor* w1, std::vector<uint16_t>& a16, std::vector<uint8_t>& mx,
+                            std::vector<int32_t>& scales) {
+  static const int shifts[8] = {-36, 0, 36, 57, 72, 84, 93, 101};
+  std::vector<double> keff((size_t)8 * 3 * 176, 0.0);
+  for (int o = 0; o < 8; ++o)
+    for (int c = 0; c < 8; ++c)
+      for (int dt = 0; dt < 3; ++dt)
+        for (int df = 0; df < 39; ++df)
+          keff[((size_t)o * 3 + dt) * 176 + (df - 19 + shifts[c] + 55)] += (double)w1->data[((o * 8 + c) * 3 + dt) * 39 + df];
+  auto tap = [&](int i, int dt, int t) -> float {  // A[i][tap' = t] of frame dt
+    const int j = i >> 3, o = i & 7, g = t - j - 1;
+    return (g >= 0 && g < 176) ? (float)keff[((size_t)o * 3 + dt) * 176 + g] : 0.0f;
+  };
+  a16.assign((size_t)36 * 64 * 8, 0);
+  for (int dt = 0; dt < 3; ++dt)
+    for (int e = 0; e < 12; ++e)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int el = 0; el < 8; ++el)
+          a16[((size_t)(dt * 12 + e) * 64 + lane) * 8 + el] = f32_to_f16(tap(lane & 31, dt, 16 * e + 8 * (lane >> 5) + el));
+  mx.assign((size_t)18 * 64 * 32, 0);
+  // ONE E8M0 scale per accumulator row and K block for all 18 steps (a register instead of 18 in the kernel): e4m3 is a
+  // floating format with 15 binades of normals, taps 2^-15 below the row maximum are noise at the corrections' scale
+  auto block_exp = [](double m) {
+    const int e2 = m > 0 ? (int)std::ceil(std::log2(m / 448.0)) : -126;
+    return e2 < -126 ? -126 : e2;
+  };
+  auto split = [&](int i, int dt, int t, double& h, double& l) {
+    const double v = (double)tap(i, dt, t);
+    h = (double)f16_to_f32(f32_to_f16((float)v)), l = v - h;
+  };
+  std::vector<int32_t> sc(64, 127);
+  for (int i = 0; i < 32; ++i) {
+    double mlo = 0, mhi = 0, h, l;
+    for (int dt = 0; dt < 3; ++dt)
+      for (int t = 0; t < 192; ++t) split(i, dt, t, h, l), mlo = std::fmax(mlo, std::fabs(l)), mhi = std::fmax(mhi, std::fabs(h));
+    const int elo = block_exp(mlo), ehi = block_exp(mhi);
+    sc[i] = 127 + elo;       // lane (i, kh = 0): K block 0 = lo_w
+    sc[32 + i] = 127 + ehi;  // lane (i, kh = 1): K block 1 = hi_w
+    for (int S = 0; S < 18; ++S)
+      for (int kh = 0; kh < 2; ++kh)
+        for (int el = 0; el < 16; ++el) {
+          split(i, S / 6, 32 * (S % 6) + 16 * kh + el, h, l);
+          uint8_t* dst = &mx[((size_t)S * 64 + 32 * kh + i) * 32];
+          dst[el] = f32_to_e4m3(std::ldexp(l, -elo));
+          dst[16 + el] = f32_to_e4m3(std::ldexp(h, -ehi));
+        }
+  }
+  scales = sc;
+}
+
 // contour conv1 Toeplitz B fragments [4 waves][126][64] (conv_contour1.hip).
 void pack_contour1(const Tensor* w, std::vector<float>& out) {
   static const int chan[4][2] = {{0, 1}, {2, 4}, {5, 3}, {6, 7}};
@@ -589,7 +671,7 @@ void pack_filterbank_f16(const Tensor* re, const Tensor* im, std::vector<uint16_
 }
 
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wrim, h->d_d1_bias, h->d_d2_w, h->d_cb_wfrag, h->d_cb_wf32, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wrim, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_cb_wfrag, h->d_cb_wf32, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->fb_scratch, h->pcm_dev, h->mono_dev, h->res_dev, reinterpret_cast<float*>(h->taps_dev)};
@@ -692,8 +774,14 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
       if (!contour_conv1_full()) {
         BP_MARK(BP_STAGE_CONTOUR_CONV1_EDGE);
         BP_DOM_BEGIN();
-        launch_contour_conv1_folded(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wfold, h->d_d1_bias, h->c1s, n,
-                                    h->n_cu, wlo, s);
+        if (h->fold_mx && wlo) {
+          const char* base = reinterpret_cast<const char*>(h->d_d1_wfold_mx);
+          launch_contour_conv1_fold_mx(reinterpret_cast<const uint32_t*>(h->zp), base, base + 36 * 64 * 16,
+                                       base + 36 * 64 * 16 + 18 * 64 * 32, h->d_d1_bias, h->c1s, n, h->n_cu, s);
+        } else {
+          launch_contour_conv1_folded(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wfold, h->d_d1_bias, h->c1s, n,
+                                      h->n_cu, wlo, s);
+        }
       }
       BP_DOM_END(BP_STAGE_CONTOUR_CONV1);
       BP_MARK(BP_STAGE_CONTOUR_CONV1);
@@ -885,6 +973,20 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wfold))) return fail(rc);
     pack_contour_rim(c1w, frag);
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wrim))) return fail(rc);
+    // folded conv1: fp8 block-scaled corrections by default (conv_contour_fold_mx.hip); BP_CONV1=f16 selects the
+    // three-product f16 kernel (A/B runs, and the reference for the fp8 corrections' ~1e-5 on the contour map)
+    if (const char* ec = std::getenv("BP_CONV1"); !(ec && std::strcmp(ec, "f16") == 0) && !(flags & BP_FLAG_BF16_WEIGHTS)) {
+      std::vector<uint16_t> a16;
+      std::vector<uint8_t> mxf;
+      std::vector<int32_t> mxs;
+      pack_contour_folded_mx(c1w, a16, mxf, mxs);
+      std::vector<float> raw(a16.size() / 2 + mxf.size() / 4 + mxs.size());
+      std::memcpy(raw.data(), a16.data(), a16.size() * 2);
+      std::memcpy(raw.data() + a16.size() / 2, mxf.data(), mxf.size());
+      std::memcpy(raw.data() + a16.size() / 2 + mxf.size() / 4, mxs.data(), mxs.size() * 4);
+      if ((rc = upload(h, raw, &h->d_d1_wfold_mx))) return fail(rc);
+      h->fold_mx = true;
+    }
     {
       const char* er = std::getenv("BP_RIM");  // "exact": the round-1 rim kernel on the 8-channel form (A/B runs)
       // the extended 345-bin CQT (BP_FLAG_EXT_CQT_44K) feeds bins 309..344 into the high rim: its GEMM table is built for
@@ -1469,7 +1571,13 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
             launch_contour_conv1_exact(bf->zp, h->d_d1_wlds, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
           else
             launch_contour_conv1_rim(bf->zp, h->d_d1_wrim, h->d_d1_bias, h->c1s, n, wlo, s);
-          launch_contour_conv1_folded(bf->zp, h->d_d1_wfold, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
+          if (h->fold_mx && wlo) {
+            const char* base = reinterpret_cast<const char*>(h->d_d1_wfold_mx);
+            launch_contour_conv1_fold_mx(bf->zp, base, base + 36 * 64 * 16, base + 36 * 64 * 16 + 18 * 64 * 32, h->d_d1_bias,
+                                         h->c1s, n, h->n_cu, s);
+          } else {
+            launch_contour_conv1_folded(bf->zp, h->d_d1_wfold, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
+          }
           launch_contour_conv2(h->c1s, h->d_d2_w, h->b_contour2, bf->contour, n, h->n_cu, s);
         }
       }

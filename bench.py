@@ -14,9 +14,9 @@ and `value` = windows processed by all ranks / max-over-ranks time.
 Extra objects on the JSON line:
   roofline      dominant kernel (contour_conv1_kernel: Conv2D 8->8 3x39, 65 % of the path's FLOPs): algorithmic FLOP per
                 launch / mean launch duration measured with HIP events on the kernel's stream over the
-                timed steps, against the dense f16 MFMA peak (2.5 PFLOP/s; the kernel spends 3 f16 MFMAs per
-                product to keep fp32-class accuracy, so frac <= 1/3 by construction — executed_frac is the
-                matrix-pipe occupancy)
+                timed steps, against the dense f16 MFMA peak (2.5 PFLOP/s; the kernel spends one f16 MFMA per
+                product plus half an f16-equivalent on block-scaled fp8 for the two split-precision corrections,
+                so frac <= 1/2 by construction — executed_frac is the matrix-pipe occupancy)
   cpu_baseline  the oracle's C restatement of the frozen graph (fp32, AVX2, OpenMP over windows, all host
                 cores) timed on rank 0 on a bounded sample of the same synthetic windows ("port": the
                 reference's own ONNX/TF runtimes are not installable here)
@@ -50,10 +50,17 @@ CB_EXECUTED_FLOP_PER_WINDOW = 2 * 186 * (63 * 3 + 4 * 2) * (2 * 32 * 32 * 16)
 # MFMAs (hi*hi, lo*hi, hi*lo).  BP_CONV1=full: the exact kernel over all 66 groups, 45 rounds x 8 waves x 63 x 3.
 F1_SHARE = 56.0 / 66.0
 F1_EXECUTED_FLOP_PER_WINDOW = 38 * 8 * 36 * 3 * (2 * 32 * 32 * 16)
+# contour_conv1_fold_mx_kernel (conv_contour_fold_mx.hip, the default): same tiling, per tile 36 f16 MFMAs (hi*hi) + 18
+# block-scaled fp8 32x32x64 MFMAs (lo*hi and hi*lo of 32 taps each).  Counted in f16-equivalent FLOPs = matrix-pipe time:
+# the fp8 instruction does 4x the MACs of the f16 one in 2x its cycles, so its FLOPs count half.
+FX_EXECUTED_FLOP_PER_WINDOW = 38 * 8 * (36 * (2 * 32 * 32 * 16) + 18 * (2 * 32 * 32 * 64) // 2)
 F1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 224 * 8 * 4  # zp read + interior c1 written
 D1_EXECUTED_FLOP_PER_WINDOW = 45 * 8 * 63 * 3 * (2 * 32 * 32 * 16)
 D1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 264 * 8 * 4  # zp read + c1 written
 HBM_PEAK_GBS = 8000.0
+DTYPE_F16 = "f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands"
+DTYPE_DEFAULT = (DTYPE_F16 + "; contour conv1 interior: hi*hi on f16, its two correction products (<= 2^-11 of a product) on "
+                 "block-scaled fp8 MFMA (BP_CONV1=f16: all three on f16)")
 PMC_PROFILE = "r02_b"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
 
 
@@ -180,7 +187,7 @@ def run_tracks(args, torch, dist, world, rank, local_rank) -> None:
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands",
+            "dtype": DTYPE_DEFAULT if os.environ.get("BP_CONV1") != "f16" else DTYPE_F16,
             "data": "synthetic",
             "config": {
                 "workload": f"{args.tracks} synthetic 3-minute tracks (110 windows each) through bp_infer_tracks (64 tracks per call), "
@@ -419,7 +426,17 @@ def main() -> None:
             c1_ms = stage["contour_conv1"]
             folded = stage.get("contour_conv1_edge", 0.0) > 0.0
             mf = (2 / 3 if args.bf16_weights else 1)
-            if folded:
+            mx = folded and os.environ.get("BP_CONV1") != "f16" and not args.bf16_weights
+            if mx:
+                c1_flop = C1_FLOP_PER_WINDOW * F1_SHARE
+                c1_kernel = ("contour_conv1_fold_mx_kernel (interior 56/66 of harmonic stack + Conv2D 8->8 3x39 + ReLU with the 8 "
+                             "shifted channels folded into one 176-tap kernel; hi*hi on f16 MFMA 32x32x16, the lo*hi + hi*lo "
+                             "corrections on block-scaled fp8 MFMA 32x32x64, one fp32 accumulator; algorithmic FLOPs = the "
+                             "reference's 8-channel products it replaces; executed = f16-equivalent matrix-pipe FLOPs)")
+                c1_exec = FX_EXECUTED_FLOP_PER_WINDOW * B / (c1_ms * 1e-3) / 1e12
+                c1_bytes = F1_BYTES_PER_WINDOW * B
+                c1_key = "contour_conv1_fold_mx_kernel"
+            elif folded:
                 c1_flop = C1_FLOP_PER_WINDOW * F1_SHARE
                 c1_kernel = ("contour_conv1_folded_kernel (interior 56/66 of harmonic stack + Conv2D 8->8 3x39 + ReLU with the 8 "
                              "shifted channels folded into one 176-tap kernel; f16 MFMA 32x32x16 on hi/lo-split operands from "
@@ -461,7 +478,7 @@ def main() -> None:
             # weights rounded to bf16 (one f16 operand), activations and CQT unchanged
             "dtype": ("f32 I/O + accumulate, bf16-rounded weights as single f16 MFMA operands, split-f16 activations" if args.bf16_weights
                       else "exact f32 MFMA (A/B path)" if args.exact_f32
-                      else "f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands"),
+                      else DTYPE_DEFAULT if os.environ.get("BP_CONV1") != "f16" else DTYPE_F16),
             "data": "synthetic",
             "config": {
                 "workload": f"batch={B} synthetic uniform[-1,1) 2 s @ 22.05 kHz mono windows per GPU, "

@@ -122,14 +122,23 @@ def test_stage_zpack(runner, cases):
     assert np.abs(z - r32["z"]).max() <= 2e-6  # fp32 rounding of the normalisation + 2^-22 split residue
 
 
-@pytest.mark.parametrize("branch", ["contour", "note", "onset"])
-def test_stage_fused_branch(runner, cases, branch):
+@pytest.mark.parametrize("branch", ["contour", "contour_f16", "note", "onset"])
+def test_stage_fused_branch(runner, cases, branch, monkeypatch):
     """The fused split-precision branches (conv -> ReLU -> conv -> sigmoid in one kernel) against the
-    oracle's fp32 posteriorgrams, fed with the oracle's own inputs of that branch."""
-    from stage_harness import zp_pack
+    oracle's fp32 posteriorgrams, fed with the oracle's own inputs of that branch.
+
+    All products are split-f16 (hi hi + lo hi + hi lo, fp32 accumulate): 5e-6.  The default contour conv1 issues the two
+    correction products of its folded interior on the block-scaled fp8 matrix instruction (3-bit mantissas on terms
+    that are <= 2^-11 of the product): 2e-5 there, and `BP_CONV1=f16` (same kernel structure, all three products in
+    f16) keeps the 5e-6."""
+    from stage_harness import StageRunner, zp_pack
 
     x, r32, r64 = cases
     n = x.shape[0]
+    tol = 2e-5 if branch == "contour" else 5e-6
+    if branch == "contour_f16":
+        monkeypatch.setenv("BP_CONV1", "f16")
+        runner, branch = StageRunner(), "contour"
     if branch == "note":
         feed = {"contour": r32["contour"]}
     elif branch == "contour":
@@ -140,7 +149,7 @@ def test_stage_fused_branch(runner, cases, branch):
     got = runner.run(branch, n, feed, {branch: ((n, 172, width), F32)})[branch]
     assert np.isfinite(got).all()
     d32 = np.abs(got - r32[branch]).max()
-    assert d32 <= 5e-6, (branch, d32)
+    assert d32 <= tol, (branch, d32)
 
 
 def test_exact_f32_reference_path(cases):
@@ -176,7 +185,8 @@ def test_fused_contour_kernel_ab(cases, monkeypatch):
         outs[name] = m.predict(x)
         m.close()
     for k in ("note", "onset", "contour"):
-        assert np.abs(outs["direct"][k] - outs["fused"][k]).max() <= 5e-6, k
+        # 2e-5: the default ("direct") path carries the fp8 corrections of the folded conv1, the fused kernel does not
+        assert np.abs(outs["direct"][k] - outs["fused"][k]).max() <= 2e-5, k
         assert np.abs(outs["fused"][k][:3] - r64[k][:3]).max() <= 1e-4, k
 
 

@@ -102,7 +102,7 @@ __global__ void layout(float* out) {
   f32x16 c;
   for (int r = 0; r < 16; ++r) c[r] = 0.f;
   // scales: A blocks x 2^1 (E8M0 128) for kh = 0 and x 2^-2 (125) for kh = 1; B all 2^0
-  const int sa = kh ? 125 : 128, sb = 127;
+  const int sa = kh ? 125 : 128, sb = kh ? 129 : 126;  // B: x 2^-1 for K block 0, x 2^2 for K block 1
   c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb);
   for (int r = 0; r < 16; ++r) out[lane * 16 + r] = c[r];
 }
@@ -123,7 +123,7 @@ int main() {
     for (int r = 0; r < 16; ++r) {
       const int n = lane & 31, m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       double ref = 0;
-      for (int k = 0; k < 64; ++k) ref += (double)((m + k) % 5) * ((2 * n + 3 * k) % 5) * (k < 32 ? 2.0 : 0.25);
+      for (int k = 0; k < 64; ++k) ref += (double)((m + k) % 5) * ((2 * n + 3 * k) % 5) * (k < 32 ? 2.0 * 0.5 : 0.25 * 4.0);
       if (fabs(ref - h[lane * 16 + r]) > 1e-3) {
         if (bad < 5) printf("mismatch C[%d][%d]: got %g want %g\n", m, n, h[lane * 16 + r], ref);
         ++bad;
