@@ -21,6 +21,7 @@ BP_FLAG_TIME_DOMINANT = 16
 BP_FLAG_F32_MFMA = 2
 BP_FLAG_BF16_WEIGHTS = 4
 BP_FLAG_EXT_CQT_44K = 8
+BP_FLAG_F16_CORRECTIONS = 32
 BP_N_STAGES = 15
 BP_Z_ROW = 448
 BP_Z_ROWS = 174

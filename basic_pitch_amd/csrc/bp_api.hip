@@ -68,7 +68,7 @@ void launch_note_branch(const float* contour, const void* wfrag, const float* wf
                         int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
 void launch_note_march(const float* contour, const void* wfrag, const float* wf32, float* note, int n_windows,
                        bool weights_have_lo, hipStream_t stream);
-void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32,
+void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, const void* wmx,
                          float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
 }  // namespace bp
 
@@ -173,7 +173,8 @@ struct bp_context {
   float *d_lowpass = nullptr, *d_sqrt_len = nullptr, *d_fb_bfrag = nullptr;
   float *d_cb_wfrag = nullptr, *d_cb_wf32 = nullptr;  // fused contour branch (conv_contour.hip)
   // fused branches (conv_branch.hip): f16 hi/lo A fragments (raw bytes) + {bias1[32], extra[9], bias2}
-  float *d_note_wfrag = nullptr, *d_note_wf32 = nullptr, *d_onset_wfrag = nullptr, *d_onset_wf32 = nullptr;
+  float *d_note_wfrag = nullptr, *d_note_wf32 = nullptr, *d_onset_wfrag = nullptr, *d_onset_wf32 = nullptr,
+        *d_onset_wmx = nullptr;
   float* zp = nullptr;  // uint32 [cap][kZRowsP][kZRow] pre-split z, zero padded (bp_common.h)
   // contour branch, two-kernel form (conv_contour_direct.hip): LDS weight image, bias[8], conv2 taps [5][5][8]
   float *d_d1_wlds = nullptr, *d_d1_wfold = nullptr, *d_d1_wrim = nullptr, *d_d1_bias = nullptr,
@@ -587,6 +588,38 @@ void pack_note1(const Tensor* w, std::vector<float>& out) {
 // A1 lane (i = out channel = lane & 31, h = lane >> 5), element e: conv1 weight of k = 8h + e of step s.
 // A2 lane (i = projection row, h), element e of step s2: conv2 weight of the channel that C-register
 // 8*s2 + e of half h holds: (e & 3) + 16*s2 + 8*(e >> 2) + 4h.
+// Onset conv1 correction products on the block-scaled fp8 instruction (conv_branch.hip, MX variant):
+//   mx [7 steps][64 lanes][32 B] then [64] E8M0 scales.  Lane (i = out channel, kh) of step S: bytes 0..15 = tap
+//   4 S + kh of the 5x5 window, bytes 16..31 = tap 4 S + 2 + kh (taps >= 25: zero); per tap [fp8(lo_w) x 8 channels |
+//   fp8(hi_w) x 8 channels], meeting the image slot's [fp8(a) | fp8(lo_a)].  ONE scale per out channel for both kinds:
+//   lo_w is stored 2^11 larger than hi_w (|lo_w| <= 2^-11 |w|), lo_a arrives 2^11 larger than a, so both products carry
+//   2^(e - 17) and a 32-tap K block may mix them.
+void pack_onset_mx(const Tensor* w1, std::vector<uint8_t>& mx, std::vector<int32_t>& scales, int sa_exp) {
+  mx.assign((size_t)7 * 64 * 32, 0);
+  scales.assign(64, 127);
+  for (int i = 0; i < 32; ++i) {
+    double mhi = 0;
+    for (int k = 0; k < 8 * 25; ++k) mhi = std::fmax(mhi, std::fabs((double)f16_to_f32(f32_to_f16(w1->data[i * 200 + k]))));
+    int e = mhi > 0 ? (int)std::ceil(std::log2(mhi / 448.0)) : -100;
+    e = e < -100 ? -100 : e;
+    // products: (A0 2^(e-11)) (a8 2^-sa) and (A1 2^e) (lo8 2^-sa 2^-11): scale_a = 2^(e-11), scale_b = 2^-sa
+    scales[i] = scales[32 + i] = 127 + e - 11;
+    for (int S = 0; S < 7; ++S)
+      for (int kh = 0; kh < 2; ++kh)
+        for (int part = 0; part < 2; ++part) {
+          const int q = 4 * S + 2 * part + kh;
+          uint8_t* dst = &mx[((size_t)S * 64 + 32 * kh + i) * 32 + 16 * part];
+          for (int c = 0; c < 8; ++c) {
+            const double v = q < 25 ? (double)w1->data[((i * 8 + c) * 5 + q / 5) * 5 + q % 5] : 0.0;
+            const double hi = (double)f16_to_f32(f32_to_f16((float)v));
+            dst[c] = f32_to_e4m3(std::ldexp(v - hi, -(e - 11)));
+            dst[8 + c] = f32_to_e4m3(std::ldexp(hi, -e));
+          }
+        }
+  }
+  (void)sa_exp;
+}
+
 void pack_branch(int ks1, const Tensor* w1, const Tensor* w2, bool onset, std::vector<uint16_t>& out) {
   const size_t a1h = 0, a1l = (size_t)ks1 * 64 * 8, a2h = 2 * a1l, a2l = a2h + 2 * 64 * 8;
   out.assign(a2l + 2 * 64 * 8, 0);
@@ -671,7 +704,7 @@ void pack_filterbank_f16(const Tensor* re, const Tensor* im, std::vector<uint16_
 }
 
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wrim, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_cb_wfrag, h->d_cb_wf32, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wrim, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_cb_wfrag, h->d_cb_wf32, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->fb_scratch, h->pcm_dev, h->mono_dev, h->res_dev, reinterpret_cast<float*>(h->taps_dev)};
@@ -793,7 +826,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
     else
       launch_note_march(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, wlo, s);
     BP_MARK(BP_STAGE_NOTE);
-    launch_onset_branch(reinterpret_cast<const uint32_t*>(h->zp), note_dev, h->d_onset_wfrag, h->d_onset_wf32,
+    launch_onset_branch(reinterpret_cast<const uint32_t*>(h->zp), note_dev, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx,
                         onset_dev, n, h->n_cu, wlo, s);
     BP_MARK(BP_STAGE_ONSET);
   }
@@ -975,7 +1008,11 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wrim))) return fail(rc);
     // folded conv1: fp8 block-scaled corrections by default (conv_contour_fold_mx.hip); BP_CONV1=f16 selects the
     // three-product f16 kernel (A/B runs, and the reference for the fp8 corrections' ~1e-5 on the contour map)
-    if (const char* ec = std::getenv("BP_CONV1"); !(ec && std::strcmp(ec, "f16") == 0) && !(flags & BP_FLAG_BF16_WEIGHTS)) {
+    // the fp8 planes hold z 2^6 with z = bn_a x + bn_b, x in [0, 1] (NormalizedLog): they must stay below e4m3's 448
+    const bool fp8_ok = std::fmax(std::fabs(h->kc.bn_b), std::fabs(h->kc.bn_a + h->kc.bn_b)) * 64.0f <= 440.0f &&
+                        !(flags & BP_FLAG_F16_CORRECTIONS);
+    if (const char* ec = std::getenv("BP_CONV1");
+        !(ec && std::strcmp(ec, "f16") == 0) && fp8_ok && !(flags & BP_FLAG_BF16_WEIGHTS)) {
       std::vector<uint16_t> a16;
       std::vector<uint8_t> mxf;
       std::vector<int32_t> mxs;
@@ -1010,6 +1047,16 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       if ((rc = upload(h, raw_of(frag), br ? &h->d_onset_wfrag : &h->d_note_wfrag)) ||
           (rc = upload(h, f32, br ? &h->d_onset_wf32 : &h->d_note_wf32)))
         return fail(rc);
+    }
+    // onset conv1: fp8 corrections by default like the folded contour conv1; BP_ONSET=f16 selects the three-product kernel
+    if (const char* eo = std::getenv("BP_ONSET"); !(eo && std::strcmp(eo, "f16") == 0) && fp8_ok && !(flags & BP_FLAG_BF16_WEIGHTS)) {
+      std::vector<uint8_t> mxf;
+      std::vector<int32_t> mxs;
+      pack_onset_mx(o1w, mxf, mxs, 6);
+      std::vector<float> raw(mxf.size() / 4 + mxs.size());
+      std::memcpy(raw.data(), mxf.data(), mxf.size());
+      std::memcpy(raw.data() + mxf.size() / 4, mxs.data(), mxs.size() * 4);
+      if ((rc = upload(h, raw, &h->d_onset_wmx))) return fail(rc);
     }
   }
   pack_contour1(c1w, c1f);
@@ -1591,7 +1638,8 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
       break;
     case BP_STAGE_ONSET:
       if ((ok = need(bf->zp) && need(bf->note) && need(bf->onset)))
-        launch_onset_branch(bf->zp, bf->note, h->d_onset_wfrag, h->d_onset_wf32, bf->onset, n, h->n_cu, wlo, s);
+        launch_onset_branch(bf->zp, bf->note, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, bf->onset, n, h->n_cu, wlo,
+                            s);
       break;
     default:
       h->err = "bp_run_stage: unknown stage";

@@ -55,6 +55,7 @@ struct BranchParams {
   float* out;          // [n][172][88]
   int n_windows;
   unsigned long long* prof;  // tools only: per-phase reference-clock totals of block 0 (null in production)
+  const uint4* wmx;    // MX kernels: [kMxSteps][64 lanes][2] x 16 bytes of fp8 conv1 corrections, then [64] E8M0 scales
 };
 
 // ---- branch descriptions ----------------------------------------------------------------------
@@ -105,6 +106,26 @@ struct OnsetBr {
 __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
   hi = (_Float16)v;
   lo = (_Float16)((v - (float)hi) * kLoScale);
+}
+
+// ---- fp8 planes of the MX variant (the correction products lo_w a + hi_w lo_a of conv1 on
+// v_mfma_scale_f32_32x32x64_f8f6f4, see conv_contour_fold_mx.hip): a slot of the second image then holds
+// [fp8(a 2^6) x 8 channels | fp8(lo_a 2^6) x 8 channels] instead of 8 f16 lo parts — the same 16 bytes.
+using s16x2 = __attribute__((ext_vector_type(2))) short;
+using h16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using i32x8 = __attribute__((ext_vector_type(8))) int;
+constexpr int kMxSA = 6;      // |z| <= 1.61 (BN of a [0, 1] map, checked in bp_create): a 2^6 <= 103 < 448
+constexpr int kMxSteps = 7;   // onset conv1: 28 taps (25 + 3 zero) in steps of 4 taps x 8 channels
+__device__ __forceinline__ uint32_t fp8x4_of_f16x4(uint32_t pair01, uint32_t pair23) {
+  s16x2 r = {0, 0};
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h16x2, pair01), 1.0f / (float)(1 << kMxSA), false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h16x2, pair23), 1.0f / (float)(1 << kMxSA), true);
+  return __builtin_bit_cast(uint32_t, r);
+}
+// (hi f16 x 8, lo f16 x 8) of a slot -> its fp8 form
+__device__ __forceinline__ uint4 fp8_slot(const uint4 vh, const uint4 vl) {
+  return uint4{fp8x4_of_f16x4(vh.x, vh.y), fp8x4_of_f16x4(vh.z, vh.w), fp8x4_of_f16x4(vl.x, vl.y),
+               fp8x4_of_f16x4(vl.z, vl.w)};
 }
 
 // ---- image staging: `nrows` rows starting at `row_first` (absolute frame index, may be outside the window).
@@ -172,7 +193,7 @@ __device__ __forceinline__ void note_stage_commit(const NoteStage<NROWS>& st, ui
   }
 }
 
-template <class Br, int NROWS>
+template <class Br, int NROWS, bool MX = false>
 __device__ __forceinline__ void stage_rows(const BranchParams& p, int b, int row_first,
                                            uint4* __restrict__ img_hi, uint4* __restrict__ img_lo, int tid) {
   constexpr int PER_ROW = Br::kOnset ? kFreqC : Br::SLOTS;       // tasks per row
@@ -215,19 +236,20 @@ __device__ __forceinline__ void stage_rows(const BranchParams& p, int b, int row
       vl.z = (u[k][4] >> 16) | (u[k][5] & 0xffff0000u);
       vl.w = (u[k][6] >> 16) | (u[k][7] & 0xffff0000u);
       img_hi[dst[k]] = vh;
-      img_lo[dst[k]] = vl;
+      img_lo[dst[k]] = MX ? fp8_slot(vh, vl) : vl;
     }
   }
 }
 
 // `NROWS` rows in pieces of Br::PIECE rows: bounds the registers a staging call holds in flight
-template <class Br, int NROWS>
+template <class Br, int NROWS, bool MX = false>
 __device__ __forceinline__ void stage_block(const BranchParams& p, int b, int row_first, uint4* __restrict__ img_hi,
                                             uint4* __restrict__ img_lo, int tid) {
   constexpr int P = Br::PIECE;
 #pragma unroll
-  for (int r = 0; r + P <= NROWS; r += P) stage_rows<Br, P>(p, b, row_first + r, img_hi, img_lo, tid);
-  if constexpr (NROWS % P != 0) stage_rows<Br, NROWS % P>(p, b, row_first + NROWS - NROWS % P, img_hi, img_lo, tid);
+  for (int r = 0; r + P <= NROWS; r += P) stage_rows<Br, P, MX>(p, b, row_first + r, img_hi, img_lo, tid);
+  if constexpr (NROWS % P != 0)
+    stage_rows<Br, NROWS % P, MX>(p, b, row_first + NROWS - NROWS % P, img_hi, img_lo, tid);
 }
 
 // ---- steady-state staging: the kBrRows source rows of the NEXT phase come in by LDS-DMA (global_load_lds_dwordx4:
@@ -271,7 +293,7 @@ __device__ __forceinline__ void raw_dma_issue(const BranchParams& p, int b, int 
   }
 }
 
-template <class Br>
+template <class Br, bool MX = false>
 __device__ __forceinline__ void raw_convert(int row_first, const uint4* raw_, uint4* __restrict__ img_hi,
                                             uint4* __restrict__ img_lo, int tid) {
   // the DMA's LDS writes are invisible to the optimiser: read through a laundered pointer
@@ -300,7 +322,7 @@ __device__ __forceinline__ void raw_convert(int row_first, const uint4* raw_, ui
       vl.w = (u[6] >> 16) | (u[7] & 0xffff0000u);
       const int dst = ((row + 64 * Br::RING) % Br::RING) * Br::SLOTS + f + 1;
       img_hi[dst] = vh;
-      img_lo[dst] = vl;
+      img_lo[dst] = MX ? fp8_slot(vh, vl) : vl;
     } else {
       if (row >= 0 && row < kFrames) {
         const float* fl = reinterpret_cast<const float*>(raw + Br::RAW_PAD + rr * Br::RAW_ROW) + 3 * f - 2;
@@ -322,8 +344,11 @@ __device__ __forceinline__ void raw_convert(int row_first, const uint4* raw_, ui
 }
 
 // WLO = false: conv1 weights without a lo part (BP_FLAG_BF16_WEIGHTS): 2 MFMAs per k-step
-template <class Br, bool WLO, bool PROF = false>
+// MX = true (onset, WLO): conv1's two correction products on the block-scaled fp8 instruction, everything in ONE
+// accumulator: per tile 13 f16 + 7 fp8 matrix instructions (864 pipe cycles) instead of 39 f16 ones (1248)
+template <class Br, bool WLO, bool PROF = false, bool MX = false>
 __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParams p) {
+  static_assert(!MX || (Br::kOnset && WLO), "the fp8-correction variant exists for the onset branch");
   unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0};
   unsigned long long t_prev = PROF ? __builtin_readcyclecounter() : 0;
 #define BR_STAMP(k)                                                \
@@ -342,11 +367,21 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
   const int h = lane >> 5, li = lane & 31;
 
   // resident A operands (weights) and biases
-  uint4 a1h[KS1], a1l[KS1], a2h[2], a2l[2];
+  uint4 a1h[KS1], a1l[MX ? 1 : KS1], a2h[2], a2l[2];
+  i32x8 amx[MX ? kMxSteps : 1];
+  int amx_scale = 127;
 #pragma unroll
   for (int s = 0; s < KS1; ++s) {
     a1h[s] = p.wfrag[s * 64 + lane];
-    a1l[s] = p.wfrag[(KS1 + s) * 64 + lane];
+    if (!MX) a1l[s] = p.wfrag[(KS1 + s) * 64 + lane];
+  }
+  if constexpr (MX) {
+#pragma unroll
+    for (int S = 0; S < kMxSteps; ++S) {
+      const uint4 m0 = p.wmx[(S * 64 + lane) * 2], m1 = p.wmx[(S * 64 + lane) * 2 + 1];
+      amx[S] = i32x8{(int)m0.x, (int)m0.y, (int)m0.z, (int)m0.w, (int)m1.x, (int)m1.y, (int)m1.z, (int)m1.w};
+    }
+    amx_scale = reinterpret_cast<const int*>(p.wmx + kMxSteps * 64 * 2)[lane];
   }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -386,7 +421,7 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
     const int n_phase = (T1 - T0 + 2 * PH2 + kBrRows - 1) / kBrRows;
 
     __syncthreads();  // previous item finished with the rings
-    stage_block<Br, Br::RING>(p, b, T0 - PH2 - PH1, img_hi, img_lo, threadIdx.x);
+    stage_block<Br, Br::RING, MX>(p, b, T0 - PH2 - PH1, img_hi, img_lo, threadIdx.x);
     // onset: the note values (concat channel 0, models.py:305) of this lane's pixels in the phase's three tiles are
     // fetched one phase ahead into registers, right in front of a vmcnt(0) wait that exists anyway: no global load is
     // left inside the tile loop (one there makes the compiler wait on vmcnt in front of every tile's MFMAs, and with
@@ -447,41 +482,82 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
             acc[r] = bias1[r];
             accc[r] = 0.0f;
           }
-          // image fragments are read kBrPf k-steps ahead of the MFMAs that consume them (the compiler's own
-          // schedule waits for every read right after issuing it)
-          constexpr int kBrPf = KS1 < 3 ? KS1 : 3;
-          f16x8 bhf[KS1], blf[KS1];
-          auto issue = [&](int s) {
-            const int o0 = rb[Br::d_of(s, 0)] + Br::x_of(s, 0);
-            const int o1 = rb[Br::d_of(s, 1)] + Br::x_of(s, 1);
-            const int slot = lane_off + (h ? o1 : o0);
-            bhf[s] = __builtin_bit_cast(f16x8, img_hi[slot]);
-            blf[s] = __builtin_bit_cast(f16x8, img_lo[slot]);
-          };
-#pragma unroll
-          for (int s = 0; s < kBrPf; ++s) issue(s);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int s = 0; s < KS1; ++s) {
-            if (s + kBrPf < KS1) issue(s + kBrPf);
-            __builtin_amdgcn_sched_barrier(0);
-            const f16x8 ah = __builtin_bit_cast(f16x8, a1h[s]);
-            const f16x8 al = __builtin_bit_cast(f16x8, a1l[s]);
-            if (WLO) accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhf[s], accc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhf[s], acc, 0, 0, 0);
-            accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blf[s], accc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-
-          // ReLU, split, and the tap projection (two values per VALU operation where the packed-f32 pipe has one)
           uint32_t b2hw[8], b2lw[8];
+          if constexpr (!MX) {
+            // image fragments are read kBrPf k-steps ahead of the MFMAs that consume them (the compiler's own
+            // schedule waits for every read right after issuing it)
+            constexpr int kBrPf = KS1 < 3 ? KS1 : 3;
+            f16x8 bhf[KS1], blf[KS1];
+            auto issue = [&](int s) {
+              const int o0 = rb[Br::d_of(s, 0)] + Br::x_of(s, 0);
+              const int o1 = rb[Br::d_of(s, 1)] + Br::x_of(s, 1);
+              const int slot = lane_off + (h ? o1 : o0);
+              bhf[s] = __builtin_bit_cast(f16x8, img_hi[slot]);
+              blf[s] = __builtin_bit_cast(f16x8, img_lo[slot]);
+            };
 #pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            f32x2 v = __builtin_elementwise_fma(f32x2{accc[r], accc[r + 1]}, f32x2{kLoUnscale, kLoUnscale},
-                                                f32x2{acc[r], acc[r + 1]});
-            v.x = fmaxf(v.x, 0.0f);
-            v.y = fmaxf(v.y, 0.0f);
-            split_f16x2(v, b2hw[r >> 1], b2lw[r >> 1]);
+            for (int s = 0; s < kBrPf; ++s) issue(s);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+              if (s + kBrPf < KS1) issue(s + kBrPf);
+              __builtin_amdgcn_sched_barrier(0);
+              const f16x8 ah = __builtin_bit_cast(f16x8, a1h[s]);
+              const f16x8 al = __builtin_bit_cast(f16x8, a1l[s]);
+              if (WLO) accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhf[s], accc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhf[s], acc, 0, 0, 0);
+              accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blf[s], accc, 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            // ReLU, split, and the tap projection (two values per VALU operation where the packed-f32 pipe has one)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              f32x2 v = __builtin_elementwise_fma(f32x2{accc[r], accc[r + 1]}, f32x2{kLoUnscale, kLoUnscale},
+                                                  f32x2{acc[r], acc[r + 1]});
+              v.x = fmaxf(v.x, 0.0f);
+              v.y = fmaxf(v.y, 0.0f);
+              split_f16x2(v, b2hw[r >> 1], b2lw[r >> 1]);
+            }
+          } else {
+            // block S = k-steps 2 S, 2 S + 1 on the f16 instruction (hi x hi) + one block-scaled fp8 instruction for the
+            // corrections of the same four taps: lane half h holds taps 4 S + h (bytes 0..15: fp8(a) | fp8(lo_a) of its 8
+            // channels) and 4 S + 2 + h (bytes 16..31) — the slots its two hi reads use.  One E8M0 scale for both
+            // correction kinds (bp_api.hip pack_onset_mx), so a 32-tap K block may mix them.  Operands one block ahead.
+            constexpr int kBlocks = kMxSteps;
+            f16x8 bhf[2][2];
+            uint4 bmf[2][2];
+            auto issue = [&](int S, int buf) {
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const int s = 2 * S + i < KS1 ? 2 * S + i : KS1 - 1;  // block 6 has one k-step: its second half is zero weights
+                const int o0 = rb[Br::d_of(s, 0)] + Br::x_of(s, 0);
+                const int o1 = rb[Br::d_of(s, 1)] + Br::x_of(s, 1);
+                const int slot = lane_off + (h ? o1 : o0);
+                if (2 * S + i < KS1) bhf[buf][i] = __builtin_bit_cast(f16x8, img_hi[slot]);
+                bmf[buf][i] = img_lo[slot];
+              }
+            };
+            issue(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int S = 0; S < kBlocks; ++S) {
+              const int buf = S & 1;
+              if (S + 1 < kBlocks) issue(S + 1, buf ^ 1);
+              __builtin_amdgcn_sched_barrier(0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1h[2 * S]), bhf[buf][0], acc, 0, 0, 0);
+              if (2 * S + 1 < KS1)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1h[2 * S + 1 < KS1 ? 2 * S + 1 : 0]),
+                                                             bhf[buf][1], acc, 0, 0, 0);
+              const i32x8 bm = {(int)bmf[buf][0].x, (int)bmf[buf][0].y, (int)bmf[buf][0].z, (int)bmf[buf][0].w,
+                                (int)bmf[buf][1].x, (int)bmf[buf][1].y, (int)bmf[buf][1].z, (int)bmf[buf][1].w};
+              acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(amx[S], bm, acc, 0, 0, 0, amx_scale, 0, 127 - kMxSA);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              f32x2 v{fmaxf(acc[r], 0.0f), fmaxf(acc[r + 1], 0.0f)};
+              split_f16x2(v, b2hw[r >> 1], b2lw[r >> 1]);
+            }
           }
           f16x8 b2h[2], b2l[2];
 #pragma unroll
@@ -573,7 +649,7 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
         }
       }
       BR_STAMP(3);
-      if (ph + 1 < n_phase) raw_convert<Br>(r0 + kBrRows + PH1, raw, img_hi, img_lo, threadIdx.x);
+      if (ph + 1 < n_phase) raw_convert<Br, MX>(r0 + kBrRows + PH1, raw, img_hi, img_lo, threadIdx.x);
       BR_STAMP(4);
       lds_barrier();
       BR_STAMP(5);
@@ -680,6 +756,12 @@ static void launch_branch(const BranchParams& p, int n_cu, bool weights_have_lo,
     }
     return;
   }
+  if constexpr (Br::kOnset) {
+    if (weights_have_lo && p.wmx) {
+      hipLaunchKernelGGL((branch_kernel<Br, true, false, true>), dim3(grid), dim3(kBrThreads), 0, stream, p);
+      return;
+    }
+  }
   if (weights_have_lo)
     hipLaunchKernelGGL((branch_kernel<Br, true>), dim3(grid), dim3(kBrThreads), 0, stream, p);
   else
@@ -688,13 +770,15 @@ static void launch_branch(const BranchParams& p, int n_cu, bool weights_have_lo,
 
 void launch_note_branch(const float* contour, const void* wfrag, const float* wf32, float* note,
                         int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream) {
-  BranchParams p{static_cast<const uint4*>(wfrag), wf32, contour, nullptr, note, n_windows, nullptr};
+  BranchParams p{static_cast<const uint4*>(wfrag), wf32, contour, nullptr, note, n_windows, nullptr, nullptr};
   launch_branch<NoteBr>(p, n_cu, weights_have_lo, stream);
 }
 
-void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32,
+// wmx: the fp8 correction fragments (pack_onset_mx) or null for the three-product f16 kernel
+void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, const void* wmx,
                          float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream) {
-  BranchParams p{static_cast<const uint4*>(wfrag), wf32, zp, note, onset, n_windows, nullptr};
+  BranchParams p{static_cast<const uint4*>(wfrag), wf32, zp, note, onset, n_windows, nullptr,
+                 static_cast<const uint4*>(wmx)};
   launch_branch<OnsetBr>(p, n_cu, weights_have_lo, stream);
 }
 

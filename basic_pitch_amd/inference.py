@@ -77,6 +77,7 @@ class Model:
         exact_f32_mfma: bool = False,
         bf16_weights: bool = False,
         ext_cqt_44k: bool = False,
+        f16_corrections: bool = False,
     ):
         self.model_type = Model.MODEL_TYPES.MI355X_HIP
         self._lib = _native.load_library()
@@ -91,6 +92,8 @@ class Model:
             flags |= _native.BP_FLAG_BF16_WEIGHTS
         if ext_cqt_44k:  # BASELINE.json configs[4]: 44.1 kHz windows of 87,688 samples, 10-octave / 345-bin CQT
             flags |= _native.BP_FLAG_EXT_CQT_44K
+        if f16_corrections:  # all three split-precision products on f16 MFMA (default: the two corrections on fp8)
+            flags |= _native.BP_FLAG_F16_CORRECTIONS
         rc = self._lib.bp_create(blob, len(blob), int(device), flags, int(max_windows), C.byref(self._handle))
         if rc != _native.BP_OK:
             self._handle = C.c_void_p()

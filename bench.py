@@ -59,8 +59,8 @@ D1_EXECUTED_FLOP_PER_WINDOW = 45 * 8 * 63 * 3 * (2 * 32 * 32 * 16)
 D1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 264 * 8 * 4  # zp read + c1 written
 HBM_PEAK_GBS = 8000.0
 DTYPE_F16 = "f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands"
-DTYPE_DEFAULT = (DTYPE_F16 + "; contour conv1 interior: hi*hi on f16, its two correction products (<= 2^-11 of a product) on "
-                 "block-scaled fp8 MFMA (BP_CONV1=f16: all three on f16)")
+DTYPE_DEFAULT = (DTYPE_F16 + "; contour conv1 interior and onset conv1: hi*hi on f16, the two correction products (<= 2^-11 of a "
+                 "product) on block-scaled fp8 MFMA (--f16-corrections: all three on f16)")
 PMC_PROFILE = "r02_d"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
 
 
@@ -262,6 +262,9 @@ def main() -> None:
     ap.add_argument("--ext-cqt-44k", action="store_true",
                     help="BASELINE.json configs[4]: 44.1 kHz windows (87,688 samples), 10-octave / 345-bin CQT (use with "
                     "--batch 512); not the headline line")
+    ap.add_argument("--f16-corrections", action="store_true",
+                    help="BP_FLAG_F16_CORRECTIONS: all three split-precision products on f16 MFMA (A/B against the default, "
+                         "whose contour / onset conv1 corrections run on block-scaled fp8)")
     ap.add_argument("--bf16-weights", action="store_true",
                     help="BASELINE.json configs[3]: bf16 CNN weights + fp32 CQT (use with --batch 1024); not the headline line")
     args = ap.parse_args()
@@ -319,7 +322,8 @@ def main() -> None:
     # full per-stage table costs 16 event records = ~25 us (2.6 %) per step and comes from a second, untimed pass.
     # The exact-f32 A/B path has no dominant-only mode: it is timed with the full set.
     model = Model(device=local_rank, max_windows=B, stage_timing=args.exact_f32, time_dominant=not args.exact_f32,
-                  exact_f32_mfma=args.exact_f32, bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k)
+                  exact_f32_mfma=args.exact_f32, bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k,
+                  f16_corrections=args.f16_corrections)
 
     def step():
         model._predict_device(audio, out=out, sync=False)
@@ -346,7 +350,8 @@ def main() -> None:
         # stays the one measured inside the timed region
         dom = {k: v for k, v in stage.items() if v > 0.0}
         model.close()
-        model = Model(device=local_rank, max_windows=B, stage_timing=True, bf16_weights=args.bf16_weights,
+        model = Model(device=local_rank, max_windows=B, stage_timing=True, f16_corrections=args.f16_corrections,
+                      bf16_weights=args.bf16_weights,
                       ext_cqt_44k=args.ext_cqt_44k)
         for _ in range(3):
             step()
@@ -373,7 +378,8 @@ def main() -> None:
     # (2) rank 0 only, the exact-f32 A/B path's rate on the same batch.
     extras = {}
     if not args.exact_f32 and args.sustained_s > 0:
-        sus_model = Model(device=local_rank, max_windows=B, bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k)
+        sus_model = Model(device=local_rank, max_windows=B, bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k,
+                          f16_corrections=args.f16_corrections)
         n_sus = max(args.steps, int(args.sustained_s / (elapsed / args.steps)) + 1)
 
         def sus_step():
@@ -426,7 +432,7 @@ def main() -> None:
             c1_ms = stage["contour_conv1"]
             folded = stage.get("contour_conv1_edge", 0.0) > 0.0
             mf = (2 / 3 if args.bf16_weights else 1)
-            mx = folded and os.environ.get("BP_CONV1") != "f16" and not args.bf16_weights
+            mx = folded and os.environ.get("BP_CONV1") != "f16" and not args.bf16_weights and not args.f16_corrections
             if mx:
                 c1_flop = C1_FLOP_PER_WINDOW * F1_SHARE
                 c1_kernel = ("contour_conv1_fold_mx_kernel (interior 56/66 of harmonic stack + Conv2D 8->8 3x39 + ReLU with the 8 "
@@ -478,7 +484,7 @@ def main() -> None:
             # weights rounded to bf16 (one f16 operand), activations and CQT unchanged
             "dtype": ("f32 I/O + accumulate, bf16-rounded weights as single f16 MFMA operands, split-f16 activations" if args.bf16_weights
                       else "exact f32 MFMA (A/B path)" if args.exact_f32
-                      else DTYPE_DEFAULT if os.environ.get("BP_CONV1") != "f16" else DTYPE_F16),
+                      else DTYPE_F16 if args.f16_corrections or os.environ.get("BP_CONV1") == "f16" else DTYPE_DEFAULT),
             "data": "synthetic",
             "config": {
                 "workload": f"batch={B} synthetic uniform[-1,1) 2 s @ 22.05 kHz mono windows per GPU, "
