@@ -524,9 +524,11 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
             // channels) and 4 S + 2 + h (bytes 16..31) — the slots its two hi reads use.  One E8M0 scale for both
             // correction kinds (bp_api.hip pack_onset_mx), so a 32-tap K block may mix them.  Operands one block ahead.
             constexpr int kBlocks = kMxSteps;
-            f16x8 bhf[2][2];
-            uint4 bmf[2][2];
-            auto issue = [&](int S, int buf) {
+            constexpr int kPf = 1, kBuf = kPf + 1;  // two blocks ahead: 8 spills at the 256-register budget for 1-2 %
+            f16x8 bhf[kBuf][2];
+            uint4 bmf[kBuf][2];
+            auto issue = [&](int S) {
+              const int buf = S % kBuf;
 #pragma unroll
               for (int i = 0; i < 2; ++i) {
                 const int s = 2 * S + i < KS1 ? 2 * S + i : KS1 - 1;  // block 6 has one k-step: its second half is zero weights
@@ -537,12 +539,13 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
                 bmf[buf][i] = img_lo[slot];
               }
             };
-            issue(0, 0);
+#pragma unroll
+            for (int S = 0; S < kPf; ++S) issue(S);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int S = 0; S < kBlocks; ++S) {
-              const int buf = S & 1;
-              if (S + 1 < kBlocks) issue(S + 1, buf ^ 1);
+              const int buf = S % kBuf;
+              if (S + kPf < kBlocks) issue(S + kPf);
               __builtin_amdgcn_sched_barrier(0);
               acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1h[2 * S]), bhf[buf][0], acc, 0, 0, 0);
               if (2 * S + 1 < KS1)
