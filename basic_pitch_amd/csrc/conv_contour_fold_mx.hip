@@ -22,6 +22,7 @@
 //     registers for the whole kernel, two come from LDS through one shared 8-register buffer (0 spills at 256 VGPRs).
 //   * a lane converts z to fp8 with v_cvt_scalef32_pk_fp8_f16 straight from the packed f16 pairs of `zp`.
 // Roofline: matrix issue.  Per 32-position tile 36 f16 + 18 block-scaled instructions; bytes as the folded kernel.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -37,10 +38,13 @@ using h16x2 = __attribute__((ext_vector_type(2))) _Float16;
 constexpr int kFxThreads = 512;
 constexpr int kFxSteps = 36;             // f16 k-steps of 16 taps
 constexpr int kFxMx = 18;                // block-scaled steps of 32 taps
+constexpr int kFxPf = 1;                 // operand blocks read ahead (2, with a third of the fp8 A fragments in LDS to
+                                         // pay for the buffers: no change — the kernel is not waiting for these reads)
 constexpr int kFxMxReg = 16;             // ... whose A fragments stay in registers; steps 8 and 17 are read from LDS
 constexpr int kFxMxLds0 = 8, kFxMxLds1 = 17;  // (not adjacent: one 8-register buffer serves both)
 __device__ constexpr int fx_lds_slot(int q) { return q == kFxMxLds0 ? 0 : q == kFxMxLds1 ? 1 : -1; }
 __device__ constexpr int fx_reg_slot(int q) { return q < kFxMxLds0 ? q : q - 1; }
+__device__ constexpr int fx_lds_step(int slot) { return slot ? kFxMxLds1 : kFxMxLds0; }
 constexpr int kFxGroups = 56;            // groups 5..60
 constexpr int kFxFirstGroup = 5;
 constexpr int kFxRing = 16;
@@ -59,6 +63,18 @@ constexpr int kFxSA = 6;                 // fp8(a) = a * 2^6, fp8(lo_a) = (a - h
 static_assert(2 * kFxCopy <= kFxRowU4 && kFxF8Copy + 448 <= kFxF8Plane && kFxF8Plane + kFxF8Copy + 448 <= kFx8Row,
               "copies and planes do not overlap");
 static_assert(kFxRing * (kFxRowU4 * 16 + kFx8Row) + kFxSteps * 64 * 16 <= 150 * 1024, "LDS budget");
+
+#ifdef FX_PROF
+__device__ unsigned long long fx_prof[8][8];  // tools only (build_variant.sh -DFX_PROF): phase clocks of workgroup 0
+#define FX_T(k)                                                    \
+  {                                                                \
+    const unsigned long long t_now = __builtin_readcyclecounter(); \
+    pt[k] += t_now - t_prev;                                       \
+    t_prev = t_now;                                                \
+  }
+#else
+#define FX_T(k)
+#endif
 
 struct FoldMxParams {
   const uint32_t* zp;    // [n][kZRowsP][kZRow]
@@ -88,7 +104,7 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
   for (int i = tid; i < kFxRing * kFx8Row / 8; i += kFxThreads) z8[i] = uint2{0u, 0u};
   // resident fp8 A fragments and scales
   for (int i = tid; i < (kFxMx - kFxMxReg) * 128; i += kFxThreads) {
-    const int S = i / 128 ? kFxMxLds1 : kFxMxLds0, r = i % 128;  // LDS layout [slot][half][lane]
+    const int S = fx_lds_step(i / 128), r = i % 128;  // LDS layout [slot][half][lane]
     amxl[i] = p.amx[(S * 64 + (r & 63)) * 2 + (r >> 6)];
   }
   i32x8 amx[kFxMxReg];
@@ -135,6 +151,10 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
     }
   };
 
+#ifdef FX_PROF
+  unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
   const int rows_per = (kFrames + p.chunks - 1) / p.chunks;
   const int n_items = p.n_windows * p.chunks;
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -155,6 +175,7 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
     }
     lds_barrier();
 
+    FX_T(0);  // item prologue: first rows staged
     for (int k = 0; k < nrounds; ++k) {
       int need_hi = t0 + (kFxRound * (k + 1) + kFxRound - 1) / kFxGroups + 1;
       need_hi = need_hi < t1 ? need_hi : t1;
@@ -191,11 +212,13 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
       }
 
       // operands of block q = (dt, e): two f16 k-steps + one block-scaled step, read one block ahead
-      f16x8 ah[2][2], bh[2][2];
-      uint2 b8[2][4];
+      constexpr int kBuf = kFxPf + 1;
+      f16x8 ah[kBuf][2], bh[kBuf][2];
+      uint2 b8[kBuf][4];
       uint4 al[2];
       uint4 st_w[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-      auto issue = [&](int q, int buf) {
+      auto issue = [&](int q) {
+        const int buf = q % kBuf;
         if (fx_lds_slot(q) >= 0) {
           al[0] = amxl[fx_lds_slot(q) * 128 + lane];
           al[1] = amxl[fx_lds_slot(q) * 128 + 64 + lane];
@@ -215,11 +238,13 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
 #pragma unroll
         for (int i = 0; i < 4; ++i) b8[buf][i] = *reinterpret_cast<const uint2*>(z8bytes + o[i]);
       };
-      issue(0, 0);
+      FX_T(1);  // round prologue: positions, addresses, bias
+#pragma unroll
+      for (int q = 0; q < kFxPf; ++q) issue(q);
 #pragma unroll
       for (int q = 0; q < kFxMx; ++q) {
-        const int buf = q & 1;
-        if (q + 1 < kFxMx) issue(q + 1, buf ^ 1);
+        const int buf = q % kBuf;
+        if (q + kFxPf < kFxMx) issue(q + kFxPf);
         // the z rows of the next round: at most 6 rows x 112 tasks, two per thread.  Both loads leave at the start of the
         // tile and are converted and written near its end: zp comes from HBM / the Infinity Cache, and (gfx9 vmcnt counts
         // stores too) the wait also covers the previous tile's c1 stores — a dozen blocks hide both
@@ -231,9 +256,11 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
           }
         }
         if (q == kFxPut0 || q == kFxPut1) {
+          FX_T(2);  // matrix blocks
           const int i = q == kFxPut0 ? 0 : 1;
           const int e = i * kFxThreads + tid;
           if (e < n_new * kTasksRow) stage_put(st_w[i], first_new + e / kTasksRow, e % kTasksRow);
+          FX_T(3);  // staging puts (incl. the wait for their loads)
         }
         __builtin_amdgcn_sched_barrier(0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[buf][0], bh[buf][0], acc, 0, 0, 0);
@@ -247,6 +274,7 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
         __builtin_amdgcn_sched_barrier(0);
       }
       staged_hi += n_new;
+      FX_T(2);
       // the accumulator is pinned here: otherwise the compiler sinks the last matrix instruction into the divergent
       // store branch below, TOGETHER with the scratch reload of its (lane-private) A fragment — the lanes without a
       // valid position then skip the reload and feed stale rows of A into every lane's result
@@ -263,9 +291,15 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
           *reinterpret_cast<float4*>(dst + j * 8) = v;
         }
       }
+      FX_T(4);  // last MFMA's latency + ReLU + stores
       lds_barrier();
+      FX_T(5);  // barrier wait
     }
   }
+#ifdef FX_PROF
+  if (blockIdx.x == 0 && lane == 0)
+    for (int k = 0; k < 8; ++k) fx_prof[w][k] = pt[k];
+#endif
 }
 
 void launch_contour_conv1_fold_mx(const uint32_t* zp, const void* a16, const void* amx, const void* ascale,
@@ -278,6 +312,19 @@ void launch_contour_conv1_fold_mx(const uint32_t* zp, const void* a16, const voi
   if (items <= 0) return;
   const int grid = items < n_cu ? items : n_cu;
   hipLaunchKernelGGL(contour_conv1_fold_mx_kernel, dim3(grid), dim3(kFxThreads), 0, stream, p);
+#ifdef FX_PROF
+  static int calls = 0;
+  if (++calls == 20) {
+    unsigned long long h[8][8];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(fx_prof), sizeof h);
+    for (int w = 0; w < 8; ++w) {
+      fprintf(stderr, "fxprof wave %d:", w);
+      for (int k = 0; k < 6; ++k) fprintf(stderr, " %llu", h[w][k]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
 }
 
 }  // namespace bp
