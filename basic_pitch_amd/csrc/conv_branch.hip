@@ -527,33 +527,37 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
             constexpr int kPf = 1, kBuf = kPf + 1;  // two blocks ahead: 8 spills at the 256-register budget for 1-2 %
             f16x8 bhf[kBuf][2];
             uint4 bmf[kBuf][2];
-            auto issue = [&](int S) {
+            // half i of block S: the f16 hi operand of k-step 2 S + i and the fp8 pair of the same slot.  A wave issues
+            // about one LDS read per 14 cycles in order with everything else, so the reads of block S + 1 go BETWEEN the
+            // (dependent) matrix instructions of block S instead of in front of them
+            auto issue = [&](int S, int i) {
               const int buf = S % kBuf;
-#pragma unroll
-              for (int i = 0; i < 2; ++i) {
-                const int s = 2 * S + i < KS1 ? 2 * S + i : KS1 - 1;  // block 6 has one k-step: its second half is zero weights
-                const int o0 = rb[Br::d_of(s, 0)] + Br::x_of(s, 0);
-                const int o1 = rb[Br::d_of(s, 1)] + Br::x_of(s, 1);
-                const int slot = lane_off + (h ? o1 : o0);
-                if (2 * S + i < KS1) bhf[buf][i] = __builtin_bit_cast(f16x8, img_hi[slot]);
-                bmf[buf][i] = img_lo[slot];
-              }
+              const int s = 2 * S + i < KS1 ? 2 * S + i : KS1 - 1;  // block 6 has one k-step: its second half is zero weights
+              const int o0 = rb[Br::d_of(s, 0)] + Br::x_of(s, 0);
+              const int o1 = rb[Br::d_of(s, 1)] + Br::x_of(s, 1);
+              const int slot = lane_off + (h ? o1 : o0);
+              if (2 * S + i < KS1) bhf[buf][i] = __builtin_bit_cast(f16x8, img_hi[slot]);
+              bmf[buf][i] = img_lo[slot];
             };
-#pragma unroll
-            for (int S = 0; S < kPf; ++S) issue(S);
+            issue(0, 0);
+            issue(0, 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int S = 0; S < kBlocks; ++S) {
               const int buf = S % kBuf;
-              if (S + kPf < kBlocks) issue(S + kPf);
-              __builtin_amdgcn_sched_barrier(0);
+              const bool more = S + 1 < kBlocks;
               acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1h[2 * S]), bhf[buf][0], acc, 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              if (more) issue(S + 1, 0);
+              __builtin_amdgcn_sched_barrier(0);
               if (2 * S + 1 < KS1)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1h[2 * S + 1 < KS1 ? 2 * S + 1 : 0]),
                                                              bhf[buf][1], acc, 0, 0, 0);
               const i32x8 bm = {(int)bmf[buf][0].x, (int)bmf[buf][0].y, (int)bmf[buf][0].z, (int)bmf[buf][0].w,
                                 (int)bmf[buf][1].x, (int)bmf[buf][1].y, (int)bmf[buf][1].z, (int)bmf[buf][1].w};
               acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(amx[S], bm, acc, 0, 0, 0, amx_scale, 0, 127 - kMxSA);
+              __builtin_amdgcn_sched_barrier(0);
+              if (more) issue(S + 1, 1);
               __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll

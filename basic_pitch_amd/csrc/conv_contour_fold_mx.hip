@@ -217,20 +217,24 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
       uint2 b8[kBuf][4];
       uint4 al[2];
       uint4 st_w[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-      auto issue = [&](int q) {
+      // A wave issues about one LDS read per 14 cycles, in order with everything else: the 8 reads of a block in front of
+      // its three (dependent) matrix instructions cost 112 cycles of which only the last instruction's 64 overlap.  So the
+      // reads of block q + 1 go BETWEEN the matrix instructions of block q, in three pieces.
+      auto issue = [&](int q, int piece) {
         const int buf = q % kBuf;
+        const int dt = q / 6, e = q - 6 * dt;
+        if (piece < 2) {
+          const int i = piece;
+          bh[buf][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(zbytes + rowb[dt] + 32 * (2 * e + i)));
+          ah[buf][i] = __builtin_bit_cast(f16x8, afr[(dt * 12 + 2 * e + i) * 64 + lane]);
+          return;
+        }
         if (fx_lds_slot(q) >= 0) {
           al[0] = amxl[fx_lds_slot(q) * 128 + lane];
           al[1] = amxl[fx_lds_slot(q) * 128 + 64 + lane];
         }
-        const int dt = q / 6, e = q - 6 * dt;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          bh[buf][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(zbytes + rowb[dt] + 32 * (2 * e + i)));
-          ah[buf][i] = __builtin_bit_cast(f16x8, afr[(dt * 12 + 2 * e + i) * 64 + lane]);
-        }
         // four separate ds_read_b64 (2 LDS cycles each, 64 banks): merged into ds_read2_b64 they take 8 cycles a pair on
-        // 32 banks, where the two copies (640 bytes apart) collide — the opaque offsets keep the merge pass off them
+        // 32 banks, where the two copies collide — the opaque offsets keep the merge pass off them
         const int o0 = row8[dt];
         int o[4] = {o0 + 32 * e, o0 + 32 * e + 8, o0 + 32 * e + kFxF8Plane, o0 + 32 * e + kFxF8Plane + 8};
 #pragma unroll
@@ -240,14 +244,14 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
       };
       FX_T(1);  // round prologue: positions, addresses, bias
 #pragma unroll
-      for (int q = 0; q < kFxPf; ++q) issue(q);
+      for (int pc = 0; pc < 3; ++pc) issue(0, pc);
 #pragma unroll
       for (int q = 0; q < kFxMx; ++q) {
         const int buf = q % kBuf;
-        if (q + kFxPf < kFxMx) issue(q + kFxPf);
+        const bool more = q + 1 < kFxMx;
         // the z rows of the next round: at most 6 rows x 112 tasks, two per thread.  Both loads leave at the start of the
-        // tile and are converted and written near its end: zp comes from HBM / the Infinity Cache, and (gfx9 vmcnt counts
-        // stores too) the wait also covers the previous tile's c1 stores — a dozen blocks hide both
+        // tile and are converted and written later: zp comes from HBM / the Infinity Cache, and (gfx9 vmcnt counts
+        // stores too) the wait also covers the previous tile's c1 stores
         if (q == 0) {
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
@@ -264,13 +268,21 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
         }
         __builtin_amdgcn_sched_barrier(0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[buf][0], bh[buf][0], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue(q + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[buf][1], bh[buf][1], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue(q + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
         const i32x8 bm = {(int)b8[buf][0].x, (int)b8[buf][0].y, (int)b8[buf][1].x, (int)b8[buf][1].y,
                           (int)b8[buf][2].x, (int)b8[buf][2].y, (int)b8[buf][3].x, (int)b8[buf][3].y};
         const i32x8 am = fx_lds_slot(q) < 0 ? amx[fx_lds_slot(q) < 0 ? fx_reg_slot(q) : 0]
                                             : i32x8{(int)al[0].x, (int)al[0].y, (int)al[0].z, (int)al[0].w,
                                               (int)al[1].x, (int)al[1].y, (int)al[1].z, (int)al[1].w};
         acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am, bm, acc, 0, 0, 0, asc, 0, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue(q + 1, 2);
         __builtin_amdgcn_sched_barrier(0);
       }
       staged_hi += n_new;
