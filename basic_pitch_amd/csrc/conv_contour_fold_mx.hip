@@ -18,8 +18,10 @@
 //     bins) and, in their own array, four fp8 planes (fp8(a) and fp8(lo_a), each twice, the second copy shifted by 4
 //     bins): a lane reads 16 consecutive bins of a plane as two ds_read_b64 — kept apart with opaque offsets, the merged
 //     ds_read2_b64 runs at half the rate on 32 banks.  Strides enumerated against the service groups: 0 conflict cycles.
-//     The f16 A fragments are read from LDS (36.9 KB); 16 of the 18 fp8 A fragments (32 bytes per lane each) stay in
-//     registers for the whole kernel, two come from LDS through one shared 8-register buffer (0 spills at 256 VGPRs).
+//     The f16 A fragments are read from LDS (36.9 KB); the 18 fp8 A fragments (32 bytes per lane each = 144 registers)
+//     stay in registers for the whole kernel.  The LDS reads of block q + 1 are issued BETWEEN the three (dependent) matrix
+//     instructions of block q: a wave issues about one LDS read per 14 cycles, in order with everything else, and reads
+//     in front of a block only overlap its last instruction (233 VGPRs, 0 spills).
 //   * a lane converts z to fp8 with v_cvt_scalef32_pk_fp8_f16 straight from the packed f16 pairs of `zp`.
 // Roofline: matrix issue.  Per 32-position tile 36 f16 + 18 block-scaled instructions; bytes as the folded kernel.
 #include <stdio.h>
@@ -40,11 +42,6 @@ constexpr int kFxSteps = 36;             // f16 k-steps of 16 taps
 constexpr int kFxMx = 18;                // block-scaled steps of 32 taps
 constexpr int kFxPf = 1;                 // operand blocks read ahead (2, with a third of the fp8 A fragments in LDS to
                                          // pay for the buffers: no change — the kernel is not waiting for these reads)
-constexpr int kFxMxReg = 16;             // ... whose A fragments stay in registers; steps 8 and 17 are read from LDS
-constexpr int kFxMxLds0 = 8, kFxMxLds1 = 17;  // (not adjacent: one 8-register buffer serves both)
-__device__ constexpr int fx_lds_slot(int q) { return q == kFxMxLds0 ? 0 : q == kFxMxLds1 ? 1 : -1; }
-__device__ constexpr int fx_reg_slot(int q) { return q < kFxMxLds0 ? q : q - 1; }
-__device__ constexpr int fx_lds_step(int slot) { return slot ? kFxMxLds1 : kFxMxLds0; }
 constexpr int kFxGroups = 56;            // groups 5..60
 constexpr int kFxFirstGroup = 5;
 constexpr int kFxRing = 16;
@@ -91,7 +88,6 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
   __shared__ __attribute__((aligned(16))) uint4 zimg[kFxRing * kFxRowU4];
   __shared__ __attribute__((aligned(16))) uint2 z8[kFxRing * kFx8Row / 8];
   __shared__ __attribute__((aligned(16))) uint4 afr[kFxSteps * 64];
-  __shared__ __attribute__((aligned(16))) uint4 amxl[(kFxMx - kFxMxReg) * 2 * 64];
   __shared__ __attribute__((aligned(16))) float bias_l[8];
 
   const int tid = threadIdx.x;
@@ -102,17 +98,12 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
   for (int i = tid; i < kFxSteps * 64; i += kFxThreads) afr[i] = p.a16[i];
   for (int i = tid; i < kFxRing * kFxRowU4; i += kFxThreads) zimg[i] = uint4{0u, 0u, 0u, 0u};
   for (int i = tid; i < kFxRing * kFx8Row / 8; i += kFxThreads) z8[i] = uint2{0u, 0u};
-  // resident fp8 A fragments and scales
-  for (int i = tid; i < (kFxMx - kFxMxReg) * 128; i += kFxThreads) {
-    const int S = fx_lds_step(i / 128), r = i % 128;  // LDS layout [slot][half][lane]
-    amxl[i] = p.amx[(S * 64 + (r & 63)) * 2 + (r >> 6)];
-  }
-  i32x8 amx[kFxMxReg];
+  // resident fp8 A fragments (all 18 steps: 144 registers) and scales
+  i32x8 amx[kFxMx];
 #pragma unroll
   for (int S = 0; S < kFxMx; ++S) {
-    if (fx_lds_slot(S) >= 0) continue;
     const uint4 a0 = p.amx[(S * 64 + lane) * 2], a1 = p.amx[(S * 64 + lane) * 2 + 1];
-    amx[fx_reg_slot(S)] = i32x8{(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+    amx[S] = i32x8{(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
   }
   const int asc = p.ascale[lane];
   if (tid < 8) bias_l[tid] = p.bias[tid];
@@ -215,7 +206,6 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
       constexpr int kBuf = kFxPf + 1;
       f16x8 ah[kBuf][2], bh[kBuf][2];
       uint2 b8[kBuf][4];
-      uint4 al[2];
       uint4 st_w[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
       // A wave issues about one LDS read per 14 cycles, in order with everything else: the 8 reads of a block in front of
       // its three (dependent) matrix instructions cost 112 cycles of which only the last instruction's 64 overlap.  So the
@@ -228,10 +218,6 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
           bh[buf][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(zbytes + rowb[dt] + 32 * (2 * e + i)));
           ah[buf][i] = __builtin_bit_cast(f16x8, afr[(dt * 12 + 2 * e + i) * 64 + lane]);
           return;
-        }
-        if (fx_lds_slot(q) >= 0) {
-          al[0] = amxl[fx_lds_slot(q) * 128 + lane];
-          al[1] = amxl[fx_lds_slot(q) * 128 + 64 + lane];
         }
         // four separate ds_read_b64 (2 LDS cycles each, 64 banks): merged into ds_read2_b64 they take 8 cycles a pair on
         // 32 banks, where the two copies collide — the opaque offsets keep the merge pass off them
@@ -277,10 +263,7 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
         __builtin_amdgcn_sched_barrier(0);
         const i32x8 bm = {(int)b8[buf][0].x, (int)b8[buf][0].y, (int)b8[buf][1].x, (int)b8[buf][1].y,
                           (int)b8[buf][2].x, (int)b8[buf][2].y, (int)b8[buf][3].x, (int)b8[buf][3].y};
-        const i32x8 am = fx_lds_slot(q) < 0 ? amx[fx_lds_slot(q) < 0 ? fx_reg_slot(q) : 0]
-                                            : i32x8{(int)al[0].x, (int)al[0].y, (int)al[0].z, (int)al[0].w,
-                                              (int)al[1].x, (int)al[1].y, (int)al[1].z, (int)al[1].w};
-        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am, bm, acc, 0, 0, 0, asc, 0, sb);
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(amx[q], bm, acc, 0, 0, 0, asc, 0, sb);
         __builtin_amdgcn_sched_barrier(0);
         if (more) issue(q + 1, 2);
         __builtin_amdgcn_sched_barrier(0);
