@@ -752,7 +752,14 @@ static void launch_branch(const BranchParams& p, int n_cu, bool weights_have_lo,
     fprintf(stderr, "brprof %s: %d workgroups resident per CU\n", Br::kOnset ? "onset" : "note", resident);
     if (hipMalloc(&q.prof, sizeof hbuf) != hipSuccess) return;
     (void)hipMemsetAsync(q.prof, 0, sizeof hbuf, stream);
-    hipLaunchKernelGGL((branch_kernel<Br, true, true>), dim3(grid), dim3(kBrThreads), 0, stream, q);
+    if constexpr (Br::kOnset) {
+      if (p.wmx)
+        hipLaunchKernelGGL((branch_kernel<Br, true, true, true>), dim3(grid), dim3(kBrThreads), 0, stream, q);
+      else
+        hipLaunchKernelGGL((branch_kernel<Br, true, true>), dim3(grid), dim3(kBrThreads), 0, stream, q);
+    } else {
+      hipLaunchKernelGGL((branch_kernel<Br, true, true>), dim3(grid), dim3(kBrThreads), 0, stream, q);
+    }
     (void)hipMemcpyAsync(hbuf, q.prof, sizeof hbuf, hipMemcpyDeviceToHost, stream);
     (void)hipStreamSynchronize(stream);
     (void)hipFree(q.prof);
