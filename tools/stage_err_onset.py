@@ -1,4 +1,5 @@
 # Stage check (tools/): the onset branch kernel alone against the fp64 oracle (BP_ONSET=f16 for the all-f16 kernel).
+# Stage check (tools/): the onset branch kernel alone against the fp64 oracle (BP_ONSET=f16 for the all-f16 kernel).
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
