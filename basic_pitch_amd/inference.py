@@ -601,6 +601,80 @@ def predict_many(
     return results
 
 
+def _save_outputs(audio_path, output_directory, result, save_midi: bool, sonify_midi: bool, save_model_outputs: bool,
+                  save_notes: bool, sonification_samplerate: int) -> Dict[str, str]:
+    """The four writers of inference.py:565-602 for one file's `(model_output, midi_data, note_events)`; returns the paths."""
+    model_output, midi_data, note_events = result
+    written: Dict[str, str] = {}
+    if save_model_outputs:
+        path = build_output_path(audio_path, output_directory, OutputExtensions.MODEL_OUTPUT_NPZ)
+        np.savez(path, basic_pitch_model_output=model_output)
+        written["model_output"] = str(path)
+    if save_midi:
+        path = build_output_path(audio_path, output_directory, OutputExtensions.MIDI)
+        midi_data.write(str(path))
+        written["midi"] = str(path)
+    if sonify_midi:
+        path = build_output_path(audio_path, output_directory, OutputExtensions.MIDI_SONIFICATION)
+        infer.sonify_midi(midi_data, path, sr=sonification_samplerate)
+        written["sonification"] = str(path)
+    if save_notes:
+        path = build_output_path(audio_path, output_directory, OutputExtensions.NOTE_EVENTS)
+        save_note_events(note_events, path)
+        written["note_events"] = str(path)
+    return written
+
+
+def predict_and_save_many(
+    audio_path_list,
+    output_directory: Union[pathlib.Path, str],
+    save_midi: bool,
+    sonify_midi: bool,
+    save_model_outputs: bool,
+    save_notes: bool,
+    model_or_model_path: Union[Model, str, pathlib.Path] = ICASSP_2022_MODEL_PATH,
+    onset_threshold: float = DEFAULT_ONSET_THRESHOLD,
+    frame_threshold: float = DEFAULT_FRAME_THRESHOLD,
+    minimum_note_length: float = DEFAULT_MINIMUM_NOTE_LENGTH_MS,
+    minimum_frequency: Optional[float] = None,
+    maximum_frequency: Optional[float] = None,
+    multiple_pitch_bends: bool = False,
+    melodia_trick: bool = True,
+    sonification_samplerate: int = DEFAULT_SONIFICATION_SAMPLERATE,
+    midi_tempo: float = DEFAULT_MINIMUM_MIDI_TEMPO,
+    group: int = 64,
+    decode_threads: Optional[int] = None,
+    return_exceptions: bool = False,
+) -> List[Any]:
+    """`predict_and_save` (inference.py:509-618) as a batch job: the files go through `predict_many` (windows packed
+    across files, reads and note decoding overlapped with the GPU) one group at a time, and a group's outputs are
+    written before the next group is predicted, so memory stays at one group of posteriorgrams.  Same files, same bytes
+    as the per-file loop.  Returns per file `{"n_note_events": k, "outputs": {kind: path}}` — or, with
+    `return_exceptions=True`, the exception that file raised (otherwise the first failure propagates, like the
+    reference's `raise e`)."""
+    model = Model(model_or_model_path) if isinstance(model_or_model_path, (str, os.PathLike)) else model_or_model_path
+    paths = [pathlib.Path(p) for p in audio_path_list]
+    report: List[Any] = []
+    for g0 in range(0, len(paths), group):
+        chunk = paths[g0 : g0 + group]
+        results = predict_many(chunk, model, onset_threshold, frame_threshold, minimum_note_length, minimum_frequency,
+                               maximum_frequency, multiple_pitch_bends, melodia_trick, midi_tempo, group=group,
+                               decode_threads=decode_threads, return_exceptions=return_exceptions)
+        for audio_path, res in zip(chunk, results):
+            if isinstance(res, BaseException):
+                report.append(res)
+                continue
+            try:
+                written = _save_outputs(audio_path, output_directory, res, save_midi, sonify_midi, save_model_outputs,
+                                        save_notes, sonification_samplerate)
+                report.append({"n_note_events": len(res[2]), "outputs": written})
+            except Exception as e:
+                if not return_exceptions:
+                    raise
+                report.append(e)
+    return report
+
+
 def predict_and_save(
     audio_path_list,
     output_directory: Union[pathlib.Path, str],
@@ -623,17 +697,9 @@ def predict_and_save(
     """inference.py:509-618: model output (.npz), MIDI (.mid), sonified MIDI (.wav), note events (.csv) per file."""
     model = model_or_model_path if isinstance(model_or_model_path, Model) else Model(model_or_model_path)
     for audio_path in audio_path_list:
-        model_output, midi_data, note_events = predict(
+        result = predict(
             pathlib.Path(audio_path), model, onset_threshold, frame_threshold, minimum_note_length,
             minimum_frequency, maximum_frequency, multiple_pitch_bends, melodia_trick, debug_file, midi_tempo,
         )
-        if save_model_outputs:
-            np.savez(build_output_path(audio_path, output_directory, OutputExtensions.MODEL_OUTPUT_NPZ),
-                     basic_pitch_model_output=model_output)
-        if save_midi:
-            midi_data.write(str(build_output_path(audio_path, output_directory, OutputExtensions.MIDI)))
-        if sonify_midi:
-            infer.sonify_midi(midi_data, build_output_path(audio_path, output_directory, OutputExtensions.MIDI_SONIFICATION),
-                              sr=sonification_samplerate)
-        if save_notes:
-            save_note_events(note_events, build_output_path(audio_path, output_directory, OutputExtensions.NOTE_EVENTS))
+        _save_outputs(audio_path, output_directory, result, save_midi, sonify_midi, save_model_outputs, save_notes,
+                      sonification_samplerate)

@@ -700,3 +700,31 @@ def test_ort_shim_session_runs_reference_call_pattern(cases):
     assert [r.shape for r in res] == [(4, 172, 88), (4, 172, 88), (4, 172, 264)]
     for got, k in zip(res, ("note", "onset", "contour")):
         assert np.abs(got[:3] - r64[k][:3]).max() <= 1e-4, k
+
+
+@pytest.mark.gpu
+def test_predict_and_save_sharded_two_workers_on_one_gpu(tmp_path):
+    """The batch-job entry point on hardware: two worker processes share the GPU, each predicts and writes its own files;
+    the MIDI of the reference clip is byte-identical to the committed pretty_midi-layout fixture whichever worker got it,
+    and equals the single-process `predict_and_save` output."""
+    import shutil
+
+    from basic_pitch_amd import predict_and_save, predict_and_save_sharded
+
+    clips = []
+    for i in range(4):
+        p = tmp_path / f"clip_{i}.wav"
+        shutil.copy(os.path.join(GOLDEN, "vocadito_10.wav"), p)
+        clips.append(str(p))
+    out2, out1 = tmp_path / "sharded", tmp_path / "serial"
+    out2.mkdir()
+    out1.mkdir()
+    rep = predict_and_save_sharded(clips, out2, True, False, False, True, gpus=1, workers_per_gpu=2, group=2)
+    assert [r["n_note_events"] for r in rep] == [28, 28, 28, 28]
+    predict_and_save(clips[:1], out1, True, False, False, True)
+    want = open(os.path.join(GOLDEN, "midi", "clip_default.mid"), "rb").read()
+    serial = open(out1 / "clip_0_basic_pitch.mid", "rb").read()
+    assert serial == want
+    for r in rep:
+        assert open(r["outputs"]["midi"], "rb").read() == want
+        assert open(r["outputs"]["note_events"]).read() == open(out1 / "clip_0_basic_pitch.csv").read()

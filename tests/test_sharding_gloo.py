@@ -9,6 +9,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -187,3 +188,36 @@ def test_predict_many_sharded_two_ranks_gloo_and_spawn(tmp_path):
                 assert g == s
             else:
                 assert g[0] == owner[i] and g[1:] == s[1:], i
+
+
+def test_predict_and_save_sharded_writes_per_worker(tmp_path):
+    """The batch job entry point with the compute stubbed: 2 spawned workers predict AND write their own shares (MIDI +
+    note CSV + .npz), only small reports come back; the files are byte-identical to the single-process job's, a missing
+    input is reported in place."""
+    from basic_pitch_amd import predict_and_save_many, predict_and_save_sharded
+
+    paths = _write_clips(tmp_path, 6)
+    paths.insert(2, str(tmp_path / "missing.wav"))
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir()
+    two.mkdir()
+    ref = predict_and_save_many(paths, one, True, False, True, True, model_or_model_path=FakeModel(0), group=4,
+                                decode_threads=2, return_exceptions=True)
+    got = predict_and_save_sharded(paths, two, True, False, True, True, gpus=2, model_factory=fake_factory, group=2,
+                                   decode_threads=2)
+    assert len(got) == len(ref) == len(paths)
+    assert isinstance(got[2], ValueError) and isinstance(ref[2], ValueError)
+    for i, (g, r) in enumerate(zip(got, ref)):
+        if i == 2:
+            continue
+        assert g["n_note_events"] == r["n_note_events"] > 0
+        assert sorted(g["outputs"]) == ["midi", "model_output", "note_events"]
+        for kind in ("midi", "note_events"):
+            a, b = open(g["outputs"][kind], "rb").read(), open(r["outputs"][kind], "rb").read()
+            assert a == b and len(a) > 0, (i, kind)
+        a = np.load(g["outputs"]["model_output"], allow_pickle=True)["basic_pitch_model_output"].item()
+        b = np.load(r["outputs"]["model_output"], allow_pickle=True)["basic_pitch_model_output"].item()
+        assert all(np.array_equal(a[k], b[k]) for k in ("note", "onset", "contour"))
+    # the reference's behaviour without return_exceptions: the first failure propagates (inference.py:603-604)
+    with pytest.raises(ValueError):
+        predict_and_save_many(paths, one, True, False, False, False, model_or_model_path=FakeModel(0))
