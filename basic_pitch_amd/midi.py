@@ -178,31 +178,88 @@ class PrettyMIDI:
                 running = status
         return _chunk(b"MTrk", bytes(data))
 
-    def _instrument_events(self, n: int, inst: "Instrument"):
+    def _instrument_track(self, n: int, inst: "Instrument") -> bytes:
+        """One instrument's MTrk chunk, byte for byte what pretty_midi + mido write: program change, then note-ons /
+        note-offs / pitch bends in pretty_midi's `event_compare` order (tick, then class key; stable), its fix-up swap of a
+        note-on directly followed by the same pitch's note-off at the same tick, delta times as variable-length quantities,
+        running status, end-of-track one tick after the last event.  Vectorised: a 3-minute track has ~11 k events and this
+        runs under the GIL."""
+        import numpy as np
+
         channels = [c for c in range(16) if c != 9]
         ch = 9 if inst.is_drum else channels[n % len(channels)]
-        # (tick, class key, note, velocity, status, payload); classes as in pretty_midi's event_compare
-        ev = [(0, 6 << 16, -1, -1, 0xC0 | ch, bytes([inst.program]))]
-        for note in inst.notes:
-            for t, vel in ((note.start, int(note.velocity)), (note.end, 0)):
-                ev.append((self.time_to_tick(t), (10 << 16) + int(note.pitch) * 256 + vel, int(note.pitch), vel,
-                           0x90 | ch, bytes([int(note.pitch), vel])))
-        for b in inst.pitch_bends:
-            v = int(b.pitch) + 8192
-            if not 0 <= v <= 16383:
-                raise ValueError(f"pitch bend {b.pitch} outside [-8192, 8191]")
-            ev.append((self.time_to_tick(b.time), (7 << 16) + int(b.pitch), -1, -1, 0xE0 | ch, bytes([v & 0x7F, v >> 7])))
-        ev.sort(key=lambda e: (e[0], e[1]))  # stable, like sorted(cmp_to_key(event_compare))
-        # pretty_midi's fix-up pass over the ORIGINAL neighbours: a note-on directly followed by the note-off of the
-        # same pitch at the same tick is swapped
-        snap = list(ev)
-        for i in range(len(snap) - 1):
-            e1, e2 = snap[i], snap[i + 1]
-            if e1[0] == e2[0] and e1[2] >= 0 and e1[2] == e2[2] and e1[3] != 0 and e2[3] == 0:
-                ev[i], ev[i + 1] = e2, e1
-        out = [(e[0], e[4], e[5]) for e in ev]
-        out.append((out[-1][0] + 1, None, b"\xff\x2f\x00"))
-        return out
+        nn, nb = len(inst.notes), len(inst.pitch_bends)
+
+        def ticks_of(times) -> "np.ndarray":
+            # time_to_tick: 0 unless time > 0, else int(round(time / tick_scale)) (round half to even, like np.rint)
+            t = np.asarray(times, dtype=np.float64)
+            return np.where(t > 0, np.rint(t / self._tick_scale), 0.0).astype(np.int64)
+
+        pitch = np.fromiter((int(x.pitch) for x in inst.notes), dtype=np.int64, count=nn)
+        vel = np.fromiter((int(x.velocity) for x in inst.notes), dtype=np.int64, count=nn)
+        t_on = ticks_of(np.fromiter((x.start for x in inst.notes), dtype=np.float64, count=nn))
+        t_off = ticks_of(np.fromiter((x.end for x in inst.notes), dtype=np.float64, count=nn))
+        bend = np.fromiter((int(x.pitch) for x in inst.pitch_bends), dtype=np.int64, count=nb)
+        t_bend = ticks_of(np.fromiter((x.time for x in inst.pitch_bends), dtype=np.float64, count=nb))
+        bad = (bend < -8192) | (bend > 8191)
+        if bad.any():
+            raise ValueError(f"pitch bend {int(bend[bad][0])} outside [-8192, 8191]")
+        v14 = bend + 8192
+
+        m = 1 + 2 * nn + nb
+        tick = np.empty(m, np.int64)
+        key = np.empty(m, np.int64)      # classes as in pretty_midi's event_compare
+        note = np.full(m, -1, np.int64)  # pitch of note events (the fix-up pass compares them)
+        velo = np.full(m, -1, np.int64)
+        status = np.empty(m, np.int64)
+        d1 = np.empty(m, np.int64)
+        d2 = np.full(m, -1, np.int64)    # -1: one data byte
+        tick[0], key[0], status[0], d1[0] = 0, 6 << 16, 0xC0 | ch, inst.program
+        on, off = slice(1, 1 + 2 * nn, 2), slice(2, 2 + 2 * nn, 2)
+        tick[on], tick[off] = t_on, t_off
+        key[on], key[off] = (10 << 16) + pitch * 256 + vel, (10 << 16) + pitch * 256
+        note[on] = note[off] = pitch
+        velo[on], velo[off] = vel, 0
+        status[1 : 1 + 2 * nn] = 0x90 | ch
+        d1[on] = d1[off] = pitch
+        d2[on], d2[off] = vel, 0
+        bs = slice(1 + 2 * nn, m)
+        tick[bs], key[bs], status[bs], d1[bs], d2[bs] = t_bend, (7 << 16) + bend, 0xE0 | ch, v14 & 0x7F, v14 >> 7
+
+        order = np.lexsort((key, tick))  # stable, like sorted(cmp_to_key(event_compare))
+        tick, note, velo, status, d1, d2 = tick[order], note[order], velo[order], status[order], d1[order], d2[order]
+        # the fix-up pass looks at the ORIGINAL neighbours; its swaps cannot overlap (the second event of a pair has
+        # velocity 0, the first of the next pair must not)
+        sw = np.nonzero((tick[:-1] == tick[1:]) & (note[:-1] >= 0) & (note[:-1] == note[1:]) & (velo[:-1] != 0)
+                        & (velo[1:] == 0))[0]
+        if sw.size:
+            perm = np.arange(m)
+            perm[sw], perm[sw + 1] = sw + 1, sw
+            tick, status, d1, d2 = tick[perm], status[perm], d1[perm], d2[perm]
+
+        delta = np.diff(tick, prepend=0)
+        if (delta < 0).any() or (delta >= 1 << 28).any():
+            raise ValueError("MIDI delta time out of range")
+        nv = 1 + (delta >= 1 << 7) + (delta >= 1 << 14) + (delta >= 1 << 21)   # bytes of the variable-length quantity
+        has_status = np.ones(m, bool)
+        has_status[1:] = status[1:] != status[:-1]                               # running status
+        has_d2 = d2 >= 0
+        size = nv + has_status + 1 + has_d2
+        start = np.cumsum(size) - size
+        out = np.zeros(int(size.sum()) + 4, np.uint8)
+        for j in range(4):  # VLQ byte j counted from the least significant group; written at start + nv - 1 - j
+            sel = nv > j
+            val = (delta[sel] >> (7 * j)) & 0x7F
+            if j:
+                val = val | 0x80
+            out[start[sel] + nv[sel] - 1 - j] = val
+        at = start + nv
+        out[at[has_status]] = status[has_status]
+        at = at + has_status
+        out[at] = d1
+        out[(at + 1)[has_d2]] = d2[has_d2]
+        out[-4:] = (1, 0xFF, 0x2F, 0x00)  # end of track, one tick after the last event
+        return _chunk(b"MTrk", out.tobytes())
 
     def to_bytes(self) -> bytes:
         tempo = int(6e7 / (60.0 / (self._tick_scale * self.resolution)))
@@ -213,7 +270,7 @@ class PrettyMIDI:
         ]
         tracks = [self._encode_track(timing)]
         for n, inst in enumerate(self.instruments):
-            tracks.append(self._encode_track(self._instrument_events(n, inst)))
+            tracks.append(self._instrument_track(n, inst))
         return _chunk(b"MThd", struct.pack(">hhh", 1, len(tracks), self.resolution)) + b"".join(tracks)
 
     def write(self, filename) -> None:

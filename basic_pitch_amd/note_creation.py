@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 from collections import defaultdict
-from typing import DefaultDict, Dict, List, Optional, Tuple
+from typing import Any, DefaultDict, Dict, List, Optional, Tuple
 
 import numpy as np
 
@@ -129,25 +129,47 @@ def drop_overlapping_pitch_bends(note_events_with_pitch_bends: List[NoteEvent]) 
 def note_events_to_midi(
     note_events_with_pitch_bends: List[NoteEvent], multiple_pitch_bends: bool = False, midi_tempo: float = 120
 ) -> pretty_midi.PrettyMIDI:
-    """note_creation.py:222-267."""
+    """note_creation.py:222-267.
+
+    Same objects in the same order as the reference's per-note loop; the pitch bends of ALL notes go through numpy in one
+    pass (a 3-minute track holds ~10 k of them, and this function runs under the GIL while the GPU waits for the next
+    group of files): `np.linspace(start, end, n)` is restated as k * step + start with the last element set to `end` —
+    numpy's own evaluation order (function_base.py), so the times are bit-identical."""
     mid = pretty_midi.PrettyMIDI(initial_tempo=midi_tempo)
     if not multiple_pitch_bends:
         note_events_with_pitch_bends = drop_overlapping_pitch_bends(note_events_with_pitch_bends)
     piano_program = pretty_midi.instrument_name_to_program("Electric Piano 1")
     instruments: DefaultDict[int, pretty_midi.Instrument] = defaultdict(lambda: pretty_midi.Instrument(program=piano_program))
-    for start_time, end_time, note_number, amplitude, pitch_bend in note_events_with_pitch_bends:
+    events = note_events_with_pitch_bends
+    counts = [len(e[4]) if e[4] else 0 for e in events]
+    total = sum(counts)
+    bend_objs: List[Any] = []
+    if total:
+        flat = np.fromiter((b for e, c in zip(events, counts) if c for b in e[4]), dtype=np.int64, count=total)
+        ticks = np.round(flat * PITCH_BEND_SCALE / CONTOURS_BINS_PER_SEMITONE).astype(int)
+        ticks[ticks > N_PITCH_BEND_TICKS - 1] = N_PITCH_BEND_TICKS - 1
+        ticks[ticks < -N_PITCH_BEND_TICKS] = -N_PITCH_BEND_TICKS
+        cnt = np.array([c for c in counts if c], dtype=np.int64)
+        start = np.array([e[0] for e, c in zip(events, counts) if c], dtype=np.float64)
+        stop = np.array([e[1] for e, c in zip(events, counts) if c], dtype=np.float64)
+        first = np.cumsum(cnt) - cnt
+        k = (np.arange(total) - np.repeat(first, cnt)).astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            step = (stop - start) / (cnt - 1)  # n = 1: never used below (k = 0 -> start)
+        step[cnt == 1] = 0.0
+        times = k * np.repeat(step, cnt) + np.repeat(start, cnt)
+        multi = cnt > 1
+        times[(first + cnt - 1)[multi]] = stop[multi]
+        bend_objs = list(map(pretty_midi.PitchBend, ticks.tolist(), times.tolist()))
+    at = 0
+    for (start_time, end_time, note_number, amplitude, _), c in zip(events, counts):
         instrument = instruments[note_number] if multiple_pitch_bends else instruments[0]
         instrument.notes.append(
             pretty_midi.Note(velocity=int(np.round(MIDI_VELOCITY_SCALE * amplitude)), pitch=note_number, start=start_time, end=end_time)
         )
-        if not pitch_bend:
-            continue
-        pitch_bend_times = np.linspace(start_time, end_time, len(pitch_bend))
-        ticks = np.round(np.array(pitch_bend) * PITCH_BEND_SCALE / CONTOURS_BINS_PER_SEMITONE).astype(int)
-        ticks[ticks > N_PITCH_BEND_TICKS - 1] = N_PITCH_BEND_TICKS - 1
-        ticks[ticks < -N_PITCH_BEND_TICKS] = -N_PITCH_BEND_TICKS
-        # one pass over plain Python numbers (a 3-minute track holds ~10 k pitch bends)
-        instrument.pitch_bends.extend(map(pretty_midi.PitchBend, ticks.tolist(), pitch_bend_times.tolist()))
+        if c:
+            instrument.pitch_bends.extend(bend_objs[at : at + c])
+            at += c
     mid.instruments.extend(instruments.values())
     return mid
 
