@@ -66,14 +66,67 @@ def pitch_bend_to_semitones(pitch_bend: int, semitone_range: float = 2.0) -> flo
 
 
 class Instrument:
+    """pretty_midi.Instrument's attributes.  An instrument built by `from_arrays` (note_creation.note_events_to_midi) keeps
+    its notes and pitch bends as numpy arrays and only turns them into `Note` / `PitchBend` objects when `.notes` /
+    `.pitch_bends` are first read: a batch job that only writes the file never creates the ~11 k objects of a 3-minute
+    track (object creation runs under the GIL, which is what bounds a file job — DESIGN.md §5)."""
+
     def __init__(self, program: int, is_drum: bool = False, name: str = ""):
         self.program, self.is_drum, self.name = program, is_drum, name
-        self.notes: List[Note] = []
-        self.pitch_bends: List[PitchBend] = []
+        self._notes: List[Note] = []
+        self._pitch_bends: List[PitchBend] = []
+        self._lazy = None  # (pitch, velocity, start, end, bend_pitch, bend_time) arrays, or None once materialised
+
+    @classmethod
+    def from_arrays(cls, program: int, pitch, velocity, start, end, bend_pitch, bend_time) -> "Instrument":
+        inst = cls(program)
+        inst._lazy = (pitch, velocity, start, end, bend_pitch, bend_time)
+        return inst
+
+    def _materialise(self) -> None:
+        if self._lazy is not None:
+            pitch, velocity, start, end, bend_pitch, bend_time = self._lazy
+            self._lazy = None
+            self._notes = list(map(Note, velocity.tolist(), pitch.tolist(), start.tolist(), end.tolist()))
+            self._pitch_bends = list(map(PitchBend, bend_pitch.tolist(), bend_time.tolist()))
+
+    @property
+    def notes(self) -> List[Note]:
+        self._materialise()
+        return self._notes
+
+    @notes.setter
+    def notes(self, value) -> None:
+        self._materialise()
+        self._notes = value
+
+    @property
+    def pitch_bends(self) -> List[PitchBend]:
+        self._materialise()
+        return self._pitch_bends
+
+    @pitch_bends.setter
+    def pitch_bends(self, value) -> None:
+        self._materialise()
+        self._pitch_bends = value
+
+    def _event_arrays(self):
+        """(pitch, velocity, start, end, bend_pitch, bend_time) as int64 / float64 arrays."""
+        import numpy as np
+
+        if self._lazy is not None:
+            return self._lazy
+        nn, nb = len(self._notes), len(self._pitch_bends)
+        return (np.fromiter((int(x.pitch) for x in self._notes), dtype=np.int64, count=nn),
+                np.fromiter((int(x.velocity) for x in self._notes), dtype=np.int64, count=nn),
+                np.fromiter((x.start for x in self._notes), dtype=np.float64, count=nn),
+                np.fromiter((x.end for x in self._notes), dtype=np.float64, count=nn),
+                np.fromiter((int(x.pitch) for x in self._pitch_bends), dtype=np.int64, count=nb),
+                np.fromiter((x.time for x in self._pitch_bends), dtype=np.float64, count=nb))
 
     def get_end_time(self) -> float:
-        ends = [n.end for n in self.notes] + [b.time for b in self.pitch_bends]
-        return max(ends) if ends else 0.0
+        _, _, _, end, _, bend_time = self._event_arrays()
+        return float(max(end.max() if end.size else 0.0, bend_time.max() if bend_time.size else 0.0))
 
     def synthesize(self, fs: int = 44100, wave=None):
         """pretty_midi.Instrument.synthesize restated: every note a `wave` (default np.sin) oscillator at its pitch,
@@ -143,8 +196,7 @@ class PrettyMIDI:
         return int(round(float(time) / self._tick_scale))
 
     def get_end_time(self) -> float:
-        ends = [n.end for i in self.instruments for n in i.notes] + [b.time for i in self.instruments for b in i.pitch_bends]
-        return max(ends) if ends else 0.0
+        return max((i.get_end_time() for i in self.instruments), default=0.0)
 
     def synthesize(self, fs: int = 44100, wave=None):
         """pretty_midi.PrettyMIDI.synthesize restated: the instruments' waveforms summed (zero padded to the longest)
@@ -188,19 +240,15 @@ class PrettyMIDI:
 
         channels = [c for c in range(16) if c != 9]
         ch = 9 if inst.is_drum else channels[n % len(channels)]
-        nn, nb = len(inst.notes), len(inst.pitch_bends)
+        pitch, vel, start_s, end_s, bend, bend_s = inst._event_arrays()
+        nn, nb = pitch.size, bend.size
 
         def ticks_of(times) -> "np.ndarray":
             # time_to_tick: 0 unless time > 0, else int(round(time / tick_scale)) (round half to even, like np.rint)
             t = np.asarray(times, dtype=np.float64)
             return np.where(t > 0, np.rint(t / self._tick_scale), 0.0).astype(np.int64)
 
-        pitch = np.fromiter((int(x.pitch) for x in inst.notes), dtype=np.int64, count=nn)
-        vel = np.fromiter((int(x.velocity) for x in inst.notes), dtype=np.int64, count=nn)
-        t_on = ticks_of(np.fromiter((x.start for x in inst.notes), dtype=np.float64, count=nn))
-        t_off = ticks_of(np.fromiter((x.end for x in inst.notes), dtype=np.float64, count=nn))
-        bend = np.fromiter((int(x.pitch) for x in inst.pitch_bends), dtype=np.int64, count=nb)
-        t_bend = ticks_of(np.fromiter((x.time for x in inst.pitch_bends), dtype=np.float64, count=nb))
+        t_on, t_off, t_bend = ticks_of(start_s), ticks_of(end_s), ticks_of(bend_s)
         bad = (bend < -8192) | (bend > 8191)
         if bad.any():
             raise ValueError(f"pitch bend {int(bend[bad][0])} outside [-8192, 8191]")

@@ -139,11 +139,13 @@ def note_events_to_midi(
     if not multiple_pitch_bends:
         note_events_with_pitch_bends = drop_overlapping_pitch_bends(note_events_with_pitch_bends)
     piano_program = pretty_midi.instrument_name_to_program("Electric Piano 1")
-    instruments: DefaultDict[int, pretty_midi.Instrument] = defaultdict(lambda: pretty_midi.Instrument(program=piano_program))
     events = note_events_with_pitch_bends
+    if not events:
+        return mid
     counts = [len(e[4]) if e[4] else 0 for e in events]
     total = sum(counts)
-    bend_objs: List[Any] = []
+    ticks = np.zeros(0, dtype=np.int64)
+    times = np.zeros(0, dtype=np.float64)
     if total:
         flat = np.fromiter((b for e, c in zip(events, counts) if c for b in e[4]), dtype=np.int64, count=total)
         ticks = np.round(flat * PITCH_BEND_SCALE / CONTOURS_BINS_PER_SEMITONE).astype(int)
@@ -160,17 +162,27 @@ def note_events_to_midi(
         times = k * np.repeat(step, cnt) + np.repeat(start, cnt)
         multi = cnt > 1
         times[(first + cnt - 1)[multi]] = stop[multi]
-        bend_objs = list(map(pretty_midi.PitchBend, ticks.tolist(), times.tolist()))
-    at = 0
-    for (start_time, end_time, note_number, amplitude, _), c in zip(events, counts):
-        instrument = instruments[note_number] if multiple_pitch_bends else instruments[0]
-        instrument.notes.append(
-            pretty_midi.Note(velocity=int(np.round(MIDI_VELOCITY_SCALE * amplitude)), pitch=note_number, start=start_time, end=end_time)
-        )
-        if c:
-            instrument.pitch_bends.extend(bend_objs[at : at + c])
-            at += c
-    mid.instruments.extend(instruments.values())
+    n_ev = len(events)
+    ev_start = np.array([e[0] for e in events], dtype=np.float64)
+    ev_end = np.array([e[1] for e in events], dtype=np.float64)
+    ev_pitch = np.array([e[2] for e in events], dtype=np.int64)
+    ev_vel = np.array([int(np.round(MIDI_VELOCITY_SCALE * e[3])) for e in events], dtype=np.int64)
+    ev_cnt = np.array(counts, dtype=np.int64)
+    ev_first = np.cumsum(ev_cnt) - ev_cnt
+    # one instrument, or (multiple_pitch_bends) one per note number in order of first appearance; inside an instrument
+    # notes and pitch bends keep the event order
+    if multiple_pitch_bends:
+        groups: Dict[int, List[int]] = {}
+        for i, e in enumerate(events):
+            groups.setdefault(e[2], []).append(i)
+        members = [np.array(ix, dtype=np.int64) for ix in groups.values()]
+    else:
+        members = [np.arange(n_ev)]
+    for ix in members:
+        c = ev_cnt[ix]
+        sel = np.repeat(ev_first[ix], c) + (np.arange(int(c.sum())) - np.repeat(np.cumsum(c) - c, c))
+        mid.instruments.append(pretty_midi.Instrument.from_arrays(piano_program, ev_pitch[ix], ev_vel[ix], ev_start[ix],
+                                                                  ev_end[ix], ticks[sel], times[sel]))
     return mid
 
 
@@ -185,8 +197,14 @@ def model_output_to_notes(
     ev, bends, n = _decode(frames, onsets, contours, onset_thresh, frame_thresh, min_note_len, infer_onsets,
                            max_freq, min_freq, melodia_trick, ENERGY_TOLERANCE, include_pitch_bends)
     events: List[NoteEvent] = []
+    flat_bends = bends.tolist() if (include_pitch_bends and hasattr(bends, "tolist")) else None
     for i in range(n):
         e = ev[i]
-        b = [int(v) for v in bends[e.bend_offset : e.bend_offset + e.n_bends]] if include_pitch_bends else None
+        if not include_pitch_bends:
+            b = None
+        elif flat_bends is not None:
+            b = flat_bends[e.bend_offset : e.bend_offset + e.n_bends]
+        else:
+            b = [int(v) for v in bends[e.bend_offset : e.bend_offset + e.n_bends]]
         events.append((float(e.start_s), float(e.end_s), int(e.pitch_midi), np.float32(e.amplitude), b))
     return note_events_to_midi(events, multiple_pitch_bends, midi_tempo), events
