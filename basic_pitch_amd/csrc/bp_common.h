@@ -118,6 +118,14 @@ __device__ __forceinline__ void split_f16x2(f32x2 v, uint32_t& hi2, uint32_t& lo
 #endif
 }
 
+// ReLU as ONE integer max on the bit pattern (negative floats, -0 included, are negative integers).  fmaxf(v, 0) on a
+// value that comes straight out of a matrix instruction costs two v_max_f32: the compiler has to quiet a possible
+// signalling NaN first.
+__device__ __forceinline__ float relu_f32(float v) {
+  const int b = __float_as_int(v);
+  return __int_as_float(b > 0 ? b : 0);
+}
+
 // order-preserving float <-> int map so per-window min/max can use integer atomics
 __device__ __forceinline__ int f2ord(float f) {
   int i = __float_as_int(f);

@@ -562,7 +562,7 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
             }
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-              f32x2 v{fmaxf(acc[r], 0.0f), fmaxf(acc[r + 1], 0.0f)};
+              f32x2 v{relu_f32(acc[r]), relu_f32(acc[r + 1])};
               split_f16x2(v, b2hw[r >> 1], b2lw[r >> 1]);
             }
           }

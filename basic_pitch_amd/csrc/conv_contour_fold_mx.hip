@@ -279,10 +279,10 @@ __global__ __launch_bounds__(kFxThreads, 2) void contour_conv1_fold_mx_kernel(Fo
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float4 v;
-          v.x = fmaxf(acc[4 * j + 0], 0.0f);
-          v.y = fmaxf(acc[4 * j + 1], 0.0f);
-          v.z = fmaxf(acc[4 * j + 2], 0.0f);
-          v.w = fmaxf(acc[4 * j + 3], 0.0f);
+          v.x = relu_f32(acc[4 * j + 0]);
+          v.y = relu_f32(acc[4 * j + 1]);
+          v.z = relu_f32(acc[4 * j + 2]);
+          v.w = relu_f32(acc[4 * j + 3]);
           *reinterpret_cast<float4*>(dst + j * 8) = v;
         }
       }
