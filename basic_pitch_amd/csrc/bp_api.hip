@@ -594,7 +594,7 @@ void pack_note1(const Tensor* w, std::vector<float>& out) {
 //   fp8(hi_w) x 8 channels], meeting the image slot's [fp8(a) | fp8(lo_a)].  ONE scale per out channel for both kinds:
 //   lo_w is stored 2^11 larger than hi_w (|lo_w| <= 2^-11 |w|), lo_a arrives 2^11 larger than a, so both products carry
 //   2^(e - 17) and a 32-tap K block may mix them.
-void pack_onset_mx(const Tensor* w1, std::vector<uint8_t>& mx, std::vector<int32_t>& scales, int sa_exp) {
+void pack_onset_mx(const Tensor* w1, std::vector<uint8_t>& mx, std::vector<int32_t>& scales) {
   mx.assign((size_t)7 * 64 * 32, 0);
   scales.assign(64, 127);
   for (int i = 0; i < 32; ++i) {
@@ -602,7 +602,7 @@ void pack_onset_mx(const Tensor* w1, std::vector<uint8_t>& mx, std::vector<int32
     for (int k = 0; k < 8 * 25; ++k) mhi = std::fmax(mhi, std::fabs((double)f16_to_f32(f32_to_f16(w1->data[i * 200 + k]))));
     int e = mhi > 0 ? (int)std::ceil(std::log2(mhi / 448.0)) : -100;
     e = e < -100 ? -100 : e;
-    // products: (A0 2^(e-11)) (a8 2^-sa) and (A1 2^e) (lo8 2^-sa 2^-11): scale_a = 2^(e-11), scale_b = 2^-sa
+    // products: (A0 2^(e-11)) (a8 2^-6) and (A1 2^e) (lo8 2^-6 2^-11): scale_a = 2^(e-11), scale_b = 2^-6 (kMxSA)
     scales[i] = scales[32 + i] = 127 + e - 11;
     for (int S = 0; S < 7; ++S)
       for (int kh = 0; kh < 2; ++kh)
@@ -617,7 +617,6 @@ void pack_onset_mx(const Tensor* w1, std::vector<uint8_t>& mx, std::vector<int32
           }
         }
   }
-  (void)sa_exp;
 }
 
 void pack_branch(int ks1, const Tensor* w1, const Tensor* w2, bool onset, std::vector<uint16_t>& out) {
@@ -1052,7 +1051,7 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     if (const char* eo = std::getenv("BP_ONSET"); !(eo && std::strcmp(eo, "f16") == 0) && fp8_ok && !(flags & BP_FLAG_BF16_WEIGHTS)) {
       std::vector<uint8_t> mxf;
       std::vector<int32_t> mxs;
-      pack_onset_mx(o1w, mxf, mxs, 6);
+      pack_onset_mx(o1w, mxf, mxs);
       std::vector<float> raw(mxf.size() / 4 + mxs.size());
       std::memcpy(raw.data(), mxf.data(), mxf.size());
       std::memcpy(raw.data() + mxf.size() / 4, mxs.data(), mxs.size() * 4);
