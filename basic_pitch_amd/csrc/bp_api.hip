@@ -20,6 +20,10 @@ namespace bp {
 void launch_pyramid(const float* audio, float* pyr, const float* lowpass, int n_windows, hipStream_t s);
 void launch_window_track(const float* samples, int64_t n_samples, int64_t first_window, int n_windows,
                          float* audio, int win_len, int hop, int lead, hipStream_t stream);
+void launch_window_tracks(const TrackSegs& ts, int n_slots, float* audio, int win_len, int hop, int lead,
+                          hipStream_t stream);
+void launch_unwrap_tracks(const TrackSegs& ts, int n_slots, const float* note, const float* onset, const float* contour,
+                          hipStream_t stream);
 void launch_unwrap(const float* win_out, int n_freq, int64_t first_window, int n_windows,
                    int64_t total_rows, float* out, hipStream_t s);
 size_t filterbank_scratch_floats(int n_windows);
@@ -1378,35 +1382,42 @@ int bp_infer_tracks(bp_handle h, int64_t n_tracks, const float* const* samples, 
       d_contour[t] = contour[t];
     }
   }
-  struct Seg {
-    int64_t track, w0;
-    int n, at;
-  };
-  std::vector<Seg> segs;
+  // the windows of consecutive tracks are packed into full chunks; the pieces of a chunk are windowed by ONE launch and
+  // un-overlapped by one launch (bp_common.h TrackSegs; more than kMaxTrackSegs pieces per chunk: several launches)
+  std::vector<TrackSeg> segs;
   int cur = 0;
+  auto for_groups = [&](auto&& fn) {
+    for (size_t g0 = 0; g0 < segs.size(); g0 += kMaxTrackSegs) {
+      TrackSegs ts{};
+      ts.n = (int)std::min<size_t>(kMaxTrackSegs, segs.size() - g0);
+      for (int k = 0; k < ts.n; ++k) ts.seg[k] = segs[g0 + k];
+      const int first = ts.seg[0].at, slots = ts.seg[ts.n - 1].at + ts.seg[ts.n - 1].n_windows - first;
+      for (int k = 0; k < ts.n; ++k) ts.seg[k].at -= first;  // slots relative to the group's first window
+      fn(ts, first, slots);
+    }
+  };
   auto flush = [&]() -> int {
     if (cur == 0) return BP_OK;
+    for_groups([&](const TrackSegs& ts, int first, int slots) {
+      launch_window_tracks(ts, slots, h->audio + (int64_t)first * h->win_len, h->win_len, h->hop, h->lead, s);
+    });
     int rc = run_chunk(h, h->audio, cur, h->note, h->onset, h->contour);
     if (rc) return rc;
-    for (const Seg& g : segs) {
-      const int64_t T = h_track_n_frames(h, n_samples[g.track]);
-      if (T <= 0) continue;
-      launch_unwrap(h->note + (int64_t)g.at * kPlaneN, 88, g.w0, g.n, T, d_note[g.track], s);
-      launch_unwrap(h->onset + (int64_t)g.at * kPlaneN, 88, g.w0, g.n, T, d_onset[g.track], s);
-      launch_unwrap(h->contour + (int64_t)g.at * kPlaneC, 264, g.w0, g.n, T, d_contour[g.track], s);
-    }
+    for_groups([&](const TrackSegs& ts, int first, int slots) {
+      launch_unwrap_tracks(ts, slots, h->note + (int64_t)first * kPlaneN, h->onset + (int64_t)first * kPlaneN,
+                           h->contour + (int64_t)first * kPlaneC, s);
+    });
     segs.clear();
     cur = 0;
     return BP_OK;
   };
   for (int64_t t = 0; t < n_tracks; ++t) {
     const int64_t n_win = h_track_n_windows(h, n_samples[t]);
+    const int64_t T = h_track_n_frames(h, n_samples[t]);
     for (int64_t w0 = 0; w0 < n_win;) {
       const int64_t room = h->cap - cur;
       const int n = (int)((n_win - w0) < room ? (n_win - w0) : room);
-      launch_window_track(d_in[t], n_samples[t], w0, n, h->audio + (int64_t)cur * h->win_len, h->win_len, h->hop, h->lead,
-                          s);
-      segs.push_back({t, w0, n, cur});
+      segs.push_back(TrackSeg{d_in[t], {d_note[t], d_onset[t], d_contour[t]}, n_samples[t], w0, T, n, cur});
       cur += n;
       w0 += n;
       if (cur == h->cap) {

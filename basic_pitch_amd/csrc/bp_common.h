@@ -126,6 +126,24 @@ __device__ __forceinline__ float relu_f32(float v) {
   return __int_as_float(b > 0 ? b : 0);
 }
 
+// The pieces of tracks that make up one chunk of windows (bp_infer_tracks packs the windows of consecutive tracks into
+// full chunks): one launch windows them all, one launch un-overlaps all three posteriorgrams of all of them — per-piece
+// launches of these small kernels cost 5-9 us each, ~10 % of a whole-tracks job.
+constexpr int kMaxTrackSegs = 16;
+struct TrackSeg {
+  const float* samples;  // the track (device)
+  float* out[3];         // its un-overlapped note / onset / contour maps (device), T rows each
+  int64_t n_samples;
+  int64_t first_window;  // first window of this piece within the track
+  int64_t total_rows;    // T of the track
+  int n_windows;         // windows of this piece
+  int at;                // its first window's slot in the chunk
+};
+struct TrackSegs {
+  TrackSeg seg[kMaxTrackSegs];
+  int n;
+};
+
 // order-preserving float <-> int map so per-window min/max can use integer atomics
 __device__ __forceinline__ int f2ord(float f) {
   int i = __float_as_int(f);

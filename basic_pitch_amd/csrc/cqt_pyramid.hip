@@ -109,6 +109,26 @@ void launch_window_track(const float* samples, int64_t n_samples, int64_t first_
                      n_samples, first_window, audio, win_len, hop, lead);
 }
 
+// all pieces of a chunk in one launch: blockIdx.y = window slot of the chunk
+__global__ __launch_bounds__(256) void window_tracks_kernel(TrackSegs ts, float* __restrict__ audio, int win_len, int hop,
+                                                            int lead) {
+  const int slot = blockIdx.y;
+  int k = 0;
+  while (k + 1 < ts.n && slot >= ts.seg[k + 1].at) ++k;  // block-uniform
+  const TrackSeg& g = ts.seg[k];
+  const int64_t start = (g.first_window + (slot - g.at)) * hop - lead;
+  float* dst = audio + (int64_t)slot * win_len;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < win_len; i += gridDim.x * 256) {
+    const int64_t x = start + i;
+    dst[i] = (x >= 0 && x < g.n_samples) ? g.samples[x] : 0.0f;
+  }
+}
+
+void launch_window_tracks(const TrackSegs& ts, int n_slots, float* audio, int win_len, int hop, int lead,
+                          hipStream_t stream) {
+  hipLaunchKernelGGL(window_tracks_kernel, dim3(43, n_slots), dim3(256), 0, stream, ts, audio, win_len, hop, lead);
+}
+
 // ---- unwrap_output (inference.py:267-279): keep frames 15..156 of every window, trim to T rows ----
 __global__ __launch_bounds__(256) void unwrap_kernel(const float* __restrict__ win_out, int n_freq,
                                                      int64_t first_window, int64_t total_rows,
@@ -127,6 +147,32 @@ void launch_unwrap(const float* win_out, int n_freq, int64_t first_window, int n
                    int64_t total_rows, float* out, hipStream_t stream) {
   hipLaunchKernelGGL(unwrap_kernel, dim3(16, n_windows), dim3(256), 0, stream, win_out, n_freq,
                      first_window, total_rows, out);
+}
+
+// all pieces of a chunk and all three maps in one launch: blockIdx.y = window slot, blockIdx.z = map
+__global__ __launch_bounds__(256) void unwrap_tracks_kernel(TrackSegs ts, const float* __restrict__ note,
+                                                            const float* __restrict__ onset,
+                                                            const float* __restrict__ contour) {
+  const int slot = blockIdx.y, map = blockIdx.z;
+  int k = 0;
+  while (k + 1 < ts.n && slot >= ts.seg[k + 1].at) ++k;
+  const TrackSeg& g = ts.seg[k];
+  if (g.total_rows <= 0) return;
+  const int n_freq = map == 2 ? 264 : 88;
+  const float* win_out = map == 0 ? note : (map == 1 ? onset : contour);
+  float* out = g.out[map];
+  const int64_t row0 = (g.first_window + (slot - g.at)) * 142;
+  const float* src = win_out + ((int64_t)slot * kFrames + 15) * n_freq;
+  const int n = 142 * n_freq;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int64_t row = row0 + i / n_freq;
+    if (row < g.total_rows) out[row0 * n_freq + i] = src[i];
+  }
+}
+
+void launch_unwrap_tracks(const TrackSegs& ts, int n_slots, const float* note, const float* onset, const float* contour,
+                          hipStream_t stream) {
+  hipLaunchKernelGGL(unwrap_tracks_kernel, dim3(16, n_slots, 3), dim3(256), 0, stream, ts, note, onset, contour);
 }
 
 }  // namespace bp

@@ -535,6 +535,16 @@ def test_multi_track_packing_is_bit_identical():
             assert np.array_equal(got[k].cpu().numpy(), ref[k]), k
     assert m.predict_tracks([]) == []
     m.close()
+    # more pieces per chunk than one windowing / un-overlapping launch describes (kMaxTrackSegs = 16): 40 one- and
+    # two-window tracks in chunks of 64 windows
+    m = Model(max_windows=64)
+    lens = [int(n) for n in rng.integers(1, 60000, 40)]
+    tracks = [rng.uniform(-0.5, 0.5, n).astype(np.float32) for n in lens]
+    for t, got in zip(tracks, m.predict_tracks(tracks)):
+        ref = m.predict_track(t)
+        for k in ref:
+            assert got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k]), (len(t), k)
+    m.close()
 
 
 def test_device_audio_ingest(weights):
