@@ -61,7 +61,7 @@ HBM_PEAK_GBS = 8000.0
 DTYPE_F16 = "f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands"
 DTYPE_DEFAULT = (DTYPE_F16 + "; contour conv1 interior and onset conv1: hi*hi on f16, the two correction products (<= 2^-11 of a "
                  "product) on block-scaled fp8 MFMA (--f16-corrections: all three on f16)")
-PMC_PROFILE = "r02_f"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
+PMC_PROFILE = "r02_i"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
 
 
 def pmc_traffic(kernel_key: str, batch: int):
