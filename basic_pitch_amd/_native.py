@@ -22,6 +22,7 @@ BP_FLAG_F32_MFMA = 2
 BP_FLAG_BF16_WEIGHTS = 4
 BP_FLAG_EXT_CQT_44K = 8
 BP_FLAG_F16_CORRECTIONS = 32
+BP_FLAG_FP8_CORRECTIONS = 64
 BP_N_STAGES = 15
 BP_Z_ROW = 448
 BP_Z_ROWS = 174

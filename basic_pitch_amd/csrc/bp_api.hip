@@ -1009,11 +1009,12 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wfold))) return fail(rc);
     pack_contour_rim(c1w, frag);
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wrim))) return fail(rc);
-    // folded conv1: fp8 block-scaled corrections by default (conv_contour_fold_mx.hip); BP_CONV1=f16 selects the
-    // three-product f16 kernel (A/B runs, and the reference for the fp8 corrections' ~1e-5 on the contour map)
+    // folded conv1: all three split-precision products on f16 by default (fp32-class); BP_FLAG_FP8_CORRECTIONS opts into
+    // the block-scaled fp8 corrections (conv_contour_fold_mx.hip; ~1e-5 on the contour map), BP_CONV1=f16 then keeps this
+    // one layer on the three-product f16 kernel (A/B runs).
     // the fp8 planes hold z 2^6 with z = bn_a x + bn_b, x in [0, 1] (NormalizedLog): they must stay below e4m3's 448
     const bool fp8_ok = std::fmax(std::fabs(h->kc.bn_b), std::fabs(h->kc.bn_a + h->kc.bn_b)) * 64.0f <= 440.0f &&
-                        !(flags & BP_FLAG_F16_CORRECTIONS);
+                        (flags & BP_FLAG_FP8_CORRECTIONS) && !(flags & BP_FLAG_F16_CORRECTIONS);
     if (const char* ec = std::getenv("BP_CONV1");
         !(ec && std::strcmp(ec, "f16") == 0) && fp8_ok && !(flags & BP_FLAG_BF16_WEIGHTS)) {
       std::vector<uint16_t> a16;
@@ -1051,7 +1052,7 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
           (rc = upload(h, f32, br ? &h->d_onset_wf32 : &h->d_note_wf32)))
         return fail(rc);
     }
-    // onset conv1: fp8 corrections by default like the folded contour conv1; BP_ONSET=f16 selects the three-product kernel
+    // onset conv1: fp8 corrections under BP_FLAG_FP8_CORRECTIONS like the folded contour conv1 (BP_ONSET=f16: not this layer)
     if (const char* eo = std::getenv("BP_ONSET"); !(eo && std::strcmp(eo, "f16") == 0) && fp8_ok && !(flags & BP_FLAG_BF16_WEIGHTS)) {
       std::vector<uint8_t> mxf;
       std::vector<int32_t> mxs;

@@ -75,19 +75,22 @@ uint8_t crc8(const uint8_t* d, size_t n) {
   return c;
 }
 
-uint16_t crc16(const uint8_t* d, size_t n) {
-  static uint16_t table[256];
-  static bool init = false;
-  if (!init) {
+struct Crc16Table {
+  uint16_t v[256];
+  Crc16Table() {
     for (int i = 0; i < 256; ++i) {
       uint16_t c = (uint16_t)(i << 8);
       for (int b = 0; b < 8; ++b) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : c << 1);
-      table[i] = c;
+      v[i] = c;
     }
-    init = true;
   }
+};
+
+uint16_t crc16(const uint8_t* d, size_t n) {
+  // a C++11 magic static: initialised once, thread-safely (files are decoded concurrently from a host thread pool)
+  static const Crc16Table table;
   uint16_t c = 0;
-  for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ table[(c >> 8) ^ d[i]]);
+  for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ table.v[(c >> 8) ^ d[i]]);
   return c;
 }
 

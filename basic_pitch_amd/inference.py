@@ -78,6 +78,7 @@ class Model:
         bf16_weights: bool = False,
         ext_cqt_44k: bool = False,
         f16_corrections: bool = False,
+        fp8_corrections: bool = False,
     ):
         self.model_type = Model.MODEL_TYPES.MI355X_HIP
         self._lib = _native.load_library()
@@ -92,8 +93,10 @@ class Model:
             flags |= _native.BP_FLAG_BF16_WEIGHTS
         if ext_cqt_44k:  # BASELINE.json configs[4]: 44.1 kHz windows of 87,688 samples, 10-octave / 345-bin CQT
             flags |= _native.BP_FLAG_EXT_CQT_44K
-        if f16_corrections:  # all three split-precision products on f16 MFMA (default: the two corrections on fp8)
+        if f16_corrections:  # the default arithmetic since round 3 (all three split-precision products on f16): a no-op
             flags |= _native.BP_FLAG_F16_CORRECTIONS
+        if fp8_corrections:  # opt-in reduced precision: contour / onset conv1 corrections on block-scaled fp8 MFMA
+            flags |= _native.BP_FLAG_FP8_CORRECTIONS
         rc = self._lib.bp_create(blob, len(blob), int(device), flags, int(max_windows), C.byref(self._handle))
         if rc != _native.BP_OK:
             self._handle = C.c_void_p()
@@ -532,6 +535,7 @@ def predict_many(
     group: int = 64,
     decode_threads: Optional[int] = None,
     return_exceptions: bool = False,
+    _finish: Optional[Any] = None,
 ) -> List[Tuple[Dict[str, np.ndarray], "infer.pretty_midi.PrettyMIDI", List["infer.NoteEvent"]]]:
     """predict() (inference.py:431-506) over many files, results in input order and identical to per-file predict().
 
@@ -543,6 +547,11 @@ def predict_many(
 
     `return_exceptions=True` isolates failures per file like the reference's per-file try / except
     (inference.py:548-604): the entry of a file that cannot be read or decoded is the exception instead of a tuple.
+
+    `_finish(index, result)` (internal; `predict_and_save_many`) runs on the pool right behind a file's note decoding and
+    its return value replaces the file's entry — the writers of a batch job, so that ONE pipeline runs over all files
+    (next group read while this one is on the GPU, decoding and writing of finished files behind it) and a file's
+    posteriorgrams are dropped as soon as they are written.  The GPU is kept at most two groups ahead of the decoders.
     """
     import concurrent.futures as cf
     import os
@@ -564,6 +573,10 @@ def predict_many(
             melodia_trick=melodia_trick, midi_tempo=midi_tempo,
         )
         return model_output, midi_data, note_events
+
+    def decode_and_finish(i: int, model_output: Dict[str, np.ndarray]):
+        res = decode(model_output)
+        return res if _finish is None else _finish(i, res)
 
     def read(p: pathlib.Path):
         verify_input_path(p)
@@ -588,8 +601,12 @@ def predict_many(
                     if not return_exceptions:
                         raise
                     results[i] = e
+            if _finish is not None and gi >= 2:  # back-pressure: posteriorgrams of at most two groups await decoding
+                for i in groups[gi - 2]:
+                    if isinstance(results[i], cf.Future):
+                        cf.wait([results[i]])
             for i, out in zip(good, model.predict_tracks(signals)):
-                results[i] = pool.submit(decode, out)
+                results[i] = pool.submit(decode_and_finish, i, out)
         for i, r in enumerate(results):
             if isinstance(r, cf.Future):
                 try:
@@ -646,33 +663,51 @@ def predict_and_save_many(
     decode_threads: Optional[int] = None,
     return_exceptions: bool = False,
 ) -> List[Any]:
-    """`predict_and_save` (inference.py:509-618) as a batch job: the files go through `predict_many` (windows packed
-    across files, reads and note decoding overlapped with the GPU) one group at a time, and a group's outputs are
-    written before the next group is predicted, so memory stays at one group of posteriorgrams.  Same files, same bytes
+    """`predict_and_save` (inference.py:509-618) as a batch job: ONE `predict_many` pipeline over all files (windows
+    packed across files; the next group's files are read while this one is on the GPU; note decoding AND the writers of
+    a finished file run on host threads behind it), a file's posteriorgrams are dropped once its outputs are written and
+    the GPU runs at most two groups ahead, so memory stays at a few groups of posteriorgrams.  Same files, same bytes
     as the per-file loop.  Returns per file `{"n_note_events": k, "outputs": {kind: path}}` — or, with
     `return_exceptions=True`, the exception that file raised (otherwise the first failure propagates, like the
-    reference's `raise e`)."""
+    reference's `raise e`).  Two inputs that map to the same output name (same stem) cannot both be written: as in the
+    reference's sequential loop (inference.py:401-404) the first one wins and every later one gets the "already exists"
+    IOError — decided up front, so concurrent writers never race on the exists-check."""
     model = Model(model_or_model_path) if isinstance(model_or_model_path, (str, os.PathLike)) else model_or_model_path
     paths = [pathlib.Path(p) for p in audio_path_list]
-    report: List[Any] = []
-    for g0 in range(0, len(paths), group):
-        chunk = paths[g0 : g0 + group]
-        results = predict_many(chunk, model, onset_threshold, frame_threshold, minimum_note_length, minimum_frequency,
-                               maximum_frequency, multiple_pitch_bends, melodia_trick, midi_tempo, group=group,
-                               decode_threads=decode_threads, return_exceptions=return_exceptions)
-        for audio_path, res in zip(chunk, results):
-            if isinstance(res, BaseException):
-                report.append(res)
-                continue
-            try:
-                written = _save_outputs(audio_path, output_directory, res, save_midi, sonify_midi, save_model_outputs,
-                                        save_notes, sonification_samplerate)
-                report.append({"n_note_events": len(res[2]), "outputs": written})
-            except Exception as e:
-                if not return_exceptions:
-                    raise
-                report.append(e)
+    dup = duplicate_output_stems(paths)
+    todo = [i for i in range(len(paths)) if i not in dup]
+
+    def finish(j: int, res):
+        written = _save_outputs(paths[todo[j]], output_directory, res, save_midi, sonify_midi, save_model_outputs,
+                                save_notes, sonification_samplerate)
+        return {"n_note_events": len(res[2]), "outputs": written}
+
+    report: List[Any] = [None] * len(paths)
+    for i, e in dup.items():
+        if not return_exceptions:
+            raise e
+        report[i] = e
+    done = predict_many([paths[i] for i in todo], model, onset_threshold, frame_threshold, minimum_note_length,
+                        minimum_frequency, maximum_frequency, multiple_pitch_bends, melodia_trick, midi_tempo, group=group,
+                        decode_threads=decode_threads, return_exceptions=return_exceptions, _finish=finish)
+    for i, r in zip(todo, done):
+        report[i] = r
     return report
+
+
+def duplicate_output_stems(paths: Sequence[Union[pathlib.Path, str]]) -> Dict[int, IOError]:
+    """Indices of inputs whose output name `<stem>_basic_pitch.*` (build_output_path) an EARLIER input of the list
+    already claims, with the IOError the reference's sequential loop would give them (inference.py:401-404)."""
+    seen: Dict[str, int] = {}
+    dup: Dict[int, IOError] = {}
+    for i, p in enumerate(paths):
+        stem, _ = os.path.splitext(os.path.basename(str(p)))
+        if stem in seen:
+            dup[i] = IOError(f"the outputs of {p} would overwrite those of {paths[seen[stem]]} (same file stem "
+                             f"'{stem}'). Skipping output files for {p}.")
+        else:
+            seen[stem] = i
+    return dup
 
 
 def predict_and_save(

@@ -53,8 +53,9 @@ def _decode(
     """One call into bp_notes_decode; returns the filled event / bend arrays."""
     lib = _native.load_library()
     # The reference takes any array-like (float64 arrays, sliced views, lists): coerce to what the C ABI needs.  When
-    # that makes a copy of note / onset, the constrained values are written back afterwards so the reference's
-    # in-place behaviour (note_creation.py:338-341) is kept; a read-only input is decoded from a copy and left alone.
+    # that makes a copy of note / onset, the columns `constrain_frequency` zeroed are zeroed in the caller's array as
+    # well, so the reference's in-place behaviour (note_creation.py:338-341) is kept — and nothing else is touched (a
+    # float64 input keeps its float64 values); a read-only input is decoded from a copy and left alone.
     given = {"note": frames, "onset": onsets}
     frames = np.require(frames, np.float32, ["C", "W"])
     onsets = np.require(onsets, np.float32, ["C", "W"])
@@ -86,7 +87,7 @@ def _decode(
             for name, used in (("note", frames), ("onset", onsets)):
                 orig = given[name]
                 if used is not orig and isinstance(orig, np.ndarray) and orig.flags.writeable:
-                    orig[...] = used
+                    orig[:, ~used.any(axis=0) & orig.any(axis=0)] = 0
             return events, bends, n_ev.value
         if n_ev.value > cap_ev or n_b.value > cap_b:  # buffers too small: sizes were returned
             cap_ev, cap_b = max(cap_ev, n_ev.value), max(cap_b, n_b.value)

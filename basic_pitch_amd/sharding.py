@@ -135,12 +135,65 @@ def _predict_shard(paths: Sequence[Any], indices: Sequence[int], device: int, mo
     return dict(zip(indices, res))
 
 
-def _spawned_worker(rank: int, world: int, device: int, paths, model_path, model_factory, kwargs, queue) -> None:
+def _post(queue, rank: int, produce: Callable[[], Any]) -> None:
+    """Run `produce` in a worker and post `(rank, pickled result)`; anything it raises — including a result that cannot
+    be pickled, which inside the queue's feeder thread would be lost without a trace — is posted as the exception."""
+    import pickle
+
     try:
-        shards = plan_shards(_file_costs(paths), world)
-        queue.put((rank, _predict_shard(paths, shards[rank], device, model_path, model_factory, kwargs)))
+        payload = pickle.dumps(produce())
     except BaseException as e:  # the parent must not wait forever for a rank that died early
-        queue.put((rank, e))
+        try:
+            payload = pickle.dumps(e)
+        except Exception:
+            payload = pickle.dumps(RuntimeError(f"rank {rank}: {type(e).__name__}: {e}"))
+    queue.put((rank, payload))
+
+
+def _collect(procs, queue, what: str, poll_s: float = 0.5) -> Dict[int, Any]:
+    """One posted result per worker, polling so that a worker that died NATIVELY (HIP abort, segfault, OOM kill — no
+    Python exception, nothing posted) is noticed: its exit code is reported instead of waiting for it forever."""
+    import pickle
+    import queue as queue_mod
+
+    pending = set(range(len(procs)))
+    merged: Dict[int, Any] = {}
+    failed: Optional[BaseException] = None
+    grace: Dict[int, int] = {}
+    while pending:
+        try:
+            rank, payload = queue.get(timeout=poll_s)
+        except queue_mod.Empty:
+            for r in sorted(pending):
+                if not procs[r].is_alive():
+                    # a worker that posted just before exiting: give the pipe a few polls to deliver
+                    grace[r] = grace.get(r, 0) + 1
+                    if grace[r] >= 4:
+                        pending.discard(r)
+                        failed = failed or RuntimeError(
+                            f"{what}: worker {r} exited with code {procs[r].exitcode} without posting a result")
+            continue
+        pending.discard(rank)
+        part = pickle.loads(payload)
+        if isinstance(part, BaseException):
+            failed = failed or part
+        else:
+            merged.update(part)
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.terminate()
+    if failed is not None:
+        raise RuntimeError(f"{what}: a worker failed: {failed!r}") from failed
+    return merged
+
+
+def _spawned_worker(rank: int, world: int, device: int, paths, model_path, model_factory, kwargs, queue) -> None:
+    def produce():
+        shards = plan_shards(_file_costs(paths), world)
+        return _predict_shard(paths, shards[rank], device, model_path, model_factory, kwargs)
+
+    _post(queue, rank, produce)
 
 
 def predict_many_sharded(
@@ -218,18 +271,7 @@ def predict_many_sharded(
              for r in range(world)]
     for p in procs:
         p.start()
-    merged = {}
-    failed: Optional[BaseException] = None
-    for _ in procs:
-        rank, part = queue.get()
-        if isinstance(part, BaseException):
-            failed = failed or part
-        else:
-            merged.update(part)
-    for p in procs:
-        p.join()
-    if failed is not None:
-        raise RuntimeError(f"a shard worker failed: {failed!r}") from failed
+    merged = _collect(procs, queue, "predict_many_sharded")
     return [merged[i] for i in range(len(paths))]
 
 
@@ -254,12 +296,11 @@ def _save_shard(paths: Sequence[Any], indices: Sequence[int], device: int, model
 
 def _spawned_saver(rank: int, world: int, device: int, paths, model_path, model_factory, output_directory, save_flags,
                    kwargs, queue) -> None:
-    try:
+    def produce():
         shards = plan_shards(_file_costs(paths), world)
-        queue.put((rank, _save_shard(paths, shards[rank], device, model_path, model_factory, output_directory, save_flags,
-                                     kwargs)))
-    except BaseException as e:
-        queue.put((rank, e))
+        return _save_shard(paths, shards[rank], device, model_path, model_factory, output_directory, save_flags, kwargs)
+
+    _post(queue, rank, produce)
 
 
 def predict_and_save_sharded(
@@ -291,6 +332,22 @@ def predict_and_save_sharded(
     if model_or_model_path is None:
         model_or_model_path = inference.ICASSP_2022_MODEL_PATH
     inference.verify_output_dir(output_directory)
+    # two inputs with the same stem would race on the exists-check of build_output_path when they land on different
+    # workers: decided here, before sharding (the first wins, later ones get the reference's IOError in place)
+    dup = inference.duplicate_output_stems(paths)
+    if dup:
+        keep = [i for i in range(len(paths)) if i not in dup]
+        sub = predict_and_save_sharded([paths[i] for i in keep], output_directory, save_midi, sonify_midi,
+                                       save_model_outputs, save_notes, model_or_model_path, gpus, workers_per_gpu,
+                                       model_factory, **predict_kwargs)
+        if sub is None:
+            return None
+        merged_all: List[Any] = [None] * len(paths)
+        for i, r in zip(keep, sub):
+            merged_all[i] = r
+        for i, e in dup.items():
+            merged_all[i] = e
+        return merged_all
     flags = {"save_midi": save_midi, "sonify_midi": sonify_midi, "save_model_outputs": save_model_outputs,
              "save_notes": save_notes}
     dist = None
@@ -339,16 +396,5 @@ def predict_and_save_sharded(
              for r in range(world)]
     for p in procs:
         p.start()
-    merged = {}
-    failed: Optional[BaseException] = None
-    for _ in procs:
-        rank, part = queue.get()
-        if isinstance(part, BaseException):
-            failed = failed or part
-        else:
-            merged.update(part)
-    for p in procs:
-        p.join()
-    if failed is not None:
-        raise RuntimeError("a worker of predict_and_save_sharded failed") from failed
+    merged = _collect(procs, queue, "predict_and_save_sharded")
     return [merged[i] for i in range(len(paths))]

@@ -44,11 +44,20 @@ def _require(cond: bool, what: str) -> None:
 
 
 def tensors_from_onnx(path_or_bytes) -> Dict[str, np.ndarray]:
-    """The 18 tensors of the frozen graph, by the names the C library looks up."""
+    """The 18 tensors of the frozen graph, by the names the C library looks up.  Anything that is not that graph — a
+    non-protobuf file, another model, a structurally damaged one — raises ValueError, the reference's contract for an
+    unloadable model (inference.py:148-154)."""
     try:
         nodes, inits = load_graph(path_or_bytes)
     except Exception as e:  # the wire reader on a non-protobuf file
         raise ValueError(f"cannot be read as an ONNX model: {e}") from e
+    try:
+        return _tensors_from_graph(nodes, inits)
+    except (KeyError, IndexError, TypeError, AttributeError) as e:  # a lookup the Basic Pitch graph always satisfies
+        raise ValueError(f"not the Basic Pitch graph: {type(e).__name__}: {e}") from e
+
+
+def _tensors_from_graph(nodes, inits) -> Dict[str, np.ndarray]:
     convs = [n for n in nodes if n["op_type"] == "Conv"]
     cqt_convs = [n for n in convs if n["attr"].get("kernel_shape") == [1, 256]]
     cnn_convs = [n for n in convs if n["attr"].get("kernel_shape") != [1, 256]]

@@ -12,11 +12,11 @@ units: file/window sharding, no collective on the data path — SURVEY.md §8e),
 and `value` = windows processed by all ranks / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (contour_conv1_kernel: Conv2D 8->8 3x39, 65 % of the path's FLOPs): algorithmic FLOP per
-                launch / mean launch duration measured with HIP events on the kernel's stream over the
-                timed steps, against the dense f16 MFMA peak (2.5 PFLOP/s; the kernel spends one f16 MFMA per
-                product plus half an f16-equivalent on block-scaled fp8 for the two split-precision corrections,
-                so frac <= 1/2 by construction — executed_frac is the matrix-pipe occupancy)
+  roofline      dominant kernel (contour_conv1_folded_kernel: Conv2D 8->8 3x39, 65 % of the path's FLOPs): algorithmic FLOP
+                per launch / mean launch duration measured with HIP events on the kernel's stream over the
+                timed steps, against the dense f16 MFMA peak (2.5 PFLOP/s; the kernel spends three f16 MFMAs per
+                product — hi*hi + lo*hi + hi*lo, the fp32-class split — on a folded operator with 528 instead of 936
+                products per output, so frac <= 0.59 by construction — executed_frac is the matrix-pipe occupancy)
   cpu_baseline  the oracle's C restatement of the frozen graph (fp32, AVX2, OpenMP over windows, all host
                 cores) timed on rank 0 on a bounded sample of the same synthetic windows ("port": the
                 reference's own ONNX/TF runtimes are not installable here)
@@ -58,9 +58,11 @@ F1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 224 * 8 * 4  # zp read + interior c1
 D1_EXECUTED_FLOP_PER_WINDOW = 45 * 8 * 63 * 3 * (2 * 32 * 32 * 16)
 D1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 264 * 8 * 4  # zp read + c1 written
 HBM_PEAK_GBS = 8000.0
-DTYPE_F16 = "f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands"
-DTYPE_DEFAULT = (DTYPE_F16 + "; contour conv1 interior and onset conv1: hi*hi on f16, the two correction products (<= 2^-11 of a "
-                 "product) on block-scaled fp8 MFMA (--f16-corrections: all three on f16)")
+DTYPE_F16 = "f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands, all three products of every layer on f16 MFMA"
+DTYPE_DEFAULT = DTYPE_F16  # since round 3 the default IS the all-f16 split (fp32-class)
+DTYPE_FP8 = ("f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands; OPT-IN reduced precision (--fp8-corrections): contour "
+             "conv1 interior and onset conv1 issue hi*hi on f16 and the two correction products (<= 2^-11 of a product) on "
+             "block-scaled fp8 MFMA")
 PMC_PROFILE = "r02_i"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
 
 
@@ -142,7 +144,7 @@ def run_tracks(args, torch, dist, world, rank, local_rank) -> None:
     lengths = [int(base * (1.0 - 0.02 * rng.random())) for _ in range(args.tracks)]
     shards = plan_shards(lengths, world)
     mine = shards[rank]
-    model = Model(device=local_rank, max_windows=256)
+    model = Model(device=local_rank, max_windows=256, fp8_corrections=args.fp8_corrections)
     lib = model._lib
     g = torch.Generator(device=dev)
     g.manual_seed(99 + rank)
@@ -169,16 +171,12 @@ def run_tracks(args, torch, dist, world, rank, local_rank) -> None:
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    total = torch.tensor([float(n_windows)], device=dev, dtype=torch.float64)
-    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(total, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total = args.reduce_over_ranks(float(n_windows), dist.ReduceOp.SUM)
+    elapsed = args.reduce_over_ranks(elapsed, dist.ReduceOp.MAX)
     if rank == 0:
-        elapsed = float(tmax.item())
         line = {
             "metric": "audio windows/sec (2 s @ 22.05 kHz) end-to-end CQT+CNN",
-            "value": float(total.item()) * args.steps / elapsed,
+            "value": total * args.steps / elapsed,
             "unit": "windows/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -187,7 +185,7 @@ def run_tracks(args, torch, dist, world, rank, local_rank) -> None:
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": DTYPE_DEFAULT if os.environ.get("BP_CONV1") != "f16" else DTYPE_F16,
+            "dtype": DTYPE_FP8 if args.fp8_corrections else DTYPE_DEFAULT,
             "data": "synthetic",
             "config": {
                 "workload": f"{args.tracks} synthetic 3-minute tracks (110 windows each) through bp_infer_tracks (64 tracks per call), "
@@ -296,8 +294,16 @@ def main() -> None:
                     help="BASELINE.json configs[4]: 44.1 kHz windows (87,688 samples), 10-octave / 345-bin CQT (use with "
                     "--batch 512); not the headline line")
     ap.add_argument("--f16-corrections", action="store_true",
-                    help="BP_FLAG_F16_CORRECTIONS: all three split-precision products on f16 MFMA (A/B against the default, "
-                         "whose contour / onset conv1 corrections run on block-scaled fp8)")
+                    help="accepted for compatibility: all three split-precision products on f16 MFMA is the default since round 3")
+    ap.add_argument("--fp8-corrections", action="store_true",
+                    help="BP_FLAG_FP8_CORRECTIONS (opt-in, reduced precision): the contour / onset conv1 corrections on "
+                         "block-scaled fp8 MFMA; not the headline line")
+    ap.add_argument("--no-fp8-extra", action="store_true", help="skip the extra fp8-corrections rate (profiling runs)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="all ranks use device 0 (exercising the N > 1 path on a one-GPU box; the numbers mean nothing)")
+    ap.add_argument("--control-backend", choices=["gloo", "nccl"], default="gloo",
+                    help="process group of the barrier / max-over-ranks reduction around the timed region: the data path "
+                         "has no collective, so the control path runs on CPU tensors over gloo by default")
     ap.add_argument("--bf16-weights", action="store_true",
                     help="BASELINE.json configs[3]: bf16 CNN weights + fp32 CQT (use with --batch 1024); not the headline line")
     args = ap.parse_args()
@@ -324,13 +330,31 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
+        # Control path only (barrier + max over ranks around the timed region): windows are independent units and the
+        # data path has no collective, so the default control group is gloo on CPU tensors; nccl (= RCCL)
+        # is kept behind --control-backend nccl.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.control_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from basic_pitch_amd.inference import Model
 
+    ctl_dev = torch.device("cuda", local_rank) if args.control_backend == "nccl" else torch.device("cpu")
+
+    def reduce_over_ranks(x: float, op) -> float:
+        if world == 1:
+            return x
+        t = torch.tensor([x], device=ctl_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    args.reduce_over_ranks = reduce_over_ranks
     if args.workload == "files":
         run_files(args)
         return
@@ -356,7 +380,7 @@ def main() -> None:
     # The exact-f32 A/B path has no dominant-only mode: it is timed with the full set.
     model = Model(device=local_rank, max_windows=B, stage_timing=args.exact_f32, time_dominant=not args.exact_f32,
                   exact_f32_mfma=args.exact_f32, bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k,
-                  f16_corrections=args.f16_corrections)
+                  fp8_corrections=args.fp8_corrections)
 
     def step():
         model._predict_device(audio, out=out, sync=False)
@@ -383,7 +407,7 @@ def main() -> None:
         # stays the one measured inside the timed region
         dom = {k: v for k, v in stage.items() if v > 0.0}
         model.close()
-        model = Model(device=local_rank, max_windows=B, stage_timing=True, f16_corrections=args.f16_corrections,
+        model = Model(device=local_rank, max_windows=B, stage_timing=True, fp8_corrections=args.fp8_corrections,
                       bf16_weights=args.bf16_weights,
                       ext_cqt_44k=args.ext_cqt_44k)
         for _ in range(3):
@@ -399,10 +423,7 @@ def main() -> None:
     else:
         stage_all_pass = None
 
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = reduce_over_ranks(elapsed, dist.ReduceOp.MAX)
 
     ok = bool(torch.isfinite(out["note"]).all() and torch.isfinite(out["onset"]).all() and torch.isfinite(out["contour"]).all())
 
@@ -412,7 +433,7 @@ def main() -> None:
     extras = {}
     if not args.exact_f32 and args.sustained_s > 0:
         sus_model = Model(device=local_rank, max_windows=B, bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k,
-                          f16_corrections=args.f16_corrections)
+                          fp8_corrections=args.fp8_corrections)
         n_sus = max(args.steps, int(args.sustained_s / (elapsed / args.steps)) + 1)
 
         def sus_step():
@@ -430,10 +451,7 @@ def main() -> None:
         if world > 1:
             dist.barrier()
         t_sus = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([t_sus], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            t_sus = float(t.item())
+        t_sus = reduce_over_ranks(t_sus, dist.ReduceOp.MAX)
         sus_model.close()
         extras["sustained"] = {"windows_per_s": B * n_sus * world / t_sus, "steps": n_sus, "seconds": t_sus,
                                "ms_per_step": t_sus / n_sus * 1e3,
@@ -449,6 +467,21 @@ def main() -> None:
         torch.cuda.synchronize()
         extras["exact_f32_windows_per_s"] = B * 8 / (time.perf_counter() - t0)
         ex_model.close()
+    if (not args.exact_f32 and not args.no_fp8_extra and not args.fp8_corrections and rank == 0
+            and not (args.bf16_weights or args.ext_cqt_44k)):
+        # beside the headline, never instead of it: the opt-in reduced-precision mode on the same batch
+        fx_model = Model(device=local_rank, max_windows=B, fp8_corrections=True)
+        for _ in range(3):
+            fx_model._predict_device(audio, out=out, sync=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fx_model._predict_device(audio, out=out, sync=False)
+        torch.cuda.synchronize()
+        extras["fp8_corrections_windows_per_s"] = B * args.steps / (time.perf_counter() - t0)
+        extras["fp8_corrections_note"] = ("BP_FLAG_FP8_CORRECTIONS, opt-in: contour / onset conv1 corrections on block-scaled fp8 "
+                                          "MFMA — narrower than the config's fp32, reported beside `value`")
+        fx_model.close()
 
     if rank == 0:
         total_windows = B * args.steps * world
@@ -465,7 +498,7 @@ def main() -> None:
             c1_ms = stage["contour_conv1"]
             folded = stage.get("contour_conv1_edge", 0.0) > 0.0
             mf = (2 / 3 if args.bf16_weights else 1)
-            mx = folded and os.environ.get("BP_CONV1") != "f16" and not args.bf16_weights and not args.f16_corrections
+            mx = folded and os.environ.get("BP_CONV1") != "f16" and not args.bf16_weights and args.fp8_corrections
             if mx:
                 c1_flop = C1_FLOP_PER_WINDOW * F1_SHARE
                 c1_kernel = ("contour_conv1_fold_mx_kernel (interior 56/66 of harmonic stack + Conv2D 8->8 3x39 + ReLU with the 8 "
@@ -517,7 +550,7 @@ def main() -> None:
             # weights rounded to bf16 (one f16 operand), activations and CQT unchanged
             "dtype": ("f32 I/O + accumulate, bf16-rounded weights as single f16 MFMA operands, split-f16 activations" if args.bf16_weights
                       else "exact f32 MFMA (A/B path)" if args.exact_f32
-                      else DTYPE_F16 if args.f16_corrections or os.environ.get("BP_CONV1") == "f16" else DTYPE_DEFAULT),
+                      else DTYPE_FP8 if args.fp8_corrections else DTYPE_DEFAULT),
             "data": "synthetic",
             "config": {
                 "workload": f"batch={B} synthetic uniform[-1,1) 2 s @ 22.05 kHz mono windows per GPU, "
@@ -527,6 +560,8 @@ def main() -> None:
                    else "fp32, HBM-resident in/out (BASELINE.json configs[1])"),
                 "windows_per_step_per_gpu": B,
                 "sharding": "independent windows per rank, no collective",
+                **({"share_gpu": "all ranks on device 0 (functional check of the N > 1 path, not a scaling number)"}
+                   if args.share_gpu else {}),
             },
             "roofline": {
                 "kernel": c1_kernel,
@@ -544,7 +579,7 @@ def main() -> None:
                 "algorithmic_flop_per_launch": c1_flop * B,
             },
             "path_roofline": {
-                "flop_frac_f32_peak": FLOP_PER_WINDOW * value / world / (F32_MFMA_PEAK_TFLOPS * 1e12),
+                "flop_frac_f16_peak": FLOP_PER_WINDOW * value / world / (F16_MFMA_PEAK_TFLOPS * 1e12),
                 "hbm_frac_algorithmic": BYTES_PER_WINDOW * value / world / (HBM_PEAK_GBS * 1e9),
             },
             "stage_ms": stage,

@@ -85,14 +85,19 @@ typedef enum bp_mem_kind {
                                    * stage alone.  Two event records per chunk instead of sixteen: the full set costs
                                    * ~25 us (2.6 %) of a 256-window step.  Ignored with BP_FLAG_STAGE_TIMING / F32_MFMA. */
 
-#define BP_FLAG_F16_CORRECTIONS 32u /* The default path issues the two correction products of the split-precision scheme
-                                    * (lo_w a + hi_w lo_a, each <= 2^-11 of a product) of the two largest layers — the
-                                    * folded contour conv1 and the onset conv1 — on the block-scaled fp8 matrix instruction
-                                    * (one v_mfma_scale_f32_32x32x64_f8f6f4 per 32 taps instead of four f16 instructions):
-                                    * ~1e-5 on the contour map, ~3e-5 on the onset map against the fp64 graph, inside the
-                                    * 1e-4 of the parity contract.  This flag keeps all three products on the f16
-                                    * instruction (5e-6 / 5e-7 per stage) at ~7 % of the throughput.  (Environment, for A/B
-                                    * runs of one layer: BP_CONV1=f16, BP_ONSET=f16.)  Implied by BP_FLAG_BF16_WEIGHTS. */
+#define BP_FLAG_F16_CORRECTIONS 32u /* Since round 3 this is the DEFAULT arithmetic and the flag is accepted as a no-op (it
+                                    * wins over BP_FLAG_FP8_CORRECTIONS when both are set): every matrix product of the path
+                                    * is hi hi + lo hi + hi lo on the f16 instruction with fp32 accumulation — fp32-class
+                                    * results (<= 2^-22 per product), 5e-6 / 5e-7 per stage against the fp32 oracle. */
+#define BP_FLAG_FP8_CORRECTIONS 64u /* OPT-IN reduced-precision mode, not the reference's fp32 contract: the two correction
+                                    * products of the split-precision scheme (lo_w a + hi_w lo_a, each <= 2^-11 of a product)
+                                    * of the two largest layers — the folded contour conv1 and the onset conv1 — run on the
+                                    * block-scaled fp8 matrix instruction (one v_mfma_scale_f32_32x32x64_f8f6f4 per 32 taps
+                                    * instead of four f16 instructions): ~1e-5 on the contour map, ~3e-5 on the onset map
+                                    * against the fp64 graph, ~8 % more throughput; 1 of 512 noise-like windows measured at
+                                    * 1.05e-4 (profiles/r02_parity_many.md).  (Environment, for A/B runs of one layer on a
+                                    * handle created with this flag: BP_CONV1=f16, BP_ONSET=f16.)  Ignored with
+                                    * BP_FLAG_BF16_WEIGHTS / BP_FLAG_F32_MFMA. */
 
 /*
  * Weights blob ("BPAMDW01", little endian) — produced from the reference's nmp.onnx

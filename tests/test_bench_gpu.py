@@ -1,0 +1,59 @@
+"""bench.py on hardware: the N > 1 path of the benchmark contract executed before the driver does.
+
+The box has one GPU, so the two ranks share device 0 (`--share-gpu`): what is checked is the control flow the driver's
+8-GPU launch goes through — self-launch over torch.distributed.run, rendezvous on 127.0.0.1, the gloo control group
+(barrier + max over ranks on CPU tensors; the data path has no collective), one JSON line from rank 0 —
+not a scaling number."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+def _json_lines(text):
+    out = []
+    for ln in text.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                out.append(json.loads(ln))
+            except ValueError:
+                pass
+    return out
+
+
+def test_bench_two_ranks_share_one_gpu():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-exact-f32", "--no-fp8-extra", "--sustained-s", "0"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-4000:]
+    lines = _json_lines(res.stdout)
+    assert len(lines) == 1, res.stdout[-2000:]  # rank 0 alone prints
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["unit"] == "windows/s" and line["value"] > 0 and line["outputs_finite"] is True
+    # value = windows of ALL ranks / max-over-ranks time
+    assert abs(line["value"] - 2 * 256 * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
+    assert "fp8" not in line["dtype"] and line["roofline"]["frac"] > 0
+
+
+def test_bench_single_rank_line_has_the_contract_keys():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--sustained-s", "0"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-4000:]
+    (line,) = _json_lines(res.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and "workload" in line["config"] and "fp8" not in line["dtype"]
+    # the opt-in reduced-precision rate and the exact-f32 A/B rate are reported BESIDE the headline
+    assert line["fp8_corrections_windows_per_s"] > 0 and line["exact_f32_windows_per_s"] > 0
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9

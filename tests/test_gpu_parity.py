@@ -122,25 +122,23 @@ def test_stage_zpack(runner, cases):
     assert np.abs(z - r32["z"]).max() <= 2e-6  # fp32 rounding of the normalisation + 2^-22 split residue
 
 
-@pytest.mark.parametrize("branch", ["contour", "contour_f16", "note", "onset", "onset_f16"])
-def test_stage_fused_branch(runner, cases, branch, monkeypatch):
+@pytest.mark.parametrize("branch", ["contour", "contour_fp8", "note", "onset", "onset_fp8"])
+def test_stage_fused_branch(runner, cases, branch):
     """The fused split-precision branches (conv -> ReLU -> conv -> sigmoid in one kernel) against the
     oracle's fp32 posteriorgrams, fed with the oracle's own inputs of that branch.
 
-    All products are split-f16 (hi hi + lo hi + hi lo, fp32 accumulate): 5e-6.  The default contour conv1 (folded
-    interior) and onset conv1 issue their two correction products on the block-scaled fp8 matrix instruction (3-bit
-    mantissas on terms that are <= 2^-11 of the product): 2e-5 on the contour map, 5e-5 on the onset map (its 3x3 head
-    sums 288 activations without averaging); `BP_CONV1=f16` / `BP_ONSET=f16` (same kernels, all three products in f16)
-    keep the 5e-6."""
+    Default path: all products are split-f16 (hi hi + lo hi + hi lo, fp32 accumulate): 5e-6.  The opt-in
+    BP_FLAG_FP8_CORRECTIONS mode (`*_fp8`) issues the two correction products of the folded contour conv1 and of the
+    onset conv1 on the block-scaled fp8 matrix instruction (3-bit mantissas on terms that are <= 2^-11 of the product):
+    2e-5 on the contour map, 5e-5 on the onset map (its 3x3 head sums 288 activations without averaging)."""
+    from basic_pitch_amd import Model
     from stage_harness import StageRunner, zp_pack
 
     x, r32, r64 = cases
     n = x.shape[0]
-    tol = {"contour": 2e-5, "onset": 5e-5}.get(branch, 5e-6)
-    if branch.endswith("_f16"):
-        monkeypatch.setenv("BP_CONV1", "f16")
-        monkeypatch.setenv("BP_ONSET", "f16")
-        runner, branch = StageRunner(), branch[:-4]
+    tol = {"contour_fp8": 2e-5, "onset_fp8": 5e-5}.get(branch, 5e-6)
+    if branch.endswith("_fp8"):
+        runner, branch = StageRunner(Model(fp8_corrections=True)), branch[:-4]
     if branch == "note":
         feed = {"contour": r32["contour"]}
     elif branch == "contour":
@@ -187,31 +185,69 @@ def test_fused_contour_kernel_ab(cases, monkeypatch):
         outs[name] = m.predict(x)
         m.close()
     for k in ("note", "onset", "contour"):
-        # the default ("direct") path carries the fp8 corrections of the folded conv1, the fused kernel does not; the
-        # onset map sees the same kernel in both runs
-        assert np.abs(outs["direct"][k] - outs["fused"][k]).max() <= 2e-5, k
+        assert np.abs(outs["direct"][k] - outs["fused"][k]).max() <= 5e-6, k
         assert np.abs(outs["fused"][k][:3] - r64[k][:3]).max() <= 1e-4, k
 
 
-def test_f16_corrections_flag(cases):
-    """BP_FLAG_F16_CORRECTIONS (Model(f16_corrections=True)) keeps the correction products of the contour / onset conv1
-    on the f16 instruction.  Both settings follow the fp64 graph to the contract's 1e-4 on the noise-like windows; the
-    flag's path sits closer to it (the fp8 corrections cost ~1e-5 on the contour map, ~3e-5 on the onset map), and the two
-    differ by no more than that."""
+def test_fp8_corrections_flag(cases):
+    """BP_FLAG_FP8_CORRECTIONS (Model(fp8_corrections=True)) moves the correction products of the contour / onset conv1
+    to the block-scaled fp8 instruction — an opt-in, reduced-precision mode.  On these noise-like windows both settings
+    follow the fp64 graph to 1e-4; the default (all products on f16) sits closer to it (the fp8 corrections cost ~1e-5 on
+    the contour map, ~3e-5 on the onset map), and the two differ by no more than that.  BP_FLAG_F16_CORRECTIONS, the old
+    name of today's default, is accepted, changes nothing, and wins over the fp8 flag."""
     from basic_pitch_amd import Model
 
     x, r32, r64 = cases
     outs = {}
-    for name, flag in (("fp8", False), ("f16", True)):
-        m = Model(max_windows=8, f16_corrections=flag)
+    for name, kw in (("f16", {}), ("fp8", {"fp8_corrections": True}), ("f16_flag", {"f16_corrections": True}),
+                     ("both", {"f16_corrections": True, "fp8_corrections": True})):
+        m = Model(max_windows=8, **kw)
         outs[name] = m.predict(x)
         m.close()
     for k, bound in (("note", 5e-5), ("onset", 6e-5), ("contour", 3e-5)):
+        assert np.array_equal(outs["f16"][k], outs["f16_flag"][k]) and np.array_equal(outs["f16"][k], outs["both"][k]), k
         assert np.abs(outs["fp8"][k] - outs["f16"][k]).max() <= bound, k
         for name in ("fp8", "f16"):
             assert np.abs(outs[name][k][:3] - r64[k][:3]).max() <= 1e-4, (name, k)
+        assert np.abs(outs["f16"][k][:3] - r64[k][:3]).max() <= np.abs(outs["fp8"][k][:3] - r64[k][:3]).max() + 1e-5, k
     # the note map is computed from the contour map: it moves with the contour's fp8 corrections, by less than them
     assert np.abs(outs["fp8"]["contour"] - outs["f16"]["contour"]).max() > 0.0
+
+
+def test_bench_batch_parity(weights):
+    """The benchmark's own input, all of it: the 256 uniform[-1, 1) windows bench.py times (same torch generator, seed
+    1234 + rank 0, drawn on the device) plus 256 normal(0, 0.01) windows, through the DEFAULT path and the fp64 oracle.
+    Every one of the 512 windows inside SURVEY.md 8c's bound max(1e-4, 2 |fp32 oracle - fp64|), and every one inside the
+    plain 1e-4 of the north star (the default arithmetic is all-f16 split products; measured worst 9.7e-5 on this
+    family, profiles/r02_parity_many.md)."""
+    from basic_pitch_amd import Model
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    xb = (torch.rand((256, 43844), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0).contiguous()
+    m = Model(max_windows=256)
+    got_b = {k: v.cpu().numpy() for k, v in m.predict(xb).items()}
+    xn = make_windows("normal", 256, seed=1)
+    got_n = m.predict(xn)
+    m.close()
+    worst = 0.0
+    for name, x, got in (("bench uniform", xb.cpu().numpy(), got_b), ("normal", xn, got_n)):
+        h64 = np.zeros(len(x))
+        o64 = np.zeros(len(x))
+        for i0 in range(0, len(x), 32):  # the oracle in slices: bounded memory, ~1 min for all 512 on the box's host cores
+            sl = slice(i0, i0 + 32)
+            r64 = O.forward(x[sl], weights, np.float64)
+            r32 = O.forward(x[sl], weights, np.float32)
+            for k in ("note", "onset", "contour"):
+                h64[sl] = np.maximum(h64[sl], np.abs(got[k][sl] - r64[k]).max(axis=(1, 2)))
+                o64[sl] = np.maximum(o64[sl], np.abs(r32[k] - r64[k]).max(axis=(1, 2)))
+        print(f"{name}: |hip-fp64| max {h64.max():.2e} median {np.median(h64):.2e}; |fp32 oracle-fp64| max {o64.max():.2e} "
+              f"median {np.median(o64):.2e}; within 1e-4: {(h64 <= 1e-4).sum()}/{len(x)}")
+        assert (h64 <= np.maximum(1e-4, 2.0 * o64)).all(), (name, np.argmax(h64 - np.maximum(1e-4, 2.0 * o64)))
+        assert (h64 <= 1e-4).all(), (name, int((h64 > 1e-4).sum()), float(h64.max()))
+        worst = max(worst, float(h64.max()))
+    assert worst > 0.0
 
 
 def test_bf16_weights_mode(weights, cases):

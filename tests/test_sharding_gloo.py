@@ -221,3 +221,82 @@ def test_predict_and_save_sharded_writes_per_worker(tmp_path):
     # the reference's behaviour without return_exceptions: the first failure propagates (inference.py:603-604)
     with pytest.raises(ValueError):
         predict_and_save_many(paths, one, True, False, False, False, model_or_model_path=FakeModel(0))
+
+
+def dying_factory(device):
+    """A worker whose process ends without a Python exception (what a HIP abort, a segfault or the OOM killer look like
+    from the parent): worker 1 exits hard before it has posted anything."""
+    if device == 1:
+        os._exit(17)
+    return FakeModel(device)
+
+
+class _Unpicklable(FakeModel):
+    def predict_tracks(self, signals):
+        outs = super().predict_tracks(signals)
+        for o in outs:
+            o["device"] = lambda: None  # a result the queue cannot pickle
+        return outs
+
+
+def unpicklable_factory(device):
+    return _Unpicklable(device)
+
+
+def test_sharded_parent_notices_a_worker_that_died_natively(tmp_path):
+    """the parent polled `queue.get()` without a timeout, so a worker that died without posting (or whose
+    result could not be pickled in the queue's feeder thread) hung the job forever.  Both now surface as RuntimeError."""
+    import time
+
+    from basic_pitch_amd import predict_and_save_sharded, predict_many_sharded
+
+    paths = _write_clips(tmp_path, 4)
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="exited with code 17"):
+        predict_many_sharded(paths, gpus=2, model_factory=dying_factory, group=2, decode_threads=1)
+    out = tmp_path / "out"
+    out.mkdir()
+    with pytest.raises(RuntimeError, match="exited with code 17"):
+        predict_and_save_sharded(paths, out, True, False, False, False, gpus=2, model_factory=dying_factory, group=2,
+                                 decode_threads=1)
+    with pytest.raises(RuntimeError, match="worker failed"):
+        predict_many_sharded(paths, gpus=2, model_factory=unpicklable_factory, group=2, decode_threads=1)
+    assert time.time() - t0 < 120
+
+
+def test_predict_and_save_many_is_one_pipeline_and_resolves_duplicate_stems(tmp_path):
+    """`predict_and_save_many` used to call `predict_many` once per group (no read-ahead, no overlap
+    between groups), and two inputs with the same stem could race on the exists-check.  Now it is one pipeline over all
+    files (every group but the first is read while its predecessor computes) and a later input with an already-claimed
+    stem gets the reference's IOError in place — in the single-process job and in the sharded one."""
+    import shutil
+
+    from basic_pitch_amd import predict_and_save_many, predict_and_save_sharded
+
+    paths = _write_clips(tmp_path, 5)
+    other = tmp_path / "elsewhere"
+    other.mkdir()
+    shutil.copy(paths[1], other / "clip_1.wav")  # same stem as paths[1]
+    paths.append(str(other / "clip_1.wav"))
+    calls = []
+
+    class Recording(FakeModel):
+        def predict_tracks(self, signals):
+            calls.append(len(signals))
+            return super().predict_tracks(signals)
+
+    out = tmp_path / "out"
+    out.mkdir()
+    rep = predict_and_save_many(paths, out, True, False, False, True, model_or_model_path=Recording(0), group=2,
+                                decode_threads=2, return_exceptions=True)
+    assert calls == [2, 2, 1]  # 5 unique files in groups of 2 through ONE predict_many call
+    assert isinstance(rep[5], IOError) and "clip_1" in str(rep[5])
+    assert all(r["n_note_events"] > 0 and os.path.exists(r["outputs"]["midi"]) for r in rep[:5])
+    with pytest.raises(IOError):
+        predict_and_save_many(paths, tmp_path / "out2", True, False, False, False, model_or_model_path=FakeModel(0))
+    out3 = tmp_path / "out3"
+    out3.mkdir()
+    rep3 = predict_and_save_sharded(paths, out3, True, False, False, True, gpus=2, model_factory=fake_factory, group=2,
+                                    decode_threads=1)
+    assert isinstance(rep3[5], IOError)
+    assert [r["n_note_events"] for r in rep3[:5]] == [r["n_note_events"] for r in rep[:5]]
