@@ -216,10 +216,19 @@ def test_fp8_corrections_flag(cases):
 
 def test_bench_batch_parity(weights):
     """The benchmark's own input, all of it: the 256 uniform[-1, 1) windows bench.py times (same torch generator, seed
-    1234 + rank 0, drawn on the device) plus 256 normal(0, 0.01) windows, through the DEFAULT path and the fp64 oracle.
-    Every one of the 512 windows inside SURVEY.md 8c's bound max(1e-4, 2 |fp32 oracle - fp64|), and every one inside the
-    plain 1e-4 of the north star (the default arithmetic is all-f16 split products; measured worst 9.7e-5 on this
-    family, profiles/r02_parity_many.md)."""
+    1234 + rank 0, drawn on the device) plus 256 normal(0, 0.01) windows, through the DEFAULT path (all-f16 split
+    products) and the fp64 / fp32 oracles, window by window.
+
+    What holds, and is asserted (profiles/r03_parity_bench_batch.md has the table this test condenses):
+      * normal windows: all 256 within the plain 1e-4 of the north star, and within SURVEY.md 8c's bound;
+      * full-scale white noise: the plain 1e-4 is NOT a property of fp32 evaluations of this graph — on ~2 % of such
+        windows the per-window minimum of the log-power (signal.py:177) sits on a bin deep enough that fp32 rounding in
+        the CQT moves every output of the window by 1e-4 .. 8e-4.  Measured on this batch: torch fp32 oracle 251/256
+        within 1e-4 (max 5.4e-4), C fp32 oracle 250/256 (7.7e-4), the exact-f32 HIP kernels 251/256 (4.0e-4), the default
+        path 252/256 (4.2e-4) — the same few windows for all of them, each evaluation an independent draw there.  So the
+        path is held to the fp32 oracle's own distribution: at least as many windows inside 1e-4 (minus a binomial slack
+        of 3), worst window and 99th percentile within 2x the oracle's, median not above the oracle's, SURVEY 8c's
+        per-window bound max(1e-4, 2 |fp32 oracle - fp64|) on >= 98 % of the windows."""
     from basic_pitch_amd import Model
 
     dev = torch.device("cuda", 0)
@@ -231,23 +240,28 @@ def test_bench_batch_parity(weights):
     xn = make_windows("normal", 256, seed=1)
     got_n = m.predict(xn)
     m.close()
-    worst = 0.0
     for name, x, got in (("bench uniform", xb.cpu().numpy(), got_b), ("normal", xn, got_n)):
         h64 = np.zeros(len(x))
         o64 = np.zeros(len(x))
-        for i0 in range(0, len(x), 32):  # the oracle in slices: bounded memory, ~1 min for all 512 on the box's host cores
+        for i0 in range(0, len(x), 32):  # the oracle in slices: bounded memory, ~1.5 min for all 512 on the box's host cores
             sl = slice(i0, i0 + 32)
             r64 = O.forward(x[sl], weights, np.float64)
             r32 = O.forward(x[sl], weights, np.float32)
             for k in ("note", "onset", "contour"):
                 h64[sl] = np.maximum(h64[sl], np.abs(got[k][sl] - r64[k]).max(axis=(1, 2)))
                 o64[sl] = np.maximum(o64[sl], np.abs(r32[k] - r64[k]).max(axis=(1, 2)))
-        print(f"{name}: |hip-fp64| max {h64.max():.2e} median {np.median(h64):.2e}; |fp32 oracle-fp64| max {o64.max():.2e} "
-              f"median {np.median(o64):.2e}; within 1e-4: {(h64 <= 1e-4).sum()}/{len(x)}")
-        assert (h64 <= np.maximum(1e-4, 2.0 * o64)).all(), (name, np.argmax(h64 - np.maximum(1e-4, 2.0 * o64)))
-        assert (h64 <= 1e-4).all(), (name, int((h64 > 1e-4).sum()), float(h64.max()))
-        worst = max(worst, float(h64.max()))
-    assert worst > 0.0
+        bound = np.maximum(1e-4, 2.0 * o64)
+        print(f"{name}: |hip-fp64| max {h64.max():.2e} p99 {np.quantile(h64, 0.99):.2e} median {np.median(h64):.2e}, within 1e-4 "
+              f"{(h64 <= 1e-4).sum()}/{len(x)}, within max(1e-4, 2 x fp32 oracle) {(h64 <= bound).sum()}/{len(x)}; |fp32 oracle-fp64| "
+              f"max {o64.max():.2e} p99 {np.quantile(o64, 0.99):.2e} median {np.median(o64):.2e}, within 1e-4 {(o64 <= 1e-4).sum()}/{len(x)}")
+        assert np.isfinite(h64).all()
+        assert (h64 <= bound).mean() >= 0.98, (name, int((h64 > bound).sum()))
+        assert (h64 <= 1e-4).sum() >= (o64 <= 1e-4).sum() - 3, name
+        assert h64.max() <= 2.0 * max(o64.max(), 1e-4), (name, float(h64.max()), float(o64.max()))
+        assert np.quantile(h64, 0.99) <= 2.0 * max(np.quantile(o64, 0.99), 1e-4), name
+        assert np.median(h64) <= np.median(o64), name
+        if name == "normal":
+            assert (h64 <= 1e-4).all() and (h64 <= bound).all(), (name, float(h64.max()))
 
 
 def test_bf16_weights_mode(weights, cases):
@@ -363,7 +377,7 @@ def test_end_to_end_synthetic(runner, cases):
     x, r32, r64 = cases
     got = runner.model.predict(x)
     _noise_aware(got, r32, r64)
-    # the headline claim: noise-like inputs (the bench workload) meet 1e-4 outright
+    # these three noise-like windows meet 1e-4 outright (the whole bench batch: test_bench_batch_parity)
     for k in ("note", "onset", "contour"):
         assert np.abs(got[k][:3] - r64[k][:3]).max() <= 1e-4, k
     # reference I/O contract: fresh, writable, C-contiguous float32 (note_creation.py:338-341 mutates)
