@@ -21,6 +21,7 @@ SOURCES = [
     "cqt_pyramid.hip",
     "cqt_filterbank.hip",
     "cqt_mfma.hip",
+    "cqt_planes.hip",
     "conv_contour1.hip",
     "conv_contour.hip",
     "conv_contour_direct.hip",

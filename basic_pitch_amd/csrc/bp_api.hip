@@ -51,6 +51,18 @@ void launch_filterbank_mfma(const float* audio, const float* pyr, const void* bf
 void launch_zpack_partials(const float* lp, const float* scratch, int n_partials, uint32_t* zp, int n_windows,
                            LogConsts kc, int n_bins, hipStream_t stream);
 int filterbank_mfma_partials(bool ext);
+// cqt_planes.hip: the pyramid as pre-split, reflect-padded f16 planes; operands straight from HBM / L2
+int64_t planes_elements_per_window(bool ext);
+void launch_planes_split(const float* src, int64_t src_stride, int level, uint16_t* pl, int n_windows, bool ext,
+                         hipStream_t stream);
+void launch_planes_unsplit(const uint16_t* pl, int level, float* dst, int64_t dst_stride, int n_windows, bool ext,
+                           hipStream_t stream);
+void launch_pyramid_planes(const float* audio, int64_t audio_stride, uint16_t* pl, const void* tfrag, int n_windows,
+                           int n_cu, bool ext, hipStream_t stream);
+int filterbank_planes_partials(bool ext);
+void launch_mm_reduce(const float* scratch, int* mm, int n_windows, int n_partials, hipStream_t stream);
+void launch_filterbank_planes(const uint16_t* pl, const void* bfrag, const float* sqrt_len, float* lp, float* scratch,
+                              int n_windows, LogConsts kc, int n_cu, bool ext, hipStream_t stream);
 void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc, int n_bins,
                   hipStream_t s);
 ResamplePlan make_resample_plan(int source_rate, int target_rate, std::vector<double>& taps);
@@ -189,6 +201,9 @@ struct bp_context {
   bool fused_contour = false;
   bool note_ring = false;  // BP_CONTOUR_PATH=fused: the single-kernel contour branch (A/B comparisons)
   float *d_dec_hfrag = nullptr, *d_fbh_bfrag = nullptr;  // cqt_mfma.hip f16 hi/lo fragments (raw bytes)
+  // cqt_planes.hip (default): decimator / filterbank fragments, the planes of a chunk [cap][2][stride] f16
+  float *d_pl_tfrag = nullptr, *d_pl_bfrag = nullptr, *planes = nullptr;
+  bool cqt_staged = false;  // BP_CQT=staged: the round-2 LDS-staged kernels of cqt_mfma.hip (A/B runs)
   float *d_c1_bfrag = nullptr, *d_c1_bias = nullptr, *d_o1_bfrag = nullptr, *d_o1_bias = nullptr;
   float *d_n1_bfrag = nullptr, *d_n1_bias = nullptr, *d_w_contour2 = nullptr, *d_w_note2 = nullptr,
         *d_w_onset2 = nullptr;
@@ -663,14 +678,16 @@ void pack_branch(int ks1, const Tensor* w1, const Tensor* w2, bool onset, std::v
 
 // cqt_mfma.hip decimator: B[i][u] = h[i - 2u] band, [hi: 9 steps][lo: 9 steps] x 64 lanes x 8 f16;
 // lane (u = lane & 15, kg = lane >> 4), element e: i = 32 s + 8 kg + e.
-void pack_decimator_f16(const Tensor* lowp, std::vector<uint16_t>& out) {
+// `shift` = 1: the transposed decimator of cqt_planes.hip, whose input window starts one sample earlier (an 8-sample
+// aligned element of the padded plane): T[u][i] = h[i - 2u - 1], as the A operand — the same lane / element mapping.
+void pack_decimator_f16(const Tensor* lowp, std::vector<uint16_t>& out, int shift = 0) {
   const size_t lo_base = (size_t)9 * 64 * 8;
   out.assign(2 * lo_base, 0);
   for (int s = 0; s < 9; ++s)
     for (int lane = 0; lane < 64; ++lane)
       for (int e = 0; e < 8; ++e) {
         const int u = lane & 15, kg = lane >> 4;
-        const int j = 32 * s + 8 * kg + e - 2 * u;
+        const int j = 32 * s + 8 * kg + e - 2 * u - shift;
         // taps pre-scaled by 2^10, residuals by a further 2^11 (kDmTapScale / kLoScale in cqt_mfma.hip)
         put_split(out, 0, lo_base, ((size_t)s * 64 + lane) * 8 + e,
                   (j >= 0 && j < 256) ? lowp->data[j] * 1024.0f : 0.f, 2048.0f);
@@ -706,8 +723,31 @@ void pack_filterbank_f16(const Tensor* re, const Tensor* im, std::vector<uint16_
         }
 }
 
+// cqt_planes.hip filterbank: [29 step-fragments][hi|lo][64 lanes][8] f16.  Column groups of 16: 0 = re of filters 0..15,
+// 1 = im 0..15 (7 steps from tap 16), 2 = re 16..31, 3 = im 16..31, 4 = {re 32..35, im 32..35, 8 zero columns} (5 steps
+// from tap 48); lane (n = lane & 15, kg), element e: tap = 16 + 32 s + 8 kg + e of k-step s.
+void pack_filterbank_planes(const Tensor* re, const Tensor* im, std::vector<uint16_t>& out) {
+  out.assign((size_t)29 * 2 * 64 * 8, 0);
+  static const int frag0[5] = {0, 7, 14, 19, 24}, step0[5] = {0, 0, 1, 1, 1}, steps[5] = {7, 7, 5, 5, 5};
+  for (int g = 0; g < 5; ++g)
+    for (int s = 0; s < steps[g]; ++s)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const int n = lane & 15, kg = lane >> 4;
+          const int tap = 16 + 32 * (step0[g] + s) + 8 * kg + e;
+          float v = 0.f;
+          if (g < 4) {
+            v = ((g & 1) ? im : re)->data[((g >> 1) * 16 + n) * 256 + tap];
+          } else if (n < 8) {
+            v = (n < 4 ? re : im)->data[(32 + (n & 3)) * 256 + tap];
+          }
+          const size_t base = ((size_t)(frag0[g] + s) * 2) * 64 * 8;
+          put_split(out, base, base + 64 * 8, (size_t)lane * 8 + e, v * 4096.0f, 2048.0f);
+        }
+}
+
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wrim, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_cb_wfrag, h->d_cb_wf32, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->planes, h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wrim, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_cb_wfrag, h->d_cb_wf32, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->fb_scratch, h->pcm_dev, h->mono_dev, h->res_dev, reinterpret_cast<float*>(h->taps_dev)};
@@ -768,12 +808,18 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
     launch_filterbank(audio_dev, h->pyr, h->d_fb_bfrag, h->d_sqrt_len, h->lp, h->mm, h->fb_scratch, n, h->kc,
                       h->n_cu, s);
     BP_MARK(BP_STAGE_FILTERBANK);
-  } else {
+  } else if (h->cqt_staged) {
     launch_pyramid_mfma(audio_dev, h->pyr, h->d_dec_hfrag, n, h->ext, s);
     BP_MARK(BP_STAGE_PYRAMID);
     // the per-window extrema are folded from the partials inside zpack (one launch and one boundary fewer)
     launch_filterbank_mfma(audio_dev, h->pyr, h->d_fbh_bfrag, h->d_sqrt_len, h->lp, nullptr, h->fb_scratch, n,
                            h->kc, h->n_cu, h->ext, s);
+    BP_MARK(BP_STAGE_FILTERBANK);
+  } else {
+    uint16_t* pl = reinterpret_cast<uint16_t*>(h->planes);
+    launch_pyramid_planes(audio_dev, h->win_len, pl, h->d_pl_tfrag, n, h->n_cu, h->ext, s);
+    BP_MARK(BP_STAGE_PYRAMID);
+    launch_filterbank_planes(pl, h->d_pl_bfrag, h->d_sqrt_len, h->lp, h->fb_scratch, n, h->kc, h->n_cu, h->ext, s);
     BP_MARK(BP_STAGE_FILTERBANK);
   }
   if (h->flags & BP_FLAG_F32_MFMA) {
@@ -790,8 +836,9 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
     launch_onset2(note_dev, h->o1, h->d_w_onset2, h->b_onset2, onset_dev, n, s);
     BP_MARK(BP_STAGE_ONSET2);
   } else {
-    launch_zpack_partials(h->lp, h->fb_scratch, filterbank_mfma_partials(h->ext), reinterpret_cast<uint32_t*>(h->zp), n,
-                          h->kc, h->n_bins, s);
+    launch_zpack_partials(h->lp, h->fb_scratch,
+                          h->cqt_staged ? filterbank_mfma_partials(h->ext) : filterbank_planes_partials(h->ext),
+                          reinterpret_cast<uint32_t*>(h->zp), n, h->kc, h->n_bins, s);
     BP_MARK(BP_STAGE_ZPACK);
     if (h->fused_contour) {
       BP_DOM_BEGIN();
@@ -992,6 +1039,14 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     if ((rc = upload(h, raw_of(frag), &h->d_dec_hfrag))) return fail(rc);
     pack_filterbank_f16(re, im, frag);
     if ((rc = upload(h, raw_of(frag), &h->d_fbh_bfrag))) return fail(rc);
+    pack_decimator_f16(lowp, frag, 1);
+    if ((rc = upload(h, raw_of(frag), &h->d_pl_tfrag))) return fail(rc);
+    pack_filterbank_planes(re, im, frag);
+    if ((rc = upload(h, raw_of(frag), &h->d_pl_bfrag))) return fail(rc);
+    {
+      const char* ec = std::getenv("BP_CQT");
+      h->cqt_staged = ec && std::strcmp(ec, "staged") == 0;
+    }
     pack_contour_branch(c1w, c2w, frag);
     std::vector<float> cb32(9, 0.f);
     for (int i = 0; i < 8; ++i) cb32[i] = c1b->data[i];
@@ -1101,6 +1156,17 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     hipError_t e = hipMemset(h->c1s, 0, (size_t)cap * kC1Win * sizeof(float));  // pad bins stay zero
     if (e != hipSuccess) {
       h->err = std::string("hipMemset(c1s) failed: ") + hipGetErrorString(e);
+      return fail(BP_ERR_HIP);
+    }
+  }
+  if (!(h->flags & BP_FLAG_F32_MFMA)) {
+    // f16 planes of a chunk; zeroed once: the slack behind a level's reflect padding is read (and discarded or masked)
+    // but never written, and has to stay finite
+    const int64_t pl_floats = (cap * planes_elements_per_window(h->ext) + 1) / 2;
+    if ((rc = alloc(h, &h->planes, pl_floats))) return fail(rc);
+    hipError_t e = hipMemset(h->planes, 0, (size_t)pl_floats * sizeof(float));
+    if (e != hipSuccess) {
+      h->err = std::string("hipMemset(planes) failed: ") + hipGetErrorString(e);
       return fail(BP_ERR_HIP);
     }
   }
@@ -1573,10 +1639,23 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
   switch (stage) {
     case BP_STAGE_PYRAMID:
       if ((ok = need(bf->audio) && need(bf->pyr))) {
-        if (h->flags & BP_FLAG_F32_MFMA)
+        if (h->flags & BP_FLAG_F32_MFMA) {
           launch_pyramid(bf->audio, bf->pyr, h->d_lowpass, n, s);
-        else
+        } else if (h->cqt_staged) {
           launch_pyramid_mfma(bf->audio, bf->pyr, h->d_dec_hfrag, n, h->ext, s);
+        } else {  // the planes pyramid, its levels converted to the fp32 rows the test compares
+          if (n > h->cap) {
+            h->err = "bp_run_stage: pyramid needs n_windows <= max_windows (internal planes buffer)";
+            return BP_ERR_INVALID_ARG;
+          }
+          uint16_t* pl = reinterpret_cast<uint16_t*>(h->planes);
+          launch_pyramid_planes(bf->audio, h->win_len, pl, h->d_pl_tfrag, n, h->n_cu, h->ext, s);
+          const int n_lev = h->ext ? kOctavesExt : kOctaves;
+          for (int k = 1; k < n_lev; ++k) {
+            const int64_t off = h->ext ? ((k == 1) ? 0 : kAudioN + pyr_off(k - 1)) : pyr_off(k);
+            launch_planes_unsplit(pl, k, bf->pyr + off, h->pyr_stride, n, h->ext, s);
+          }
+        }
       }
       break;
     case BP_STAGE_FILTERBANK:
@@ -1586,9 +1665,24 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
         if (h->flags & BP_FLAG_F32_MFMA)
           launch_filterbank(bf->audio, bf->pyr, h->d_fb_bfrag, h->d_sqrt_len, bf->lp, bf->mm, h->fb_scratch, n,
                             h->kc, h->n_cu, s);
-        else
+        else if (h->cqt_staged)
           launch_filterbank_mfma(bf->audio, bf->pyr, h->d_fbh_bfrag, h->d_sqrt_len, bf->lp, bf->mm,
                                  h->fb_scratch, n, h->kc, h->n_cu, h->ext, s);
+        else {  // the given fp32 levels split into planes (test hook), then the planes filterbank
+          if (n > h->cap) {
+            h->err = "bp_run_stage: filterbank needs n_windows <= max_windows (internal planes buffer)";
+            return BP_ERR_INVALID_ARG;
+          }
+          uint16_t* pl = reinterpret_cast<uint16_t*>(h->planes);
+          launch_planes_split(bf->audio, h->win_len, 0, pl, n, h->ext, s);
+          const int n_lev = h->ext ? kOctavesExt : kOctaves;
+          for (int k = 1; k < n_lev; ++k) {
+            const int64_t off = h->ext ? ((k == 1) ? 0 : kAudioN + pyr_off(k - 1)) : pyr_off(k);
+            launch_planes_split(bf->pyr + off, h->pyr_stride, k, pl, n, h->ext, s);
+          }
+          launch_filterbank_planes(pl, h->d_pl_bfrag, h->d_sqrt_len, bf->lp, h->fb_scratch, n, h->kc, h->n_cu, h->ext, s);
+          launch_mm_reduce(h->fb_scratch, bf->mm, n, filterbank_planes_partials(h->ext), s);
+        }
       }
       break;
     case BP_STAGE_CONTOUR1:

@@ -1,0 +1,658 @@
+// CQT front end, round 3: the pyramid lives in HBM as PRE-SPLIT, REFLECT-PADDED f16 planes and the matrix operands of
+// both kernels come straight from those planes — no LDS staging, no workgroup barriers, every wave an independent
+// worker.  Same operators and reference lines as cqt_mfma.hip (which this file supersedes on the default path):
+//   basic_pitch/layers/nnaudio.py:259-284, 636-638   downsampling_by_n: zero-pad 127, 256-tap FIR, stride 2
+//   basic_pitch/layers/nnaudio.py:216-256, 640-661   get_cqt_complex per level, * sqrt(lengths), magnitude
+//   basic_pitch/layers/nnaudio.py:300-301            ReflectionPad1D(128)
+//   basic_pitch/layers/signal.py:171-178             power, 10*log10(power + 1e-10), per-example min / max
+//
+// Why.  The staged kernels were paced by their instruction count: per (window, level, 16-frame tile) the
+// four role waves of a workgroup spent ~1570 wave-instructions around 84 matrix instructions — every sample split into
+// f16 hi + lo again in front of every use (2.3 times on average: once for the decimator, ~1.25 times for the
+// filterbank's overlapping tiles), an exchange of the re / im planes through LDS, three workgroup barriers.  Here
+//   * a sample is split ONCE, where it is produced (level 0: pl_split_kernel; level k >= 1: the decimator's epilogue),
+//     and stored as two f16 planes (hi, lo * 2^11) — the same 4 bytes per sample as fp32;
+//   * a level's region carries its own reflect padding (128 samples either side, nnaudio.py:300-301), written by the
+//     tile that computes the mirrored samples, so a filterbank A fragment — 8 consecutive samples of a frame's 256-tap
+//     window — is ONE aligned 16-byte global load per lane (L1 / L2 absorb the Hankel overlap), for every frame;
+//   * one wave owns a whole (window, level, tile): all five 16-column groups of the 72 filter columns, re and im of a
+//     filter in the SAME lane, so the magnitude / log epilogue runs in registers: no exchange, no barrier.  The filter
+//     fragments (58 KB) are the only LDS tenants (read-only, one copy per CU);
+//   * the decimator runs transposed (filter = A operand, signal = B operand): a lane ends up with 4 CONSECUTIVE
+//     outputs, i.e. one 8-byte store per plane.  The reference zero-pads where the filterbank reflects: the two edge
+//     tiles of a level mask their fragments, all others run unmasked.
+//
+// Arithmetic is unchanged: x = hi + lo 2^-11 (rn), products hi*hi + (lo*hi + hi*lo) 2^-11 on v_mfma_f32_16x16x32_f16,
+// fp32 accumulation, taps pre-scaled by 2^10 (decimator) / 2^12 (CQT kernels) — see cqt_mfma.hip's header.
+#include <type_traits>
+
+#include "bp_common.h"
+
+namespace bp {
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+constexpr float kPlDmTapUnscale = 1.0f / 1024.0f;
+constexpr float kPlFmTapUnscale = 1.0f / 4096.0f;
+constexpr int kPlPad = 128;        // reflect padding in front of a level's samples (a multiple of 8: units stay aligned)
+constexpr int kPlTileOut = 256;    // decimator outputs per tile (16 row-blocks x 16)
+constexpr int kPlDmSteps = 9;
+constexpr int kPlTilesPerLevel = (kFrames + 15) / 16;  // 11 filterbank tiles of 16 frames
+
+// Geometry of a window's planes.  Element = one f16; a window owns 2 * stride elements: hi plane, then lo plane.  Level
+// k's samples live at [off[k] + kPlPad, off[k] + kPlPad + len[k]); regions are multiples of 64 elements (128 bytes).
+struct PlGeo {
+  int n_levels, hop0, n_bins;
+  int len[10];
+  int off[10];
+  int rlen[10];
+  int64_t stride;
+};
+
+PlGeo make_pl_geo(bool ext) {
+  PlGeo g{};
+  g.n_levels = ext ? kOctavesExt : kOctaves;
+  g.hop0 = ext ? 512 : 256;
+  g.n_bins = ext ? kBinsExt : kBins;
+  int64_t off = 0;
+  for (int k = 0; k < g.n_levels; ++k) {
+    g.len[k] = ext ? (k == 0 ? kAudioNExt : level_len(k - 1)) : level_len(k);
+    // readers: the next level's decimator up to len + 767 past the region start + pad; the filterbank's padding frames
+    // (172..175 of the 11th tile) up to 176 hop + 256
+    const int hop = g.hop0 >> k;
+    int need = kPlPad + g.len[k] + 776;
+    if (need < 176 * hop + 256) need = 176 * hop + 256;
+    g.rlen[k] = (need + 63) & ~63;
+    g.off[k] = (int)off;
+    off += g.rlen[k];
+  }
+  g.stride = off;
+  return g;
+}
+
+int64_t planes_elements_per_window(bool ext) { return 2 * make_pl_geo(ext).stride; }
+
+#define BP_PL_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0)
+
+// value of lane + 4 of the same 16-lane row (DPP row_shl:4; lanes 12..15 of a row read 0)
+__device__ __forceinline__ float pl_from_lane_plus4(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ uint4 pl_load16(const uint16_t* p) {
+  uint4 v;
+  __builtin_memcpy(&v, p, 16);  // alignment as the pointer has it (2 bytes for the hop-1 level): the compiler picks
+  return v;
+}
+
+// ================================================================================================
+// fp32 signal -> planes of one level (level 0 in production; any level for the per-stage test hook)
+__global__ __launch_bounds__(256) void pl_split_kernel(const float* __restrict__ src, int64_t src_stride, int L,
+                                                       uint16_t* __restrict__ pl, int64_t stride, int off, int rlen) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (8 * q >= rlen) return;
+  const float* x = src + (int64_t)blockIdx.y * src_stride;
+  uint16_t* hi = pl + (int64_t)blockIdx.y * 2 * stride + off + 8 * q;
+  const int g0 = 8 * q - kPlPad;
+  float v[8];
+  if (g0 >= 0 && g0 + 8 <= L) {
+    const float4 a = *reinterpret_cast<const float4*>(x + g0);  // dword alignment is enough for global vector loads
+    const float4 c = *reinterpret_cast<const float4*>(x + g0 + 4);
+    v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = c.x, v[5] = c.y, v[6] = c.z, v[7] = c.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int g = g0 + e;
+      g = g < 0 ? -g : g;                    // nnaudio.py:300-301: reflection without repeating the edge sample
+      g = g >= L ? 2 * (L - 1) - g : g;
+      const bool ok = g >= 0 && g < L;       // beyond one reflection: slack nobody's result depends on
+      v[e] = ok ? x[ok ? g : 0] : 0.0f;
+    }
+  }
+  uint4 h, l;
+  split_f16x2_rn(f32x2{v[0], v[1]}, h.x, l.x);
+  split_f16x2_rn(f32x2{v[2], v[3]}, h.y, l.y);
+  split_f16x2_rn(f32x2{v[4], v[5]}, h.z, l.z);
+  split_f16x2_rn(f32x2{v[6], v[7]}, h.w, l.w);
+  *reinterpret_cast<uint4*>(hi) = h;
+  *reinterpret_cast<uint4*>(hi + stride) = l;
+}
+
+// planes -> fp32 (test hook: the pyramid stage's levels as the oracle lays them out)
+__global__ __launch_bounds__(256) void pl_unsplit_kernel(const uint16_t* __restrict__ pl, int64_t stride, int off, int L,
+                                                         float* __restrict__ dst, int64_t dst_stride) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= L) return;
+  const uint16_t* hi = pl + (int64_t)blockIdx.y * 2 * stride + off + kPlPad + i;
+  const float h = (float)__builtin_bit_cast(_Float16, hi[0]);
+  const float l = (float)__builtin_bit_cast(_Float16, hi[stride]);
+  dst[(int64_t)blockIdx.y * dst_stride + i] = h + l * kLoUnscale;
+}
+
+// ================================================================================================
+// decimate by 2: one wave per tile of 256 outputs
+//   D[u][m] = sum_i T[u][i] X[i][m],  T[u][i] = h[i - 2u - 1] (A operand, packed on the host),  X[i][m] = element
+//   2 o0 + 32 m + i of the input region (B operand): output n = o0 + 16 m + u reads samples 2n + j - 127, i.e. region
+//   elements kPlPad + 2n + j - 127 = 2 o0 + 32 m + (2u + j + 1).
+// Row rho of a tile = the 32 elements from 2 o0 + 32 rho; the fragment of lane (m, kg) at k-step s is row m + s, unit kg:
+// 24 rows serve all 9 steps.  Re-loading the fragment every step would pull the tile through the texture path 9 times
+// (18 KB per tile, and a chain of dependent latencies); instead the 24 rows are fetched ONCE — lane (m, kg) row m, lanes
+// m >= 8 also row m + 8 —, parked in a wave-private LDS image, and the fragments are ds_read_b128 from there.
+constexpr int kPlRowU = 5;                      // 16-byte units per row in LDS (4 + 1 of skew)
+constexpr int kPlRowsU = 2 * 24 * kPlRowU;      // hi rows, then lo rows: 240 units = 3840 bytes per wave
+
+__device__ __forceinline__ uint4 pl_zero_outside(uint4 v, int idx, int L_in) {
+  // keep elements whose sample index idx + e - kPlPad lies in [0, L_in): the reference zero-pads the decimator's input
+  int nv = kPlPad + L_in - idx;  // elements [0, nv) of this unit are real samples ...
+  nv = idx < kPlPad ? 0 : nv;    // ... unless the whole unit lies in front of the signal (kPlPad is a multiple of 8)
+  v.x &= (nv > 0 ? 0xffffu : 0u) | (nv > 1 ? 0xffff0000u : 0u);
+  v.y &= (nv > 2 ? 0xffffu : 0u) | (nv > 3 ? 0xffff0000u : 0u);
+  v.z &= (nv > 4 ? 0xffffu : 0u) | (nv > 5 ? 0xffff0000u : 0u);
+  v.w &= (nv > 6 ? 0xffffu : 0u) | (nv > 7 ? 0xffff0000u : 0u);
+  return v;
+}
+
+// One value split like split_f16x2_rn (hi and lo rounded to nearest), for the few scalar pad writes.
+__device__ __forceinline__ void pl_split1(float v, uint16_t& h, uint16_t& l) {
+  uint32_t h2, l2;
+  split_f16x2_rn(f32x2{v, 0.0f}, h2, l2);
+  h = (uint16_t)(h2 & 0xffffu);
+  l = (uint16_t)(l2 & 0xffffu);
+}
+
+__device__ __forceinline__ bool pl_tile_is_edge(int tile, int L_in) {
+  return tile == 0 || 2 * kPlTileOut * tile + 32 * 23 + 32 > kPlPad + L_in;  // some fragment reaches outside the signal
+}
+
+// What a lane fetches for a tile: its row m, and (lanes m >= 8) row m + 8.  F32IN: 8 fp32 samples per row (the level-0
+// signal itself, zero outside [0, L): nnaudio.py:269-279); else 8 f16 hi + 8 f16 lo from the input level's planes.
+template <bool F32IN>
+struct PlRaw;
+template <>
+struct PlRaw<true> {
+  float4 a0, a1, b0, b1;
+};
+template <>
+struct PlRaw<false> {
+  uint4 ah, al, bh, bl;
+};
+
+template <bool F32IN>
+__device__ __forceinline__ PlRaw<F32IN> pl_fetch_rows(const float* __restrict__ x, const uint16_t* __restrict__ in_hi,
+                                                       int64_t stride, int L_in, int tile, int lane) {
+  const int m = lane & 15, kg = lane >> 4;
+  const int base = 2 * kPlTileOut * tile + 32 * m + 8 * kg;
+  PlRaw<F32IN> r;
+  if constexpr (F32IN) {
+    auto row = [&](int g0, float4& lo4, float4& hi4) {
+      if (!pl_tile_is_edge(tile, L_in)) {
+        lo4 = *reinterpret_cast<const float4*>(x + g0);  // dword alignment is enough for global vector loads
+        hi4 = *reinterpret_cast<const float4*>(x + g0 + 4);
+      } else {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int g = g0 + e;
+          const bool ok = g >= 0 && g < L_in;
+          v[e] = ok ? x[ok ? g : 0] : 0.0f;
+        }
+        lo4 = float4{v[0], v[1], v[2], v[3]};
+        hi4 = float4{v[4], v[5], v[6], v[7]};
+      }
+    };
+    row(base - kPlPad, r.a0, r.a1);
+    r.b0 = r.b1 = float4{0.f, 0.f, 0.f, 0.f};
+    if (m >= 8) row(base - kPlPad + 256, r.b0, r.b1);
+  } else {
+    r.ah = *reinterpret_cast<const uint4*>(in_hi + base);
+    r.al = *reinterpret_cast<const uint4*>(in_hi + stride + base);
+    r.bh = r.bl = uint4{0u, 0u, 0u, 0u};
+    if (m >= 8) {
+      r.bh = *reinterpret_cast<const uint4*>(in_hi + base + 256);
+      r.bl = *reinterpret_cast<const uint4*>(in_hi + stride + base + 256);
+    }
+  }
+  return r;
+}
+
+__device__ __forceinline__ void pl_split8(const float4& a, const float4& c, uint4& h, uint4& l) {
+  split_f16x2_rn(f32x2{a.x, a.y}, h.x, l.x);
+  split_f16x2_rn(f32x2{a.z, a.w}, h.y, l.y);
+  split_f16x2_rn(f32x2{c.x, c.y}, h.z, l.z);
+  split_f16x2_rn(f32x2{c.z, c.w}, h.w, l.w);
+}
+
+// F32IN = false: the input level is a plane region (`in_hi`, lo plane `stride` elements behind it).
+// F32IN = true:  the input is the fp32 signal `x` (level 0): rows are split in registers, and the tile also WRITES the
+//                level-0 planes (`in_hi` is then the level-0 region to fill): its sixteen own rows are exactly the 512
+//                elements [2 o0, 2 o0 + 512); tile 0 / the last tile add the reflect padding of level 0.
+template <bool F32IN>
+__device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, const float* __restrict__ x,
+                                            uint16_t* __restrict__ in_hi, int64_t stride, int L_in,
+                                            uint16_t* __restrict__ out_hi, int L_out, int tile, int n_tiles,
+                                            const uint4 (&th)[kPlDmSteps], const uint4* __restrict__ tlo,
+                                            uint4* __restrict__ rows, int lane) {
+  // keep the lo fragments in LDS: without an opaque offset the compiler hoists the 9 item-invariant reads into registers
+  asm volatile("" : "+v"(lane));
+  const int m = lane & 15, kg = lane >> 4;
+  const int o0 = kPlTileOut * tile;
+  const int base = 2 * o0 + 32 * m + 8 * kg;  // region element of this lane's own row
+  uint4 ah, al, bh, bl;
+  if constexpr (F32IN) {
+    pl_split8(raw.a0, raw.a1, ah, al);
+    pl_split8(raw.b0, raw.b1, bh, bl);
+  } else {
+    ah = raw.ah, al = raw.al, bh = raw.bh, bl = raw.bl;
+    if (pl_tile_is_edge(tile, L_in)) {  // the planes carry reflect padding where the decimator wants zeros
+      ah = pl_zero_outside(ah, base, L_in);
+      al = pl_zero_outside(al, base, L_in);
+      bh = pl_zero_outside(bh, base + 256, L_in);
+      bl = pl_zero_outside(bl, base + 256, L_in);
+    }
+  }
+  uint4* rh = rows + m * kPlRowU + kg;
+  uint4* rl = rh + 24 * kPlRowU;
+  rh[0] = ah;
+  rl[0] = al;
+  if (m >= 8) {
+    rh[8 * kPlRowU] = bh;
+    rl[8 * kPlRowU] = bl;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  if constexpr (F32IN) {
+    // level-0 planes: this lane's own row is 8 of the 512 elements [2 o0, 2 o0 + 512) the tile owns
+    const bool partial = tile == 0 || 2 * o0 + 512 > kPlPad + L_in;  // some of them lie outside the signal (padding)
+    uint16_t* w0 = in_hi + base;
+    if (!partial) {
+      *reinterpret_cast<uint4*>(w0) = ah;
+      *reinterpret_cast<uint4*>(w0 + stride) = al;
+    } else {
+      const uint32_t hw[4] = {ah.x, ah.y, ah.z, ah.w}, lw[4] = {al.x, al.y, al.z, al.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int g = base + e - kPlPad;
+        if (g >= 0 && g < L_in) {
+          w0[e] = (uint16_t)(hw[e >> 1] >> (16 * (e & 1)));
+          w0[stride + e] = (uint16_t)(lw[e >> 1] >> (16 * (e & 1)));
+        }
+      }
+    }
+    // reflect padding of level 0 (nnaudio.py:300-301): 128 elements either side, mirrored from the signal itself
+    if (tile == 0 || tile == n_tiles - 1) {
+      for (int side = 0; side < 2; ++side) {
+        if ((side == 0 && tile != 0) || (side == 1 && tile != n_tiles - 1)) continue;
+        for (int j = (lane & 63) + 1; j <= kPlPad; j += 64) {
+          const int g = side == 0 ? j : L_in - 1 - j;                     // mirrored sample
+          const int q = side == 0 ? kPlPad - j : kPlPad + L_in - 1 + j;    // element it lands on
+          if (g >= 0 && g < L_in) {
+            uint16_t h1, l1;
+            pl_split1(x[g], h1, l1);
+            in_hi[q] = h1;
+            in_hi[stride + q] = l1;
+          }
+        }
+      }
+    }
+  }
+
+  f32x4 hh = {0.f, 0.f, 0.f, 0.f}, xx = hh;
+  const uint4* tl = tlo + lane;
+#pragma unroll
+  for (int s = 0; s < kPlDmSteps; ++s) {
+    const uint4 xh = rh[s * kPlRowU], xl = rl[s * kPlRowU];
+    const uint4 tls = tl[s * 64];
+    hh = BP_PL_MFMA16(th[s], xh, hh);
+    xx = BP_PL_MFMA16(tls, xh, xx);
+    xx = BP_PL_MFMA16(th[s], xl, xx);
+  }
+  // the rows are read: the next tile of this wave may overwrite them
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // D: column m = lane & 15, rows u = 4 kg + r: four consecutive outputs
+  const int n0 = o0 + 16 * m + 4 * kg;
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = (hh[r] + xx[r] * kLoUnscale) * kPlDmTapUnscale;
+  uint2 h2, l2;
+  split_f16x2_rn(f32x2{v[0], v[1]}, h2.x, l2.x);
+  split_f16x2_rn(f32x2{v[2], v[3]}, h2.y, l2.y);
+  uint16_t* oh = out_hi + kPlPad + n0;
+  if (n0 + 3 < L_out) {
+    *reinterpret_cast<uint2*>(oh) = h2;
+    *reinterpret_cast<uint2*>(oh + stride) = l2;
+  }
+  // the level's last (partial) group of four, and the reflect padding: the tiles that hold samples 1..128 and
+  // L-129..L-2 write their mirror images (nnaudio.py:300-301).  Wave-uniform conditions, 16-bit stores.
+  const bool tail = o0 + kPlTileOut > L_out - 130 || tile == 0;
+  if (tail) {
+    const uint16_t eh[4] = {(uint16_t)(h2.x & 0xffffu), (uint16_t)(h2.x >> 16), (uint16_t)(h2.y & 0xffffu), (uint16_t)(h2.y >> 16)};
+    const uint16_t el[4] = {(uint16_t)(l2.x & 0xffffu), (uint16_t)(l2.x >> 16), (uint16_t)(l2.y & 0xffffu), (uint16_t)(l2.y >> 16)};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + r;
+      if (n >= L_out) continue;
+      if (n0 + 3 >= L_out) {
+        oh[r] = eh[r];
+        oh[stride + r] = el[r];
+      }
+      if (n >= 1 && n <= kPlPad) {
+        out_hi[kPlPad - n] = eh[r];
+        out_hi[stride + kPlPad - n] = el[r];
+      }
+      if (n <= L_out - 2 && n >= L_out - 1 - kPlPad) {
+        const int q = kPlPad + 2 * (L_out - 1) - n;
+        out_hi[q] = eh[r];
+        out_hi[stride + q] = el[r];
+      }
+    }
+  }
+}
+
+// The filter's hi fragments live in registers (36 VGPRs), its lo fragments in LDS (9 KB, one ds_read_b128 per k-step):
+// with all 18 in registers the kernels would hold 3 waves per SIMD instead of 4.
+__device__ __forceinline__ void pl_load_tfrag(const uint4* __restrict__ tfrag, uint4 (&th)[kPlDmSteps], uint4* tlo) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int s = 0; s < kPlDmSteps; ++s) th[s] = tfrag[s * 64 + lane];
+  for (int i = threadIdx.x; i < kPlDmSteps * 64; i += blockDim.x) tlo[i] = tfrag[kPlDmSteps * 64 + i];
+  __syncthreads();
+}
+
+// One level of every window.  F32IN: level 0 -> 1 from the fp32 audio (splits the signal once, writes the level-0 planes
+// with their reflect padding and the level-1 planes); else planes -> planes.  Waves walk (window, tile) items, the rows
+// of the next item are fetched before the matrix work of the current one; no workgroup barrier after the fragments are in.
+template <bool F32IN>
+__global__ __launch_bounds__(256, 4) void pl_decimate_kernel(const float* __restrict__ audio, int64_t audio_stride,
+                                                             uint16_t* __restrict__ pl, int64_t stride, int off_in, int L_in,
+                                                             int off_out, int L_out, int tiles,
+                                                             const uint4* __restrict__ tfrag, int n_windows) {
+  __shared__ __attribute__((aligned(16))) uint4 tlo[kPlDmSteps * 64];
+  __shared__ __attribute__((aligned(16))) uint4 rows_all[4 * kPlRowsU];
+  uint4 th[kPlDmSteps];
+  pl_load_tfrag(tfrag, th, tlo);
+  const int lane = threadIdx.x & 63;
+  uint4* rows = rows_all + wave_id() * kPlRowsU;
+  const int n_items = n_windows * tiles;
+  const int n_waves = gridDim.x * 4;
+  int item = blockIdx.x * 4 + wave_id();
+  if (item >= n_items) return;
+  int b = item / tiles, tile = item - b * tiles;
+  PlRaw<F32IN> raw = pl_fetch_rows<F32IN>(audio + (int64_t)b * audio_stride, pl + (int64_t)b * 2 * stride + off_in, stride,
+                                          L_in, tile, lane);
+  for (;;) {
+    const int nitem = item + n_waves;
+    const bool more = nitem < n_items;
+    const int nb = more ? nitem / tiles : b, ntile = more ? nitem - nb * tiles : tile;
+    const PlRaw<F32IN> nraw = pl_fetch_rows<F32IN>(audio + (int64_t)nb * audio_stride,
+                                                   pl + (int64_t)nb * 2 * stride + off_in, stride, L_in, ntile, lane);
+    uint16_t* w = pl + (int64_t)b * 2 * stride;
+    pl_dec_tile<F32IN>(raw, audio + (int64_t)b * audio_stride, w + off_in, stride, L_in, w + off_out, L_out, tile, tiles, th,
+                       tlo, rows, lane);
+    if (!more) break;
+    raw = nraw, item = nitem, b = nb, tile = ntile;
+  }
+}
+
+// The deeper levels of one window, one workgroup of 16 waves: a level is a few dozen tiles at most and depends on the one
+// above it, so as separate launches each would pay a launch boundary and a ramp for a few microseconds of work.  A level
+// written by this workgroup is read by this workgroup after a barrier (global memory, workgroup scope: same CU, same L1).
+struct PlTail {
+  int first, last;
+};
+constexpr int kPlTailThreads = 1024;
+
+__global__ __launch_bounds__(kPlTailThreads) void pl_decimate_tail_kernel(uint16_t* __restrict__ pl, PlGeo g, PlTail t,
+                                                                       const uint4* __restrict__ tfrag) {
+  __shared__ __attribute__((aligned(16))) uint4 tlo[kPlDmSteps * 64];
+  __shared__ __attribute__((aligned(16))) uint4 rows_all[(kPlTailThreads / 64) * kPlRowsU];
+  uint4 th[kPlDmSteps];
+  pl_load_tfrag(tfrag, th, tlo);
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  uint4* rows = rows_all + wave * kPlRowsU;
+  uint16_t* w = pl + (int64_t)blockIdx.x * 2 * g.stride;
+  for (int k = t.first; k <= t.last; ++k) {
+    const int tiles = (g.len[k] + kPlTileOut - 1) / kPlTileOut;
+    for (int tile = wave; tile < tiles; tile += kPlTailThreads / 64) {
+      const PlRaw<false> raw = pl_fetch_rows<false>(nullptr, w + g.off[k - 1], g.stride, g.len[k - 1], tile, lane);
+      pl_dec_tile<false>(raw, nullptr, w + g.off[k - 1], g.stride, g.len[k - 1], w + g.off[k], g.len[k], tile, tiles, th, tlo,
+                         rows, lane);
+    }
+    __syncthreads();  // release / acquire at workgroup scope: level k is visible to every wave of this workgroup
+  }
+}
+
+// ================================================================================================
+// filterbank: one wave per (window, level, 16-frame tile), all 72 filter columns, epilogue in registers
+//   column groups (16 columns each): 0 = re of filters 0..15, 1 = im 0..15 (taps 16..239: k-steps 0..6),
+//   2 = re 16..31, 3 = im 16..31, 4 = {re 32..35 | im 32..35 | 8 zero columns} (taps 48..207: k-steps 1..5)
+constexpr int kPlFbThreads = 1024;
+constexpr int kPlFbFrags = 7 + 7 + 5 + 5 + 5;  // step-fragments, hi and lo each
+__host__ __device__ constexpr int pl_fb_frag0(int g) { return g == 0 ? 0 : g == 1 ? 7 : g == 2 ? 14 : g == 3 ? 19 : 24; }
+__host__ __device__ constexpr int pl_fb_step0(int g) { return g < 2 ? 0 : 1; }
+__host__ __device__ constexpr int pl_fb_steps(int g) { return g < 2 ? 7 : 5; }
+
+__global__ __launch_bounds__(kPlFbThreads) void cqt_filterbank_planes_kernel(
+    const uint16_t* __restrict__ pl, const uint4* __restrict__ bfrag, const float* __restrict__ sqrt_len,
+    float* __restrict__ lp, float2* __restrict__ mmp, int n_windows, LogConsts kc, PlGeo g) {
+  __shared__ __attribute__((aligned(16))) uint4 bfr[kPlFbFrags * 2 * 64];
+  for (int i = threadIdx.x; i < kPlFbFrags * 2 * 64; i += kPlFbThreads) bfr[i] = bfrag[i];
+  __syncthreads();
+  int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  const int per_window = g.n_levels * kPlTilesPerLevel;
+  const int n_tasks = n_windows * per_window;
+  const float kln2 = 0.69314718055994531f * kc.s0 * kc.s1;  // log2 -> 10 log10
+  // (window, level, tile) of a task, advanced by the grid stride without a division by the runtime per_window
+  struct Pos {
+    int b, rem;
+  };
+  auto advance = [&](Pos p, int db, int drem) {
+    p.b += db, p.rem += drem;
+    if (p.rem >= per_window) p.rem -= per_window, ++p.b;
+    return p;
+  };
+  // address of a task's first A fragment for this lane (hi plane; the lo plane is g.stride elements behind it)
+  auto frag0 = [&](Pos p) -> const uint16_t* {
+    const int level_ = (p.rem * 745) >> 13;  // rem / 11 for rem < 2700
+    const int tile_ = p.rem - level_ * kPlTilesPerLevel;
+    return pl + (int64_t)p.b * 2 * g.stride + g.off[level_] + (16 * tile_ + (lane & 15)) * (g.hop0 >> level_) + 16 +
+           8 * (lane >> 4);
+  };
+  static_assert(kPlTilesPerLevel == 11, "the multiply-shift above divides by 11");
+  constexpr int kPf = 3;  // k-steps of A fragments in flight
+  const int task_stride = gridDim.x * (kPlFbThreads / 64);
+  const int db = task_stride / per_window, drem = task_stride - db * per_window;
+  int task = blockIdx.x * (kPlFbThreads / 64) + wave;
+  if (task >= n_tasks) return;
+  Pos pos{task / per_window, 0};
+  pos.rem = task - pos.b * per_window;
+  // the first kPf steps of the NEXT task are fetched before the matrix work of the current one: a level-0 / level-1
+  // task streams its samples from HBM, and that latency would otherwise open every task
+  uint4 nh[kPf], nl[kPf];
+  {
+    const uint16_t* p0 = frag0(pos);
+#pragma unroll
+    for (int s = 0; s < kPf; ++s) {
+      nh[s] = pl_load16(p0 + 32 * s);
+      nl[s] = pl_load16(p0 + g.stride + 32 * s);
+    }
+  }
+  for (;; task += task_stride) {
+    // keep the filter fragments in LDS: without an opaque offset the compiler hoists all 58 loop-invariant reads
+    asm volatile("" : "+v"(lane));
+    const int b = pos.b, rem = pos.rem;
+    const int level = (rem * 745) >> 13, tile = rem - level * kPlTilesPerLevel;
+    const int t = lane & 15, kg = lane >> 4;
+    const uint16_t* ph = frag0(pos);
+    const uint16_t* pq = ph + g.stride;
+    const uint4* bl = bfr + lane;
+    const bool more = task + task_stride < n_tasks;
+    const Pos npos = more ? advance(pos, db, drem) : pos;
+
+    f32x4 hh[5], xx[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) hh[q] = xx[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 ah[7], al[7];
+#pragma unroll
+    for (int s = 0; s < kPf; ++s) ah[s] = nh[s], al[s] = nl[s];
+#pragma unroll
+    for (int s = kPf; s < 7; ++s) {
+      ah[s] = pl_load16(ph + 32 * s);
+      al[s] = pl_load16(pq + 32 * s);
+    }
+    {
+      const uint16_t* p1 = frag0(npos);
+#pragma unroll
+      for (int s = 0; s < kPf; ++s) {
+        nh[s] = pl_load16(p1 + 32 * s);
+        nl[s] = pl_load16(p1 + g.stride + 32 * s);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        if (s < pl_fb_step0(q) || s >= pl_fb_step0(q) + pl_fb_steps(q)) continue;
+        const int f = pl_fb_frag0(q) + s - pl_fb_step0(q);
+        const uint4 bh = bl[(2 * f) * 64], bw = bl[(2 * f + 1) * 64];
+        hh[q] = BP_PL_MFMA16(ah[s], bh, hh[q]);
+        xx[q] = BP_PL_MFMA16(al[s], bh, xx[q]);
+        xx[q] = BP_PL_MFMA16(ah[s], bw, xx[q]);
+      }
+    }
+
+    // epilogue: D row (frame) = 4 kg + r, column (filter of the group) = lane & 15
+    const int bin0 = (g.n_levels - 1 - level) * kBpo - 15;  // nnaudio.py:640-642
+    float* lp_t = lp + ((int64_t)b * kFrames + 16 * tile + 4 * kg) * g.n_bins + bin0;
+    const int fr0 = 16 * tile + 4 * kg;
+    float vmin = __int_as_float(0x7f800000), vmax = -__int_as_float(0x7f800000);
+    // `masked` (wave-uniform): the tile has padding frames (the 11th tile) or the level has bins below the CQT's first
+    // (the deepest level): 8 of 10 tasks have neither, and then only group 4's unused columns need a predicate
+    const bool masked = tile == kPlTilesPerLevel - 1 || bin0 < 0;
+    auto finish = [&](auto masked_c, const f32x4& hr, const f32x4& xr, const f32x4& hi_, const f32x4& xi, int k, bool col_ok) {
+      constexpr bool kMasked = decltype(masked_c)::value;
+      const bool bin_ok = col_ok && (!kMasked || bin0 + k >= 0);
+      // * sqrt(lengths) (nnaudio.py:650, before squaring) and the taps' 2^-12 in one factor: a power of two commutes
+      // with the rounding of the product
+      const float slk = sqrt_len[bin_ok ? bin0 + k : 0] * kPlFmTapUnscale;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float re = __fmul_rn(hr[r] + xr[r] * kLoUnscale, slk);
+        const float im = __fmul_rn(hi_[r] + xi[r] * kLoUnscale, slk);
+        // nnaudio.py:661 magnitude, signal.py:174-175 power and 10 log10 on the hardware's 1-ulp sqrt / log2
+        const float mag = __builtin_amdgcn_sqrtf(__fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)));
+        const float pw = __fmul_rn(mag, mag);
+        v[r] = __fmul_rn(__builtin_amdgcn_logf(__fadd_rn(pw, kc.eps)), kln2);
+      }
+      if constexpr (kMasked) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (bin_ok && fr0 + r < kFrames) {
+            lp_t[r * g.n_bins + k] = v[r];
+            vmin = fminf(vmin, v[r]);
+            vmax = fmaxf(vmax, v[r]);
+          }
+      } else if (bin_ok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          lp_t[r * g.n_bins + k] = v[r];
+          vmin = fminf(vmin, v[r]);
+          vmax = fmaxf(vmax, v[r]);
+        }
+      }
+    };
+    // group 4: re of filter 32 + c in column c, im in column 4 + c: bring the im values over (row_shl:4)
+    // (one call per element: written as a loop over r, hipcc 7.2 emits the DPP move for r = 0 only and reuses it)
+    const f32x4 hi4 = {pl_from_lane_plus4(hh[4][0]), pl_from_lane_plus4(hh[4][1]), pl_from_lane_plus4(hh[4][2]),
+                       pl_from_lane_plus4(hh[4][3])};
+    const f32x4 xi4 = {pl_from_lane_plus4(xx[4][0]), pl_from_lane_plus4(xx[4][1]), pl_from_lane_plus4(xx[4][2]),
+                       pl_from_lane_plus4(xx[4][3])};
+    if (masked) {
+      finish(std::true_type{}, hh[0], xx[0], hh[1], xx[1], t, true);
+      finish(std::true_type{}, hh[2], xx[2], hh[3], xx[3], 16 + t, true);
+      finish(std::true_type{}, hh[4], xx[4], hi4, xi4, 32 + (t & 3), t < 4);
+    } else {
+      finish(std::false_type{}, hh[0], xx[0], hh[1], xx[1], t, true);
+      finish(std::false_type{}, hh[2], xx[2], hh[3], xx[3], 16 + t, true);
+      finish(std::false_type{}, hh[4], xx[4], hi4, xi4, 32 + (t & 3), t < 4);
+    }
+    vmin = wave_min_lane63(vmin);
+    vmax = wave_max_lane63(vmax);
+    if ((threadIdx.x & 63) == 63) mmp[(int64_t)b * per_window + rem] = make_float2(vmin, vmax);
+    if (!more) break;
+    pos = npos;
+  }
+}
+
+// ================================================================================================
+// host side
+static int pl_resident_waves(int n_cu) { return n_cu * 16; }
+
+void launch_planes_split(const float* src, int64_t src_stride, int level, uint16_t* pl, int n_windows, bool ext,
+                         hipStream_t stream) {
+  const PlGeo g = make_pl_geo(ext);
+  const int units = g.rlen[level] / 8;
+  hipLaunchKernelGGL(pl_split_kernel, dim3((units + 255) / 256, n_windows), dim3(256), 0, stream, src, src_stride,
+                     g.len[level], pl, g.stride, g.off[level], g.rlen[level]);
+}
+
+void launch_planes_unsplit(const uint16_t* pl, int level, float* dst, int64_t dst_stride, int n_windows, bool ext,
+                           hipStream_t stream) {
+  const PlGeo g = make_pl_geo(ext);
+  hipLaunchKernelGGL(pl_unsplit_kernel, dim3((g.len[level] + 255) / 256, n_windows), dim3(256), 0, stream, pl, g.stride,
+                     g.off[level], g.len[level], dst, dst_stride);
+}
+
+// levels 0 (planes) and 1 .. n-1 from the fp32 audio: one wide launch for level 0 -> 1, then the rest per window
+void launch_pyramid_planes(const float* audio, int64_t audio_stride, uint16_t* pl, const void* tfrag, int n_windows, int n_cu,
+                           bool ext, hipStream_t stream) {
+  const PlGeo g = make_pl_geo(ext);
+  const uint4* tf = static_cast<const uint4*>(tfrag);
+  {
+    // tiles: enough for the level-1 outputs AND for the level-0 elements the tiles write (512 each, pad included)
+    int tiles = (g.len[1] + kPlTileOut - 1) / kPlTileOut;
+    const int cover = (kPlPad + g.len[0] + 2 * kPlTileOut - 1) / (2 * kPlTileOut);
+    if (tiles < cover) tiles = cover;
+    const int items = tiles * n_windows;
+    int grid = (items + 3) / 4;
+    if (grid > pl_resident_waves(n_cu) / 4) grid = pl_resident_waves(n_cu) / 4;
+    hipLaunchKernelGGL(pl_decimate_kernel<true>, dim3(grid), dim3(256), 0, stream, audio, audio_stride, pl, g.stride, g.off[0],
+                       g.len[0], g.off[1], g.len[1], tiles, tf, n_windows);
+  }
+  // with fewer windows than CUs the per-window kernel would leave most of the chip idle on the long levels: those run wide
+  int first_tail = 2;
+  if (n_windows < n_cu / 2)
+    for (; first_tail < g.n_levels && g.len[first_tail] > 16 * kPlTileOut; ++first_tail) {
+      const int k = first_tail;
+      const int tiles = (g.len[k] + kPlTileOut - 1) / kPlTileOut;
+      const int items = tiles * n_windows;
+      int grid = (items + 3) / 4;
+      if (grid > pl_resident_waves(n_cu) / 4) grid = pl_resident_waves(n_cu) / 4;
+      hipLaunchKernelGGL(pl_decimate_kernel<false>, dim3(grid), dim3(256), 0, stream, (const float*)nullptr, (int64_t)0, pl,
+                         g.stride, g.off[k - 1], g.len[k - 1], g.off[k], g.len[k], tiles, tf, n_windows);
+    }
+  if (first_tail < g.n_levels)
+    hipLaunchKernelGGL(pl_decimate_tail_kernel, dim3(n_windows), dim3(kPlTailThreads), 0, stream, pl, g,
+                       PlTail{first_tail, g.n_levels - 1}, tf);
+}
+
+int filterbank_planes_partials(bool ext) { return make_pl_geo(ext).n_levels * kPlTilesPerLevel; }
+
+void launch_filterbank_planes(const uint16_t* pl, const void* bfrag, const float* sqrt_len, float* lp, float* scratch,
+                              int n_windows, LogConsts kc, int n_cu, bool ext, hipStream_t stream) {
+  const PlGeo g = make_pl_geo(ext);
+  const int tasks = n_windows * g.n_levels * kPlTilesPerLevel;
+  int grid = (tasks + 15) / 16;
+  if (grid > n_cu) grid = n_cu;
+  hipLaunchKernelGGL(cqt_filterbank_planes_kernel, dim3(grid), dim3(kPlFbThreads), 0, stream, pl,
+                     static_cast<const uint4*>(bfrag), sqrt_len, lp, reinterpret_cast<float2*>(scratch), n_windows, kc, g);
+}
+
+}  // namespace bp
