@@ -24,6 +24,7 @@
 //
 // Arithmetic is unchanged: x = hi + lo 2^-11 (rn), products hi*hi + (lo*hi + hi*lo) 2^-11 on v_mfma_f32_16x16x32_f16,
 // fp32 accumulation, taps pre-scaled by 2^10 (decimator) / 2^12 (CQT kernels) — see cqt_mfma.hip's header.
+#include <cstdlib>
 #include <type_traits>
 
 #include "bp_common.h"
@@ -378,15 +379,26 @@ __global__ __launch_bounds__(256, 4) void pl_decimate_kernel(const float* __rest
   const int lane = threadIdx.x & 63;
   uint4* rows = rows_all + wave_id() * kPlRowsU;
   const int n_items = n_windows * tiles;
-  const int n_waves = gridDim.x * 4;
-  int item = blockIdx.x * 4 + wave_id();
-  if (item >= n_items) return;
+  // items of this workgroup: blockIdx.x + gridDim.x * j, drawn from a counter in LDS (the older waves of a workgroup win
+  // the issue arbitration and would otherwise run out of work long before the younger ones: see the filterbank below)
+  __shared__ int s_next;
+  if (threadIdx.x == 0) s_next = 0;
+  __syncthreads();
+  auto grab = [&]() -> int {
+    int j = 0;
+    if ((threadIdx.x & 63) == 0) j = atomicAdd(&s_next, 1);
+    const int it = blockIdx.x + gridDim.x * __builtin_amdgcn_readfirstlane(j);
+    return it < n_items ? it : -1;
+  };
+  int item = grab();
+  if (item < 0) return;
+  int nitem = grab();
   int b = item / tiles, tile = item - b * tiles;
   PlRaw<F32IN> raw = pl_fetch_rows<F32IN>(audio + (int64_t)b * audio_stride, pl + (int64_t)b * 2 * stride + off_in, stride,
                                           L_in, tile, lane);
   for (;;) {
-    const int nitem = item + n_waves;
-    const bool more = nitem < n_items;
+    const bool more = nitem >= 0;
+    const int nnitem = more ? grab() : -1;
     const int nb = more ? nitem / tiles : b, ntile = more ? nitem - nb * tiles : tile;
     const PlRaw<F32IN> nraw = pl_fetch_rows<F32IN>(audio + (int64_t)nb * audio_stride,
                                                    pl + (int64_t)nb * 2 * stride + off_in, stride, L_in, ntile, lane);
@@ -394,7 +406,7 @@ __global__ __launch_bounds__(256, 4) void pl_decimate_kernel(const float* __rest
     pl_dec_tile<F32IN>(raw, audio + (int64_t)b * audio_stride, w + off_in, stride, L_in, w + off_out, L_out, tile, tiles, th,
                        tlo, rows, lane);
     if (!more) break;
-    raw = nraw, item = nitem, b = nb, tile = ntile;
+    raw = nraw, item = nitem, b = nb, tile = ntile, nitem = nnitem;
   }
 }
 
@@ -431,102 +443,154 @@ __global__ __launch_bounds__(kPlTailThreads) void pl_decimate_tail_kernel(uint16
 // filterbank: one wave per (window, level, 16-frame tile), all 72 filter columns, epilogue in registers
 //   column groups (16 columns each): 0 = re of filters 0..15, 1 = im 0..15 (taps 16..239: k-steps 0..6),
 //   2 = re 16..31, 3 = im 16..31, 4 = {re 32..35 | im 32..35 | 8 zero columns} (taps 48..207: k-steps 1..5)
-constexpr int kPlFbThreads = 1024;
 constexpr int kPlFbFrags = 7 + 7 + 5 + 5 + 5;  // step-fragments, hi and lo each
 __host__ __device__ constexpr int pl_fb_frag0(int g) { return g == 0 ? 0 : g == 1 ? 7 : g == 2 ? 14 : g == 3 ? 19 : 24; }
 __host__ __device__ constexpr int pl_fb_step0(int g) { return g < 2 ? 0 : 1; }
 __host__ __device__ constexpr int pl_fb_steps(int g) { return g < 2 ? 7 : 5; }
+// the 29 (k-step, group) products of a task in issue order: k-step major, so an A fragment is finished with after its step
+struct PlFbItem {
+  int s, q, f;  // k-step, column group, index of the group's step-fragment in LDS
+};
+__host__ __device__ constexpr PlFbItem pl_fb_item(int i) {
+  int n = 0;
+  for (int s = 0; s < 7; ++s)
+    for (int q = 0; q < 5; ++q) {
+      if (s < pl_fb_step0(q) || s >= pl_fb_step0(q) + pl_fb_steps(q)) continue;
+      if (n == i) return PlFbItem{s, q, pl_fb_frag0(q) + s - pl_fb_step0(q)};
+      ++n;
+    }
+  return PlFbItem{-1, -1, -1};
+}
+static_assert(pl_fb_item(kPlFbFrags - 1).s == 6 && pl_fb_item(kPlFbFrags).s == -1, "29 products per task");
 
-__global__ __launch_bounds__(kPlFbThreads) void cqt_filterbank_planes_kernel(
+// THREADS / APF: 1024 threads = 4 waves per SIMD (128 VGPRs each) keep three k-steps of A fragments ahead (the default:
+// 54 us at B = 256); 768 / 704 threads = 3 waves per SIMD with up to 168 VGPRs hold the whole next task's fragments in
+// flight (56 registers) — measured the same 55 us: once the waves draw their tasks from a queue the kernel is paced by
+// instruction issue (matrix pipe 41 % busy, VALU most of the rest), not by memory latency.
+template <int THREADS, int APF>
+__global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
     const uint16_t* __restrict__ pl, const uint4* __restrict__ bfrag, const float* __restrict__ sqrt_len,
-    float* __restrict__ lp, float2* __restrict__ mmp, int n_windows, LogConsts kc, PlGeo g) {
+    float* __restrict__ lp, float2* __restrict__ mmp, int n_windows, LogConsts kc, PlGeo g, unsigned per_window_magic) {
   __shared__ __attribute__((aligned(16))) uint4 bfr[kPlFbFrags * 2 * 64];
-  for (int i = threadIdx.x; i < kPlFbFrags * 2 * 64; i += kPlFbThreads) bfr[i] = bfrag[i];
+  // sqrt(lengths) and the level offsets from LDS, not from global / constant memory: a wave's memory counters are in
+  // order, so a global load in the epilogue would wait for every A fragment prefetched for the next task before it
+  __shared__ float s_sqrt_len[kBinsExt];
+  __shared__ int s_off[10];
+  __shared__ int s_next;
+#if defined(PL_FB_PROF)
+  const unsigned long long pentry = __builtin_amdgcn_s_memtime();
+#endif
+  if (threadIdx.x == 0) s_next = 0;
+  for (int i = threadIdx.x; i < kPlFbFrags * 2 * 64; i += THREADS) bfr[i] = bfrag[i];
+  for (int i = threadIdx.x; i < g.n_bins; i += THREADS) s_sqrt_len[i] = sqrt_len[i];
+  if (threadIdx.x < 10) s_off[threadIdx.x] = g.off[threadIdx.x];
   __syncthreads();
   int lane = threadIdx.x & 63;
-  const int wave = wave_id();
   const int per_window = g.n_levels * kPlTilesPerLevel;
   const int n_tasks = n_windows * per_window;
   const float kln2 = 0.69314718055994531f * kc.s0 * kc.s1;  // log2 -> 10 log10
-  // (window, level, tile) of a task, advanced by the grid stride without a division by the runtime per_window
+  // Tasks of this workgroup: blockIdx.x + gridDim.x * j, j = 0, 1, ...; its waves DRAW j from a counter in LDS instead of
+  // owning a fixed share: the SIMD's issue arbitration favours the older waves of a workgroup (phase clocks: wave 0
+  // finishes a task in 7.5 k cycles, wave 10 in 19.5 k), so with fixed shares the old waves ran out of work at 40 % of
+  // the kernel's duration and the young ones finished it alone.
   struct Pos {
     int b, rem;
   };
-  auto advance = [&](Pos p, int db, int drem) {
-    p.b += db, p.rem += drem;
-    if (p.rem >= per_window) p.rem -= per_window, ++p.b;
-    return p;
+  auto grab = [&]() -> int {
+    int j = 0;
+    if ((threadIdx.x & 63) == 0) j = atomicAdd(&s_next, 1);
+    const int task_ = blockIdx.x + gridDim.x * __builtin_amdgcn_readfirstlane(j);
+    return task_ < n_tasks ? task_ : -1;
+  };
+  auto pos_of = [&](int task_) {  // task / per_window by multiply-shift (exact below 2^32 / 95 for 99, 2^32 / 4 for 110)
+    const int b_ = (int)__umulhi((unsigned)task_, per_window_magic);
+    return Pos{b_, task_ - b_ * per_window};
   };
   // address of a task's first A fragment for this lane (hi plane; the lo plane is g.stride elements behind it)
   auto frag0 = [&](Pos p) -> const uint16_t* {
     const int level_ = (p.rem * 745) >> 13;  // rem / 11 for rem < 2700
     const int tile_ = p.rem - level_ * kPlTilesPerLevel;
-    return pl + (int64_t)p.b * 2 * g.stride + g.off[level_] + (16 * tile_ + (lane & 15)) * (g.hop0 >> level_) + 16 +
+    return pl + (int64_t)p.b * 2 * g.stride + s_off[level_] + (16 * tile_ + (lane & 15)) * (g.hop0 >> level_) + 16 +
            8 * (lane >> 4);
   };
   static_assert(kPlTilesPerLevel == 11, "the multiply-shift above divides by 11");
-  constexpr int kPf = 3;  // k-steps of A fragments in flight
-  const int task_stride = gridDim.x * (kPlFbThreads / 64);
-  const int db = task_stride / per_window, drem = task_stride - db * per_window;
-  int task = blockIdx.x * (kPlFbThreads / 64) + wave;
-  if (task >= n_tasks) return;
-  Pos pos{task / per_window, 0};
-  pos.rem = task - pos.b * per_window;
-  // the first kPf steps of the NEXT task are fetched before the matrix work of the current one: a level-0 / level-1
-  // task streams its samples from HBM, and that latency would otherwise open every task
-  uint4 nh[kPf], nl[kPf];
+  int task = grab();
+  if (task < 0) return;
+  int ntask = grab();
+  Pos pos = pos_of(task);
+  // A fragments: a ring of 7 k-steps.  When a task starts, its first APF steps are in the ring (fetched during the task
+  // before); step s + APF is fetched when step s has been consumed — for s + APF >= 7 that is step s + APF - 7 of the NEXT
+  // task.  APF = 7: every load has a whole task's matrix work to land (a level-0 / level-1 task streams from HBM).
+  uint4 ah[7], al[7];
   {
     const uint16_t* p0 = frag0(pos);
 #pragma unroll
-    for (int s = 0; s < kPf; ++s) {
-      nh[s] = pl_load16(p0 + 32 * s);
-      nl[s] = pl_load16(p0 + g.stride + 32 * s);
+    for (int s = 0; s < APF; ++s) {
+      ah[s] = pl_load16(p0 + 32 * s);
+      al[s] = pl_load16(p0 + g.stride + 32 * s);
     }
   }
-  for (;; task += task_stride) {
+#if defined(PL_FB_PROF)
+  unsigned long long pk = 0, pe = 0, pn_ = 0, pstart = __builtin_amdgcn_s_memtime();
+#endif
+  for (;;) {
+#if defined(PL_FB_PROF)
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#endif
     // keep the filter fragments in LDS: without an opaque offset the compiler hoists all 58 loop-invariant reads
     asm volatile("" : "+v"(lane));
+    const int nntask = ntask >= 0 ? grab() : -1;  // drawn a task ahead: its LDS round trip is nobody's critical path
     const int b = pos.b, rem = pos.rem;
     const int level = (rem * 745) >> 13, tile = rem - level * kPlTilesPerLevel;
     const int t = lane & 15, kg = lane >> 4;
     const uint16_t* ph = frag0(pos);
-    const uint16_t* pq = ph + g.stride;
     const uint4* bl = bfr + lane;
-    const bool more = task + task_stride < n_tasks;
-    const Pos npos = more ? advance(pos, db, drem) : pos;
+    const bool more = ntask >= 0;
+    const Pos npos = more ? pos_of(ntask) : pos;
+    const uint16_t* pn = frag0(npos);
 
     f32x4 hh[5], xx[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q) hh[q] = xx[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint4 ah[7], al[7];
+    // filter fragments two products ahead of the matrix instructions that use them: issued right behind a product's
+    // instructions, an LDS read's ~100 cycles would be exposed 29 times per task (they were: the compiler's own order)
+    constexpr int kBPf = 2;
+    uint4 bh[kPlFbFrags], bw[kPlFbFrags];
 #pragma unroll
-    for (int s = 0; s < kPf; ++s) ah[s] = nh[s], al[s] = nl[s];
-#pragma unroll
-    for (int s = kPf; s < 7; ++s) {
-      ah[s] = pl_load16(ph + 32 * s);
-      al[s] = pl_load16(pq + 32 * s);
-    }
-    {
-      const uint16_t* p1 = frag0(npos);
-#pragma unroll
-      for (int s = 0; s < kPf; ++s) {
-        nh[s] = pl_load16(p1 + 32 * s);
-        nl[s] = pl_load16(p1 + g.stride + 32 * s);
-      }
+    for (int i = 0; i < kBPf; ++i) {
+      bh[i] = bl[(2 * pl_fb_item(i).f) * 64];
+      bw[i] = bl[(2 * pl_fb_item(i).f + 1) * 64];
     }
 #pragma unroll
-    for (int s = 0; s < 7; ++s) {
-#pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        if (s < pl_fb_step0(q) || s >= pl_fb_step0(q) + pl_fb_steps(q)) continue;
-        const int f = pl_fb_frag0(q) + s - pl_fb_step0(q);
-        const uint4 bh = bl[(2 * f) * 64], bw = bl[(2 * f + 1) * 64];
-        hh[q] = BP_PL_MFMA16(ah[s], bh, hh[q]);
-        xx[q] = BP_PL_MFMA16(al[s], bh, xx[q]);
-        xx[q] = BP_PL_MFMA16(ah[s], bw, xx[q]);
+    for (int i = 0; i < kPlFbFrags; ++i) {
+      constexpr auto item = [](int j) { return pl_fb_item(j); };
+      const int s = item(i).s, q = item(i).q;
+      if (i + kBPf < kPlFbFrags) {
+        bh[i + kBPf] = bl[(2 * item(i + kBPf).f) * 64];
+        bw[i + kBPf] = bl[(2 * item(i + kBPf).f + 1) * 64];
       }
+      __builtin_amdgcn_sched_barrier(0);
+      hh[q] = BP_PL_MFMA16(ah[s], bh[i], hh[q]);
+      xx[q] = BP_PL_MFMA16(al[s], bh[i], xx[q]);
+      xx[q] = BP_PL_MFMA16(ah[s], bw[i], xx[q]);
+      if (i + 1 == kPlFbFrags || item(i + 1).s != s) {  // last product of k-step s: its ring slot takes step s + APF
+        const int sn = s + APF;
+        if (sn < 7) {
+          ah[sn] = pl_load16(ph + 32 * sn);
+          al[sn] = pl_load16(ph + g.stride + 32 * sn);
+        } else {
+          ah[sn - 7] = pl_load16(pn + 32 * (sn - 7));
+          al[sn - 7] = pl_load16(pn + g.stride + 32 * (sn - 7));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
 
+#if defined(PL_FB_PROF)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(hh[0]), "+v"(xx[4]));
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+#endif
     // epilogue: D row (frame) = 4 kg + r, column (filter of the group) = lane & 15
     const int bin0 = (g.n_levels - 1 - level) * kBpo - 15;  // nnaudio.py:640-642
     float* lp_t = lp + ((int64_t)b * kFrames + 16 * tile + 4 * kg) * g.n_bins + bin0;
@@ -540,7 +604,7 @@ __global__ __launch_bounds__(kPlFbThreads) void cqt_filterbank_planes_kernel(
       const bool bin_ok = col_ok && (!kMasked || bin0 + k >= 0);
       // * sqrt(lengths) (nnaudio.py:650, before squaring) and the taps' 2^-12 in one factor: a power of two commutes
       // with the rounding of the product
-      const float slk = sqrt_len[bin_ok ? bin0 + k : 0] * kPlFmTapUnscale;
+      const float slk = s_sqrt_len[bin_ok ? bin0 + k : 0] * kPlFmTapUnscale;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -586,9 +650,22 @@ __global__ __launch_bounds__(kPlFbThreads) void cqt_filterbank_planes_kernel(
     vmin = wave_min_lane63(vmin);
     vmax = wave_max_lane63(vmax);
     if ((threadIdx.x & 63) == 63) mmp[(int64_t)b * per_window + rem] = make_float2(vmin, vmax);
+#if defined(PL_FB_PROF)
+    {
+      const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+      pk += c1 - c0, pe += c2 - c1, ++pn_;
+    }
+#endif
     if (!more) break;
-    pos = npos;
+    pos = npos, task = ntask, ntask = nntask;
   }
+#if defined(PL_FB_PROF)
+  if ((threadIdx.x & 63) == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && (wave_id() == 0 || wave_id() == 5 || wave_id() == 10))
+    printf("fbprof block %d wave %d: tasks %llu, K-loop %llu cycles/task, epilogue %llu, whole loop %llu, prologue %llu, entry at %llu\n",
+           blockIdx.x, wave_id(), pn_, pk / pn_, pe / pn_, (unsigned long long)(__builtin_amdgcn_s_memtime() - pstart),
+           (unsigned long long)(pstart - pentry), pentry);
+  (void)task;
+#endif
 }
 
 // ================================================================================================
@@ -647,12 +724,33 @@ int filterbank_planes_partials(bool ext) { return make_pl_geo(ext).n_levels * kP
 
 void launch_filterbank_planes(const uint16_t* pl, const void* bfrag, const float* sqrt_len, float* lp, float* scratch,
                               int n_windows, LogConsts kc, int n_cu, bool ext, hipStream_t stream) {
-  const PlGeo g = make_pl_geo(ext);
+  PlGeo g = make_pl_geo(ext);
+  if (const char* e = getenv("BP_FB_ONLY_LEVEL")) {  // tools only (timing of one level's tasks; results are garbage)
+    const int k = atoi(e);
+    g.hop0 >>= k, g.off[0] = g.off[k], g.len[0] = g.len[k], g.n_levels = 1;
+  }
   const int tasks = n_windows * g.n_levels * kPlTilesPerLevel;
-  int grid = (tasks + 15) / 16;
-  if (grid > n_cu) grid = n_cu;
-  hipLaunchKernelGGL(cqt_filterbank_planes_kernel, dim3(grid), dim3(kPlFbThreads), 0, stream, pl,
-                     static_cast<const uint4*>(bfrag), sqrt_len, lp, reinterpret_cast<float2*>(scratch), n_windows, kc, g);
+  static const int variant = [] {  // BP_FB_WAVES=16 / 12 / 11: waves per workgroup (A/B runs); default 16
+    const char* e = getenv("BP_FB_WAVES");
+    return e ? atoi(e) : 16;
+  }();
+  const uint4* bf = static_cast<const uint4*>(bfrag);
+  float2* mm = reinterpret_cast<float2*>(scratch);
+  const unsigned per_window = (unsigned)(g.n_levels * kPlTilesPerLevel);
+  const unsigned magic = (unsigned)((0x100000000ull + per_window - 1) / per_window);
+  auto grid_for = [&](int waves) {
+    const int grid = (tasks + waves - 1) / waves;
+    return grid > n_cu ? n_cu : grid;
+  };
+  if (variant == 16)
+    hipLaunchKernelGGL((cqt_filterbank_planes_kernel<1024, 3>), dim3(grid_for(16)), dim3(1024), 0, stream, pl, bf, sqrt_len, lp,
+                       mm, n_windows, kc, g, magic);
+  else if (variant == 11)
+    hipLaunchKernelGGL((cqt_filterbank_planes_kernel<704, 7>), dim3(grid_for(11)), dim3(704), 0, stream, pl, bf, sqrt_len, lp,
+                       mm, n_windows, kc, g, magic);
+  else
+    hipLaunchKernelGGL((cqt_filterbank_planes_kernel<768, 7>), dim3(grid_for(12)), dim3(768), 0, stream, pl, bf, sqrt_len, lp,
+                       mm, n_windows, kc, g, magic);
 }
 
 }  // namespace bp
