@@ -61,8 +61,8 @@ void launch_pyramid_planes(const float* audio, int64_t audio_stride, uint16_t* p
                            int n_cu, bool ext, hipStream_t stream);
 int filterbank_planes_partials(bool ext);
 void launch_mm_reduce(const float* scratch, int* mm, int n_windows, int n_partials, hipStream_t stream);
-void launch_filterbank_planes(const uint16_t* pl, const void* bfrag, const float* sqrt_len, float* lp, float* scratch,
-                              int n_windows, LogConsts kc, int n_cu, bool ext, hipStream_t stream);
+bool launch_filterbank_planes(const uint16_t* pl, const void* bfrag, const float* sqrt_len, float* lp, float* scratch,
+                              uint32_t* zp, int n_windows, LogConsts kc, int n_cu, bool ext, hipStream_t stream);
 void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc, int n_bins,
                   hipStream_t s);
 ResamplePlan make_resample_plan(int source_rate, int target_rate, std::vector<double>& taps);
@@ -802,6 +802,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
       BP_HIP(hipEventRecord(ev[++e], s));          \
     }                                              \
   } while (0)
+  bool zp_done = false;
   if (h->flags & BP_FLAG_F32_MFMA) {
     launch_pyramid(audio_dev, h->pyr, h->d_lowpass, n, s);
     BP_MARK(BP_STAGE_PYRAMID);
@@ -819,7 +820,9 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
     uint16_t* pl = reinterpret_cast<uint16_t*>(h->planes);
     launch_pyramid_planes(audio_dev, h->win_len, pl, h->d_pl_tfrag, n, h->n_cu, h->ext, s);
     BP_MARK(BP_STAGE_PYRAMID);
-    launch_filterbank_planes(pl, h->d_pl_bfrag, h->d_sqrt_len, h->lp, h->fb_scratch, n, h->kc, h->n_cu, h->ext, s);
+    // with at least half a window per CU the kernel also normalises / BatchNorms / splits its windows (`zp` complete)
+    zp_done = launch_filterbank_planes(pl, h->d_pl_bfrag, h->d_sqrt_len, h->lp, h->fb_scratch,
+                                       reinterpret_cast<uint32_t*>(h->zp), n, h->kc, h->n_cu, h->ext, s);
     BP_MARK(BP_STAGE_FILTERBANK);
   }
   if (h->flags & BP_FLAG_F32_MFMA) {
@@ -836,10 +839,12 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
     launch_onset2(note_dev, h->o1, h->d_w_onset2, h->b_onset2, onset_dev, n, s);
     BP_MARK(BP_STAGE_ONSET2);
   } else {
-    launch_zpack_partials(h->lp, h->fb_scratch,
-                          h->cqt_staged ? filterbank_mfma_partials(h->ext) : filterbank_planes_partials(h->ext),
-                          reinterpret_cast<uint32_t*>(h->zp), n, h->kc, h->n_bins, s);
-    BP_MARK(BP_STAGE_ZPACK);
+    if (!zp_done) {
+      launch_zpack_partials(h->lp, h->fb_scratch,
+                            h->cqt_staged ? filterbank_mfma_partials(h->ext) : filterbank_planes_partials(h->ext),
+                            reinterpret_cast<uint32_t*>(h->zp), n, h->kc, h->n_bins, s);
+      BP_MARK(BP_STAGE_ZPACK);
+    }
     if (h->fused_contour) {
       BP_DOM_BEGIN();
       launch_contour_branch(reinterpret_cast<const uint32_t*>(h->zp), h->d_cb_wfrag, h->d_cb_wf32, contour_dev, n,
@@ -1146,14 +1151,16 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
 
   const int64_t cap = h->cap;
   if ((rc = alloc(h, &h->audio, cap * (int64_t)h->win_len)) || (rc = alloc(h, &h->pyr, cap * h->pyr_stride)) ||
-      (rc = alloc(h, &h->lp, cap * kFrames * (int64_t)h->n_bins)) || (rc = alloc(h, &h->c1, cap * 8 * kPlaneC)) ||
+      (rc = alloc(h, &h->lp, cap * kFrames * (int64_t)h->n_bins + 4)) || (rc = alloc(h, &h->c1, cap * 8 * kPlaneC)) ||
       (rc = alloc(h, &h->contour, cap * kPlaneC)) || (rc = alloc(h, &h->n1, cap * 32 * kPlaneN)) ||
       (rc = alloc(h, &h->note, cap * kPlaneN)) || (rc = alloc(h, &h->o1, cap * 32 * kPlaneN)) ||
       (rc = alloc(h, &h->onset, cap * kPlaneN)) || (rc = alloc(h, &h->zp, cap * (int64_t)kZWin)) ||
       (rc = alloc(h, &h->c1s, cap * (int64_t)kC1Win)))
     return fail(rc);
   {
-    hipError_t e = hipMemset(h->c1s, 0, (size_t)cap * kC1Win * sizeof(float));  // pad bins stay zero
+    // pad frames / pad words of zp are zero for good: the fused filterbank writes only the words that carry bins
+    hipError_t e = hipMemset(h->zp, 0, (size_t)cap * kZWin * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->c1s, 0, (size_t)cap * kC1Win * sizeof(float));  // pad bins stay zero
     if (e != hipSuccess) {
       h->err = std::string("hipMemset(c1s) failed: ") + hipGetErrorString(e);
       return fail(BP_ERR_HIP);
@@ -1680,7 +1687,8 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
             const int64_t off = h->ext ? ((k == 1) ? 0 : kAudioN + pyr_off(k - 1)) : pyr_off(k);
             launch_planes_split(bf->pyr + off, h->pyr_stride, k, pl, n, h->ext, s);
           }
-          launch_filterbank_planes(pl, h->d_pl_bfrag, h->d_sqrt_len, bf->lp, h->fb_scratch, n, h->kc, h->n_cu, h->ext, s);
+          (void)launch_filterbank_planes(pl, h->d_pl_bfrag, h->d_sqrt_len, bf->lp, h->fb_scratch, nullptr, n, h->kc, h->n_cu,
+                                         h->ext, s);
           launch_mm_reduce(h->fb_scratch, bf->mm, n, filterbank_planes_partials(h->ext), s);
         }
       }

@@ -467,16 +467,23 @@ static_assert(pl_fb_item(kPlFbFrags - 1).s == 6 && pl_fb_item(kPlFbFrags).s == -
 // 54 us at B = 256); 768 / 704 threads = 3 waves per SIMD with up to 168 VGPRs hold the whole next task's fragments in
 // flight (56 registers) — measured the same 55 us: once the waves draw their tasks from a queue the kernel is paced by
 // instruction issue (matrix pipe 41 % busy, VALU most of the rest), not by memory latency.
-template <int THREADS, int APF>
+// FUSED: a workgroup owns whole windows (its waves draw the window's 99 tasks), keeps the tiles' extrema in LDS and, when
+// the window's last task is done, normalises its log-power map itself and writes the pre-split, BatchNorm-ed `zp` words
+// (signal.py:177-183, models.py:187-189: what zpack_kernel does in a launch of its own) — the map was written by this
+// CU a few microseconds ago and comes back from L2, the extrema never leave the CU.  !FUSED: tasks strided over all
+// workgroups, extrema partials to `mmp` (launches with fewer windows than CUs, and the per-stage test hook).
+template <int THREADS, int APF, bool FUSED>
 __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
     const uint16_t* __restrict__ pl, const uint4* __restrict__ bfrag, const float* __restrict__ sqrt_len,
-    float* __restrict__ lp, float2* __restrict__ mmp, int n_windows, LogConsts kc, PlGeo g, unsigned per_window_magic) {
+    float* __restrict__ lp, float2* __restrict__ mmp, uint32_t* __restrict__ zp, int n_windows, LogConsts kc, PlGeo g,
+    unsigned per_window_magic) {
   __shared__ __attribute__((aligned(16))) uint4 bfr[kPlFbFrags * 2 * 64];
   // sqrt(lengths) and the level offsets from LDS, not from global / constant memory: a wave's memory counters are in
   // order, so a global load in the epilogue would wait for every A fragment prefetched for the next task before it
   __shared__ float s_sqrt_len[kBinsExt];
   __shared__ int s_off[10];
   __shared__ int s_next;
+  __shared__ float2 s_mm[FUSED ? 10 * kPlTilesPerLevel : 1];
 #if defined(PL_FB_PROF)
   const unsigned long long pentry = __builtin_amdgcn_s_memtime();
 #endif
@@ -496,13 +503,17 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
   struct Pos {
     int b, rem;
   };
+  int win = blockIdx.x;  // FUSED: the window this workgroup is working on
   auto grab = [&]() -> int {
     int j = 0;
     if ((threadIdx.x & 63) == 0) j = atomicAdd(&s_next, 1);
-    const int task_ = blockIdx.x + gridDim.x * __builtin_amdgcn_readfirstlane(j);
+    j = __builtin_amdgcn_readfirstlane(j);
+    if constexpr (FUSED) return j < per_window ? win * per_window + j : -1;
+    const int task_ = blockIdx.x + gridDim.x * j;
     return task_ < n_tasks ? task_ : -1;
   };
   auto pos_of = [&](int task_) {  // task / per_window by multiply-shift (exact below 2^32 / 95 for 99, 2^32 / 4 for 110)
+    if constexpr (FUSED) return Pos{win, task_ - win * per_window};
     const int b_ = (int)__umulhi((unsigned)task_, per_window_magic);
     return Pos{b_, task_ - b_ * per_window};
   };
@@ -514,9 +525,10 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
            8 * (lane >> 4);
   };
   static_assert(kPlTilesPerLevel == 11, "the multiply-shift above divides by 11");
+  for (; win < (FUSED ? n_windows : blockIdx.x + 1); win += gridDim.x) {
   int task = grab();
-  if (task < 0) return;
-  int ntask = grab();
+  int ntask = task >= 0 ? grab() : -1;
+  if (task >= 0) {
   Pos pos = pos_of(task);
   // A fragments: a ring of 7 k-steps.  When a task starts, its first APF steps are in the ring (fetched during the task
   // before); step s + APF is fetched when step s has been consumed — for s + APF >= 7 that is step s + APF - 7 of the NEXT
@@ -649,7 +661,12 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
     }
     vmin = wave_min_lane63(vmin);
     vmax = wave_max_lane63(vmax);
-    if ((threadIdx.x & 63) == 63) mmp[(int64_t)b * per_window + rem] = make_float2(vmin, vmax);
+    if ((threadIdx.x & 63) == 63) {
+      if constexpr (FUSED)
+        s_mm[rem] = make_float2(vmin, vmax);
+      else
+        mmp[(int64_t)b * per_window + rem] = make_float2(vmin, vmax);
+    }
 #if defined(PL_FB_PROF)
     {
       const unsigned long long c2 = __builtin_amdgcn_s_memtime();
@@ -659,12 +676,62 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
     if (!more) break;
     pos = npos, task = ntask, ntask = nntask;
   }
+  }  // if (task >= 0)
+  if constexpr (!FUSED) break;
+  if constexpr (FUSED) {
+    // ---- the window is complete: normalise + BatchNorm + split, as zpack_kernel (conv_branch.hip) ----
+    __syncthreads();  // every tile's log-power values (global stores of this workgroup) and extrema (LDS) are visible
+    float vmin = __int_as_float(0x7f800000), vmax = -__int_as_float(0x7f800000);
+    for (int i = threadIdx.x & 63; i < per_window; i += 64) {
+      vmin = fminf(vmin, s_mm[i].x);
+      vmax = fmaxf(vmax, s_mm[i].y);
+    }
+    const float mn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_min_lane63(vmin)), 63));
+    const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_max_lane63(vmax)), 63));
+    const float range = mx - mn;
+    const float* lpb = lp + (int64_t)win * kFrames * g.n_bins;
+    uint32_t* zb = zp + (int64_t)win * kZWin;
+    // only the words that carry bins: `zp`'s pad frames / pad words are zero since bp_create and nobody writes them
+    const int row_u4 = (g.n_bins + 3) / 4;  // uint4 per frame that hold bins (kZPadL is a multiple of 4)
+    // loads of kZb items in flight per thread (the values come back from L2): issued one by one, every item would pay
+    // the round trip on its own.  The last item of a row reads up to 3 floats of the next row (masked below; `lp` is
+    // allocated with that much slack behind its last row).
+    constexpr int kZb = 7;
+    const int n_items = kFrames * row_u4;
+    for (int i0 = threadIdx.x; i0 < n_items; i0 += kZb * THREADS) {
+      float4 v[kZb];
+#pragma unroll
+      for (int k = 0; k < kZb; ++k) {
+        const int i = i0 + k * THREADS;
+        const int ic = i < n_items ? i : n_items - 1;
+        const int t_ = ic / row_u4, g0 = 4 * (ic - t_ * row_u4);
+        v[k] = *reinterpret_cast<const float4*>(lpb + t_ * g.n_bins + g0);  // dword alignment is enough
+      }
+#pragma unroll
+      for (int k = 0; k < kZb; ++k) {
+        const int i = i0 + k * THREADS;
+        if (i >= n_items) break;
+        const int t_ = i / row_u4, g0 = 4 * (i - t_ * row_u4);
+        const float x4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        uint32_t u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = norm_bn(x4[e], mn, range, kc);
+          const _Float16 hi = (_Float16)z;
+          const _Float16 lo = (_Float16)((z - (float)hi) * kLoScale);
+          const uint32_t w = (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
+          u[e] = g0 + e < g.n_bins ? w : 0u;
+        }
+        *reinterpret_cast<uint4*>(zb + (t_ + 1) * kZRow + kZPadL + g0) = uint4{u[0], u[1], u[2], u[3]};
+      }
+    }
+    __syncthreads();  // s_mm and the task counter are free for the next window
+    if (threadIdx.x == 0) s_next = 0;
+    __syncthreads();
+  }
+  }  // windows
 #if defined(PL_FB_PROF)
-  if ((threadIdx.x & 63) == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && (wave_id() == 0 || wave_id() == 5 || wave_id() == 10))
-    printf("fbprof block %d wave %d: tasks %llu, K-loop %llu cycles/task, epilogue %llu, whole loop %llu, prologue %llu, entry at %llu\n",
-           blockIdx.x, wave_id(), pn_, pk / pn_, pe / pn_, (unsigned long long)(__builtin_amdgcn_s_memtime() - pstart),
-           (unsigned long long)(pstart - pentry), pentry);
-  (void)task;
+  (void)pentry;
 #endif
 }
 
@@ -722,35 +789,50 @@ void launch_pyramid_planes(const float* audio, int64_t audio_stride, uint16_t* p
 
 int filterbank_planes_partials(bool ext) { return make_pl_geo(ext).n_levels * kPlTilesPerLevel; }
 
-void launch_filterbank_planes(const uint16_t* pl, const void* bfrag, const float* sqrt_len, float* lp, float* scratch,
-                              int n_windows, LogConsts kc, int n_cu, bool ext, hipStream_t stream) {
+// zp != null and enough windows to give every CU its own: the fused kernel (filterbank + normalise / BatchNorm / split of
+// whole windows per workgroup) — returns true, `zp` is complete; otherwise tasks strided over the chip, extrema partials in
+// `scratch` (fold them with launch_zpack_partials or launch_mm_reduce) — returns false.
+bool launch_filterbank_planes(const uint16_t* pl, const void* bfrag, const float* sqrt_len, float* lp, float* scratch,
+                              uint32_t* zp, int n_windows, LogConsts kc, int n_cu, bool ext, hipStream_t stream) {
   PlGeo g = make_pl_geo(ext);
   if (const char* e = getenv("BP_FB_ONLY_LEVEL")) {  // tools only (timing of one level's tasks; results are garbage)
     const int k = atoi(e);
     g.hop0 >>= k, g.off[0] = g.off[k], g.len[0] = g.len[k], g.n_levels = 1;
+    zp = nullptr;
   }
   const int tasks = n_windows * g.n_levels * kPlTilesPerLevel;
   static const int variant = [] {  // BP_FB_WAVES=16 / 12 / 11: waves per workgroup (A/B runs); default 16
     const char* e = getenv("BP_FB_WAVES");
     return e ? atoi(e) : 16;
   }();
+  static const bool no_fuse = getenv("BP_FB_NOFUSE") != nullptr;  // A/B runs: the separate zpack launch
   const uint4* bf = static_cast<const uint4*>(bfrag);
   float2* mm = reinterpret_cast<float2*>(scratch);
   const unsigned per_window = (unsigned)(g.n_levels * kPlTilesPerLevel);
   const unsigned magic = (unsigned)((0x100000000ull + per_window - 1) / per_window);
+  const bool fused = zp != nullptr && !no_fuse && 2 * n_windows >= n_cu;
   auto grid_for = [&](int waves) {
+    if (fused) return n_windows < n_cu ? n_windows : n_cu;
     const int grid = (tasks + waves - 1) / waves;
     return grid > n_cu ? n_cu : grid;
   };
-  if (variant == 16)
-    hipLaunchKernelGGL((cqt_filterbank_planes_kernel<1024, 3>), dim3(grid_for(16)), dim3(1024), 0, stream, pl, bf, sqrt_len, lp,
-                       mm, n_windows, kc, g, magic);
-  else if (variant == 11)
-    hipLaunchKernelGGL((cqt_filterbank_planes_kernel<704, 7>), dim3(grid_for(11)), dim3(704), 0, stream, pl, bf, sqrt_len, lp,
-                       mm, n_windows, kc, g, magic);
+#define BP_PL_FB_LAUNCH(T, A, W)                                                                                         \
+  do {                                                                                                                   \
+    if (fused)                                                                                                           \
+      hipLaunchKernelGGL((cqt_filterbank_planes_kernel<T, A, true>), dim3(grid_for(W)), dim3(T), 0, stream, pl, bf,      \
+                         sqrt_len, lp, mm, zp, n_windows, kc, g, magic);                                                 \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((cqt_filterbank_planes_kernel<T, A, false>), dim3(grid_for(W)), dim3(T), 0, stream, pl, bf,     \
+                         sqrt_len, lp, mm, zp, n_windows, kc, g, magic);                                                 \
+  } while (0)
+  if (variant == 11)
+    BP_PL_FB_LAUNCH(704, 7, 11);
+  else if (variant == 12)
+    BP_PL_FB_LAUNCH(768, 7, 12);
   else
-    hipLaunchKernelGGL((cqt_filterbank_planes_kernel<768, 7>), dim3(grid_for(12)), dim3(768), 0, stream, pl, bf, sqrt_len, lp,
-                       mm, n_windows, kc, g, magic);
+    BP_PL_FB_LAUNCH(1024, 3, 16);
+#undef BP_PL_FB_LAUNCH
+  return fused;
 }
 
 }  // namespace bp
