@@ -21,10 +21,15 @@ Pin: with this resampler in front, the graph oracle (`bp_oracle.py`) reproduces 
 for its 44.1 kHz test clip to <= 5e-5 max-abs, inside the reference's own `atol=1e-4`
 (`tests/test_inference.py:66-70`) — `tests/test_oracle_golden.py::test_oracle_reproduces_golden_posteriorgrams`.
 With scipy's default polyphase design in front instead the same oracle is 4e-3 away: the test keeps that
-comparison, so "the residual was the resampler" is a tested statement.  Other ratios than 2 : 1: libsoxr splits the work
-into several stages (half-band stages, a polyphase stage with 147 phases for 48 kHz, ...); here they are ONE polyphase
-stage with the same pass-band / stop-band / attenuation — the same response to the filter's 1e-6 ripple, but no golden
-vector exists for them: unpinned beyond the design.
+comparison, so "the residual was the resampler" is a tested statement.  Other ratios than 2 : 1 (round 3): `stage_plan`
+restates libsoxr's stage determination (cr.c) — 48 kHz, 16 kHz and 8 kHz come out as ONE rational poly-phase stage
+(147 : 320, 441 : 320, 441 : 160: no half-band pre-stage), 11.025 kHz as one 2 x interpolating stage; 88.2 / 96 kHz put a
+half-band decimation (a fixed coefficient table of libsoxr) and 32 / 24 kHz a 2 x interpolation in front of the poly-phase
+stage.  `design_lpf(..., phases)` restates the poly-phase design rule (tap count k * phases - 1, Kaiser support rho = .75).
+No golden vector exists for these ratios; what is open is measured instead of claimed: the designs that meet the SOXR_HQ
+specification differ by the filter's alignment (half a filter-rate tick for the even-length poly-phase filter) — on the
+reference's clip brought to 48 kHz the posteriorgrams of the candidates are within 9.4e-5 of each other, at 16 kHz
+within 4.3e-4 (onset map; 1.1e-4 on note / contour): profiles/r03_soxr_plan_distance.md.
 """
 from __future__ import annotations
 
@@ -68,35 +73,140 @@ def kaiser_beta(att: float, tr_bw: float) -> float:
     return b0 + (b1 - b0) * (realm - int(realm))
 
 
-def design_lpf(Fp: float, Fs: float, Fn: float, att: float, modulo: int = 4) -> np.ndarray:
-    """lsx_design_lpf(Fp, Fs, Fn, att, &num_taps = 0, k = -modulo, beta = -1) + lsx_make_lpf(rho = .5, scale = 1)."""
+def design_lpf(Fp: float, Fs: float, Fn: float, att: float, modulo: int = 4, phases: int = 1) -> np.ndarray:
+    """lsx_design_lpf(Fp, Fs, Fn, att, &num_taps = 0, k, beta = -1) + lsx_make_lpf(rho, scale = 1).
+
+    k < 0 (`modulo`, phases = 1: the single-rate `dft_stage` filters): num_taps = 1 (mod modulo), rho = .5.
+    k > 0 (`phases` > 1: the coefficient set of a poly-phase stage, designed at phases x the stage's input rate):
+    transition band and stop-band scaled by 1 / phases, num_taps rounded to a multiple of phases minus 1, and the Kaiser
+    window's support parameter rho = .63 below 120 dB, .75 from 120 dB (filter.c)."""
     Fp, Fs = Fp / Fn, Fs / Fn
-    tr_bw = min(0.5 * (Fs - Fp), 0.5 * Fs)
+    tr_bw = 0.5 * (Fs - Fp) / phases
+    Fs = Fs / phases
+    tr_bw = min(tr_bw, 0.5 * Fs)
     Fc = Fs - tr_bw
     beta = kaiser_beta(att, tr_bw * 0.5 / Fc)
     a = ((0.0007528358 - 1.577737e-05 * beta) * beta + 0.6248022) * beta + 0.06186902  # lsx_kaiser_params, att >= 60
     n = int(np.ceil(a / tr_bw + 1))
-    n = (n + modulo - 2) // modulo * modulo + 1
+    if phases > 1:
+        n = n // phases * phases + phases - 1
+        rho = 0.63 if att < 120 else 0.75
+    else:
+        n = (n + modulo - 2) // modulo * modulo + 1
+        rho = 0.5
     m = n - 1
     z = np.arange(n, dtype=np.float64) - 0.5 * m
     x = z * np.pi
     h = np.where(x != 0, np.sin(Fc * x) / np.where(x != 0, x, 1.0), Fc)
-    y = z / (0.5 * m + 0.5)
+    y = z / (0.5 * m + rho)
     return h * i0(beta * np.sqrt(1.0 - y * y)) / i0(beta)
 
 
-def resample(x: np.ndarray, orig_sr: int, target_sr: int = 22050) -> np.ndarray:
+def stage_plan(io_ratio: float, coef_size_kbytes: float = 400.0, sizeof_real: int = 4) -> dict:
+    """The stage determination of libsoxr's `_soxr_init` (cr.c, "Determine stages"), restated from the published source
+    for a quality with `precision` > 16 bit, the default runtime spec (SOXR_COEF_INTERP_AUTO, small-integer
+    optimisation on) and float32 samples.  Returns the factors of the pipeline
+        [shr half-band decimations] -> [pre stage preL : preM] -> [arbitrary / poly-phase stage arbL : arbM] -> [post stage]
+    `rational` says the middle stage is an exact poly-phase FIR with arbL phases (no coefficient interpolation).
+
+    What this restatement is used for: deciding WHICH ratios libsoxr runs as one stage.  2 : 1 is one `dft_stage`
+    (preL : preM = 1 : 2, pinned by the reference's golden vectors); 48 kHz -> 22.05 kHz and 16 kHz -> 22.05 kHz come out
+    as ONE rational poly-phase stage (147 : 320 and 441 : 320) — no half-band pre-stage, contrary to what this file's
+    header said in round 2; 88.2 / 96 kHz have one half-band decimation in front (a fixed coefficient table in libsoxr
+    that is not reproducible from memory) and 32 kHz a 2 x interpolating pre-stage: for those the restatement stops at
+    the plan."""
+    U100_l = 42
+    MULT32 = 65536.0 * 65536.0
+    arbM, mode, n = float(io_ratio), 0, 0
+    postL, iOpt = 1, True
+    while True:
+        n += 1
+        if n != 1:
+            break
+        maxL = 2048 if mode else int(np.ceil(coef_size_kbytes * 1000.0 / (U100_l * sizeof_real)))
+        upsample = arbM < 1
+        shr, i = 0, int(0.5 * arbM)
+        while True:
+            i >>= 1
+            if not i:
+                break
+            arbM *= 0.5
+            shr += 1
+        preM = 1 if (upsample or 1.5 < arbM < 2) else 0
+        postM = 1 + (1 if (arbM > 1 and preM) else 0)
+        arbM /= postM
+        preL = 1 + (1 if (not preM and arbM < 2) else 0) + (1 if (upsample and mode) else 0)
+        arbM *= preL
+        frac, epsilon, arbL = arbM - int(arbM), 0.0, 1
+        if frac != 0:
+            epsilon = abs(np.floor(frac * MULT32 + 0.5) / (frac * MULT32) - 1)
+        rational = frac == 0
+        i = 1
+        while i <= maxL and not rational:
+            d = frac * i
+            tr = int(d + 0.5)
+            rational = tr > 0 and abs(tr / d - 1) <= epsilon
+            if rational:
+                if tr == i:
+                    arbM = float(np.ceil(arbM))
+                    x = 1 if arbM > 3 else 0
+                    shr += x
+                    arbM /= 1 + x
+                else:
+                    arbM, arbL = float(i * int(arbM) + tr), i
+            i += 1
+        L, M = preL * arbL, int(arbM * postM)
+        x = (L | M) & 1
+        if not x:
+            L, M = L >> 1, M >> 1
+        d = preL * arbL / arbM
+        if iOpt and postL == 1 and d > 4 and d != 5:
+            postL, i = 4, int(d / 16)
+            while True:
+                i >>= 1
+                if not i or postL >= 256:
+                    break
+                postL <<= 1
+            arbM, arbL, n = arbM * postL / arbL / preL, 1, 0
+        elif rational and (max(L, M) < 3 + 2 * iOpt or L * M < 6 * iOpt):
+            preL, preM, arbM, arbL, postM = L, M, 1.0, 1, 1
+        if not mode and (not rational or not n):
+            mode, n = mode + 1, 0
+    return {"shr": shr, "preL": preL, "preM": max(preM, 1), "arbL": arbL, "arbM": arbM, "postL": postL, "postM": postM,
+            "rational": bool(rational), "single_stage": shr == 0 and postL == 1 and postM == 1 and
+            ((arbL == 1 and arbM == 1) or (preL == 1 and max(preM, 1) == 1))}
+
+
+def taps(up: int, down: int, poly_rule: bool = True) -> np.ndarray:
+    """The filter of an up : down rate change at the rate `orig_sr * up`, DC gain `up`.  up = 1: the single-rate design
+    (k = -4); up > 1 and `poly_rule`: lsx_design_lpf's poly-phase rule (k = up phases) — the filter is then specified at
+    the stage's input rate (Fn = down / up input Nyquists per output Nyquist when down-sampling) and designed at `up` times
+    that rate, which is the same cut-off and transition band as the single-rate formula at the high rate, with the
+    poly-phase tap count and window support."""
+    Fp, Fs, att = hq_spec()
+    if up > 1 and poly_rule:
+        return design_lpf(Fp, Fs, max(float(down) / up, 1.0), att, phases=up) * up
+    return design_lpf(Fp, Fs, float(max(up, down)), att) * up
+
+
+def resample(x: np.ndarray, orig_sr: int, target_sr: int = 22050, poly_rule: bool = False) -> np.ndarray:
     """mono float signal at orig_sr -> float32 at target_sr, ceil(n * target / orig) samples, soxr_hq response.
 
-    Direct form, float64: y[k] = up * sum_j x[j] h[k * down - j * up + c] (zero outside the file, c = filter centre)."""
+    Direct form, float64: y[k] = up * sum_j x[j] h[k * down - j * up + c] (zero outside the file, c = filter centre).
+    Ratios whose libsoxr pipeline is one stage (`stage_plan(...)["single_stage"]`: 2 : 1, 48 kHz, 16 kHz, 8 kHz, ...) are
+    that stage; the others (a half-band decimation or a 2 x interpolation in front) run as one stage of the same
+    specification.  `poly_rule` selects lsx_design_lpf's poly-phase tap-count / window rule for up > 1 (what libsoxr's
+    stage runs); the default is the single-rate rule with an odd, exactly centred filter (zero phase: output k sits
+    exactly at input time k * down / up) — the product's design.  The poly-phase rule's even tap count leaves half a
+    filter-rate tick of alignment that cannot be settled without libsoxr itself; tools/soxr_plan_distance.py measures what
+    the choice is worth on the posteriorgrams (profiles/r03_soxr_plan_distance.md)."""
     x = np.asarray(x, dtype=np.float64)
     n_out = int(np.ceil(len(x) * target_sr / orig_sr))
     if orig_sr == target_sr:
         return x.astype(np.float32)
     fr = Fraction(int(target_sr), int(orig_sr))
     up, down = fr.numerator, fr.denominator
-    Fp, Fs, att = hq_spec()
-    h = design_lpf(Fp, Fs, float(max(up, down)), att) * up
+    h = taps(up, down, poly_rule)
     c = (len(h) - 1) // 2
     if up == 1:
         xx = np.concatenate([np.zeros(c), x, np.zeros(c + down)])

@@ -185,3 +185,24 @@ def test_extended_cqt_restatement_is_consistent(weights):
     ratio = ext[:309].astype(np.float64) / weights["cqt_sqrt_len"].astype(np.float64)
     assert np.abs(r["mag"][:, :, :309] - std * ratio).max() <= 1e-12
     assert r["mag"][:, :, 309:].max() > 0  # the new top octave carries data
+
+
+def test_soxr_stage_plan_restatement():
+    """oracle/soxr_oracle.py::stage_plan restates libsoxr's stage determination (cr.c): the 2 : 1 ratio of the
+    reference's golden clip is ONE single-rate stage (what the golden pin rests on); 48 kHz, 16 kHz and 8 kHz are one
+    rational poly-phase stage each; 88.2 / 96 kHz put a half-band decimation in front, 32 kHz a 2 x interpolation.  The two
+    design rules give the tap counts the restatement documents."""
+    from oracle import soxr_oracle as S
+
+    p = S.stage_plan(44100 / 22050)
+    assert (p["shr"], p["preL"], p["preM"], p["arbL"], p["single_stage"]) == (0, 1, 2, 1, True)
+    for sr, (L, M) in ((48000, (147, 320)), (16000, (441, 320)), (8000, (441, 160))):
+        p = S.stage_plan(sr / 22050)
+        assert (p["shr"], p["preL"], p["arbL"], int(p["arbM"]), p["rational"], p["single_stage"]) == (0, 1, L, M, True, True), sr
+    assert S.stage_plan(88200 / 22050)["shr"] == 1 and S.stage_plan(96000 / 22050)["shr"] == 1
+    assert S.stage_plan(32000 / 22050)["preL"] == 2 and not S.stage_plan(32000 / 22050)["single_stage"]
+    assert len(S.taps(1, 2)) == 389
+    odd, poly = S.taps(147, 320, poly_rule=False), S.taps(147, 320, poly_rule=True)
+    assert len(odd) % 2 == 1 and len(odd) % 4 == 1 and (len(poly) + 1) % 147 == 0
+    for h in (odd, poly):
+        assert abs(h.sum() / 147 - 1.0) < 1e-6 and np.allclose(h, h[::-1])
