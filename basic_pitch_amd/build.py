@@ -20,10 +20,8 @@ SOURCES = [
     "bp_api.hip",
     "cqt_pyramid.hip",
     "cqt_filterbank.hip",
-    "cqt_mfma.hip",
     "cqt_planes.hip",
     "conv_contour1.hip",
-    "conv_contour.hip",
     "conv_contour_direct.hip",
     "conv_contour_rim.hip",
     "conv_contour_fold_mx.hip",

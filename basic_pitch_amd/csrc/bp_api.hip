@@ -32,8 +32,6 @@ void launch_filterbank(const float* audio, const float* pyr, const float* bfrag,
                        hipStream_t s);
 void launch_contour1(const float* lp, const int* mm, const float* bfrag, const float* bias, float* c1,
                      int n_windows, LogConsts kc, int n_cu, hipStream_t s);
-void launch_contour_branch(const uint32_t* zp, const void* wfrag, const float* wf32, float* contour,
-                           int n_windows, int n_cu, hipStream_t s);
 void launch_onset1(const float* lp, const int* mm, const float* bfrag, const float* bias, float* o1,
                    int n_windows, LogConsts kc, int n_cu, hipStream_t s);
 void launch_note1(const float* contour, const float* bfrag, const float* bias, float* n1, int n_windows,
@@ -44,13 +42,8 @@ void launch_note2(const float* n1, const float* wgt, float bias, float* note, in
                   hipStream_t s);
 void launch_onset2(const float* note, const float* o1, const float* wgt, float bias, float* onset,
                    int n_windows, hipStream_t s);
-void launch_pyramid_mfma(const float* audio, float* pyr, const void* hfrag, int n_windows, bool ext, hipStream_t s);
-void launch_filterbank_mfma(const float* audio, const float* pyr, const void* bfrag, const float* sqrt_len,
-                            float* lp, int* mm, float* scratch, int n_windows, LogConsts kc, int n_cu, bool ext,
-                            hipStream_t stream);
 void launch_zpack_partials(const float* lp, const float* scratch, int n_partials, uint32_t* zp, int n_windows,
                            LogConsts kc, int n_bins, hipStream_t stream);
-int filterbank_mfma_partials(bool ext);
 // cqt_planes.hip: the pyramid as pre-split, reflect-padded f16 planes; operands straight from HBM / L2
 int64_t planes_elements_per_window(bool ext);
 void launch_planes_split(const float* src, int64_t src_stride, int level, uint16_t* pl, int n_windows, bool ext,
@@ -80,8 +73,6 @@ void launch_contour_conv1_fold_mx(const uint32_t* zp, const void* a16, const voi
                                   const float* bias, float* c1, int n_windows, int n_cu, hipStream_t stream);
 void launch_contour_conv2(const float* c1, const float* w2, float bias, float* contour, int n_windows, int n_cu,
                           hipStream_t stream);
-void launch_note_branch(const float* contour, const void* wfrag, const float* wf32, float* note,
-                        int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
 void launch_note_march(const float* contour, const void* wfrag, const float* wf32, float* note, int n_windows,
                        bool weights_have_lo, hipStream_t stream);
 void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, const void* wmx,
@@ -187,7 +178,6 @@ struct bp_context {
   float b_contour2 = 0, b_note2 = 0, b_onset2 = 0;
   // device constants
   float *d_lowpass = nullptr, *d_sqrt_len = nullptr, *d_fb_bfrag = nullptr;
-  float *d_cb_wfrag = nullptr, *d_cb_wf32 = nullptr;  // fused contour branch (conv_contour.hip)
   // fused branches (conv_branch.hip): f16 hi/lo A fragments (raw bytes) + {bias1[32], extra[9], bias2}
   float *d_note_wfrag = nullptr, *d_note_wf32 = nullptr, *d_onset_wfrag = nullptr, *d_onset_wf32 = nullptr,
         *d_onset_wmx = nullptr;
@@ -198,12 +188,8 @@ struct bp_context {
   bool rim_exact = false, fold_mx = false;
   float* d_d1_wfold_mx = nullptr;
   float* c1s = nullptr;  // [cap][172][kC1Row][8] relu(conv1); pad bins zeroed once at allocation
-  bool fused_contour = false;
-  bool note_ring = false;  // BP_CONTOUR_PATH=fused: the single-kernel contour branch (A/B comparisons)
-  float *d_dec_hfrag = nullptr, *d_fbh_bfrag = nullptr;  // cqt_mfma.hip f16 hi/lo fragments (raw bytes)
-  // cqt_planes.hip (default): decimator / filterbank fragments, the planes of a chunk [cap][2][stride] f16
+  // cqt_planes.hip: decimator / filterbank fragments (raw bytes of f16 hi / lo), the planes of a chunk [cap][2][stride] f16
   float *d_pl_tfrag = nullptr, *d_pl_bfrag = nullptr, *planes = nullptr;
-  bool cqt_staged = false;  // BP_CQT=staged: the round-2 LDS-staged kernels of cqt_mfma.hip (A/B runs)
   float *d_c1_bfrag = nullptr, *d_c1_bias = nullptr, *d_o1_bfrag = nullptr, *d_o1_bias = nullptr;
   float *d_n1_bfrag = nullptr, *d_n1_bias = nullptr, *d_w_contour2 = nullptr, *d_w_note2 = nullptr,
         *d_w_onset2 = nullptr;
@@ -361,45 +347,6 @@ void put_split(std::vector<uint16_t>& out, size_t hi_base, size_t lo_base, size_
   const uint16_t hi = f32_to_f16(v);
   out[hi_base + idx] = hi;
   out[lo_base + idx] = f32_to_f16((v - f16_to_f32(hi)) * lo_scale);
-}
-
-// Fused contour branch (conv_contour.hip).
-//   conv1 A fragments [4 waves][16 k-steps][hi|lo][64 lanes][8 channels] f16; k-step = (frame dt, tap pair
-//   ep), lane -> (tap parity h = lane >> 5, row i = lane & 31 = out channel o*4 + bin offset j); value
-//   W1[o][c][dt][2ep + h - j] (Toeplitz over 4 adjacent bins).
-//   conv2 A fragments [2][64 lanes][8]: lane -> (tap = lane & 31 (25 used), h); k-slot e < 4 is channel
-//   2e + h of the hi part, e >= 4 channel 2(e-4) + h of the scaled lo part of relu(c1):
-//     fragment 0 = [hi(w) | 0], fragment 1 = [lo(w) * 2^11 | hi(w)].
-void pack_contour_branch(const Tensor* w1, const Tensor* w2, std::vector<uint16_t>& out) {
-  const size_t n1 = (size_t)4 * 16 * 2 * 64 * 8;
-  out.assign(n1 + 2 * 64 * 8, 0);
-  for (int wave = 0; wave < 4; ++wave)
-    for (int s = 0; s < 16; ++s) {
-      const int step = wave * 16 + s;
-      if (step >= 63) continue;
-      const int dt = step / 21, ep = step % 21;
-      for (int lane = 0; lane < 64; ++lane) {
-        const int hh = lane >> 5, n = lane & 31, o = n >> 2, jj = n & 3;
-        const int df = 2 * ep + hh - jj;
-        const size_t base = ((((size_t)wave * 16 + s) * 2 + 0) * 64 + lane) * 8;
-        for (int c = 0; c < 8; ++c) {
-          float v = 0.f;
-          if (df >= 0 && df < 39) v = w1->data[((o * 8 + c) * 3 + dt) * 39 + df];
-          put_split(out, base, base + 64 * 8, c, v, 2048.0f);
-        }
-      }
-    }
-  for (int lane = 0; lane < 64; ++lane) {
-    const int tap = lane & 31, hh = lane >> 5;
-    for (int e = 0; e < 4; ++e) {
-      const float v = tap < 25 ? w2->data[(2 * e + hh) * 25 + tap] : 0.f;
-      const uint16_t hi = f32_to_f16(v);
-      const uint16_t lo = f32_to_f16((v - f16_to_f32(hi)) * 2048.0f);
-      out[n1 + (size_t)lane * 8 + e] = hi;                 // fragment 0: hi(w) x hi(c)
-      out[n1 + 64 * 8 + (size_t)lane * 8 + e] = lo;        // fragment 1: lo(w) x hi(c)
-      out[n1 + 64 * 8 + (size_t)lane * 8 + 4 + e] = hi;    //             hi(w) x lo(c)
-    }
-  }
 }
 
 // Two-kernel contour branch (conv_contour_direct.hip): LDS weight image [hi | lo][3 dt][45 taps][8 o] x (8 c) f16,
@@ -676,11 +623,10 @@ void pack_branch(int ks1, const Tensor* w1, const Tensor* w2, bool onset, std::v
       }
 }
 
-// cqt_mfma.hip decimator: B[i][u] = h[i - 2u] band, [hi: 9 steps][lo: 9 steps] x 64 lanes x 8 f16;
-// lane (u = lane & 15, kg = lane >> 4), element e: i = 32 s + 8 kg + e.
-// `shift` = 1: the transposed decimator of cqt_planes.hip, whose input window starts one sample earlier (an 8-sample
-// aligned element of the padded plane): T[u][i] = h[i - 2u - 1], as the A operand — the same lane / element mapping.
-void pack_decimator_f16(const Tensor* lowp, std::vector<uint16_t>& out, int shift = 0) {
+// cqt_planes.hip decimator (transposed: the filter is the A operand): T[u][i] = h[i - 2u - 1] — the input window starts one
+// sample before the reference's (an 8-sample aligned element of the padded plane) — as [hi: 9 steps][lo: 9 steps] x 64
+// lanes x 8 f16; lane (u = lane & 15, kg = lane >> 4), element e: i = 32 s + 8 kg + e.
+void pack_decimator_f16(const Tensor* lowp, std::vector<uint16_t>& out, int shift = 1) {
   const size_t lo_base = (size_t)9 * 64 * 8;
   out.assign(2 * lo_base, 0);
   for (int s = 0; s < 9; ++s)
@@ -692,35 +638,6 @@ void pack_decimator_f16(const Tensor* lowp, std::vector<uint16_t>& out, int shif
         put_split(out, 0, lo_base, ((size_t)s * 64 + lane) * 8 + e,
                   (j >= 0 && j < 256) ? lowp->data[j] * 1024.0f : 0.f, 2048.0f);
       }
-}
-
-// cqt_mfma.hip filterbank: [4 roles][7 steps][hi|lo][64 lanes][8] f16; lane (n = lane & 15, kg), element e:
-// tap = base + 32 s' + 8 kg + e of the role's segment (FmRole in cqt_mfma.hip).
-void pack_filterbank_f16(const Tensor* re, const Tensor* im, std::vector<uint16_t>& out) {
-  out.assign((size_t)4 * 7 * 2 * 64 * 8, 0);
-  for (int role = 0; role < 4; ++role)
-    for (int s = 0; s < 7; ++s)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int e = 0; e < 8; ++e) {
-          const int n = lane & 15, kg = lane >> 4;
-          float v = 0.f;
-          if (role < 2) {
-            const int tap = 16 + 32 * s + 8 * kg + e;
-            v = (role == 0 ? re : im)->data[n * 256 + tap];
-          } else if (s < 5) {
-            const int tap = 48 + 32 * s + 8 * kg + e;
-            v = (role == 2 ? re : im)->data[(16 + n) * 256 + tap];
-          } else {
-            const int tap = (role == 2 ? 64 : 128) + 32 * (s - 5) + 8 * kg + e;
-            if (n < 4)
-              v = re->data[(32 + n) * 256 + tap];
-            else if (n < 8)
-              v = im->data[(32 + n - 4) * 256 + tap];
-          }
-          const size_t base = (((size_t)role * 7 + s) * 2) * 64 * 8;
-          // taps pre-scaled by 2^12, residuals by a further 2^11 (kFmTapScale / kLoScale in cqt_mfma.hip)
-          put_split(out, base, base + 64 * 8, (size_t)lane * 8 + e, v * 4096.0f, 2048.0f);
-        }
 }
 
 // cqt_planes.hip filterbank: [29 step-fragments][hi|lo][64 lanes][8] f16.  Column groups of 16: 0 = re of filters 0..15,
@@ -747,7 +664,7 @@ void pack_filterbank_planes(const Tensor* re, const Tensor* im, std::vector<uint
 }
 
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->planes, h->d_dec_hfrag, h->d_fbh_bfrag, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wrim, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_cb_wfrag, h->d_cb_wf32, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->planes, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wrim, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->fb_scratch, h->pcm_dev, h->mono_dev, h->res_dev, reinterpret_cast<float*>(h->taps_dev)};
@@ -809,13 +726,6 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
     launch_filterbank(audio_dev, h->pyr, h->d_fb_bfrag, h->d_sqrt_len, h->lp, h->mm, h->fb_scratch, n, h->kc,
                       h->n_cu, s);
     BP_MARK(BP_STAGE_FILTERBANK);
-  } else if (h->cqt_staged) {
-    launch_pyramid_mfma(audio_dev, h->pyr, h->d_dec_hfrag, n, h->ext, s);
-    BP_MARK(BP_STAGE_PYRAMID);
-    // the per-window extrema are folded from the partials inside zpack (one launch and one boundary fewer)
-    launch_filterbank_mfma(audio_dev, h->pyr, h->d_fbh_bfrag, h->d_sqrt_len, h->lp, nullptr, h->fb_scratch, n,
-                           h->kc, h->n_cu, h->ext, s);
-    BP_MARK(BP_STAGE_FILTERBANK);
   } else {
     uint16_t* pl = reinterpret_cast<uint16_t*>(h->planes);
     launch_pyramid_planes(audio_dev, h->win_len, pl, h->d_pl_tfrag, n, h->n_cu, h->ext, s);
@@ -840,18 +750,12 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
     BP_MARK(BP_STAGE_ONSET2);
   } else {
     if (!zp_done) {
-      launch_zpack_partials(h->lp, h->fb_scratch,
-                            h->cqt_staged ? filterbank_mfma_partials(h->ext) : filterbank_planes_partials(h->ext),
-                            reinterpret_cast<uint32_t*>(h->zp), n, h->kc, h->n_bins, s);
+      // fewer windows than CUs: the filterbank left per-tile extrema, folded here by every workgroup for itself
+      launch_zpack_partials(h->lp, h->fb_scratch, filterbank_planes_partials(h->ext), reinterpret_cast<uint32_t*>(h->zp), n,
+                            h->kc, h->n_bins, s);
       BP_MARK(BP_STAGE_ZPACK);
     }
-    if (h->fused_contour) {
-      BP_DOM_BEGIN();
-      launch_contour_branch(reinterpret_cast<const uint32_t*>(h->zp), h->d_cb_wfrag, h->d_cb_wf32, contour_dev, n,
-                            h->n_cu, s);
-      BP_DOM_END(BP_STAGE_CONTOUR);
-      BP_MARK(BP_STAGE_CONTOUR);
-    } else {
+    {
       if (contour_conv1_full()) BP_DOM_BEGIN();
       if (contour_conv1_full() || h->rim_exact)
         launch_contour_conv1_exact(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wlds, h->d_d1_bias, h->c1s, n,
@@ -876,10 +780,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
       launch_contour_conv2(h->c1s, h->d_d2_w, h->b_contour2, contour_dev, n, h->n_cu, s);
       BP_MARK(BP_STAGE_CONTOUR_CONV2);
     }
-    if (h->note_ring)
-      launch_note_branch(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, h->n_cu, wlo, s);
-    else
-      launch_note_march(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, wlo, s);
+    launch_note_march(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, wlo, s);
     BP_MARK(BP_STAGE_NOTE);
     launch_onset_branch(reinterpret_cast<const uint32_t*>(h->zp), note_dev, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx,
                         onset_dev, n, h->n_cu, wlo, s);
@@ -1041,22 +942,9 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     };
     std::vector<uint16_t> frag;
     pack_decimator_f16(lowp, frag);
-    if ((rc = upload(h, raw_of(frag), &h->d_dec_hfrag))) return fail(rc);
-    pack_filterbank_f16(re, im, frag);
-    if ((rc = upload(h, raw_of(frag), &h->d_fbh_bfrag))) return fail(rc);
-    pack_decimator_f16(lowp, frag, 1);
     if ((rc = upload(h, raw_of(frag), &h->d_pl_tfrag))) return fail(rc);
     pack_filterbank_planes(re, im, frag);
     if ((rc = upload(h, raw_of(frag), &h->d_pl_bfrag))) return fail(rc);
-    {
-      const char* ec = std::getenv("BP_CQT");
-      h->cqt_staged = ec && std::strcmp(ec, "staged") == 0;
-    }
-    pack_contour_branch(c1w, c2w, frag);
-    std::vector<float> cb32(9, 0.f);
-    for (int i = 0; i < 8; ++i) cb32[i] = c1b->data[i];
-    cb32[8] = c2b->data[0];
-    if ((rc = upload(h, raw_of(frag), &h->d_cb_wfrag)) || (rc = upload(h, cb32, &h->d_cb_wf32))) return fail(rc);
     pack_contour_direct(c1w, frag);
     std::vector<float> w2t(200);
     for (int dt = 0; dt < 5; ++dt)
@@ -1093,12 +981,6 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       // the extended 345-bin CQT (BP_FLAG_EXT_CQT_44K) feeds bins 309..344 into the high rim: its GEMM table is built for
       // the model's 309 bins, so that mode stays on the exact kernel
       h->rim_exact = (er && std::strcmp(er, "exact") == 0) || (flags & BP_FLAG_EXT_CQT_44K);
-    }
-    {
-      const char* e = std::getenv("BP_CONTOUR_PATH");
-      h->fused_contour = e && std::strcmp(e, "fused") == 0;
-      const char* en = std::getenv("BP_NOTE_PATH");  // "ring": the round-1 workgroup kernel (A/B runs)
-      h->note_ring = en && std::strcmp(en, "ring") == 0;
     }
     for (int br = 0; br < 2; ++br) {
       pack_branch(br ? 13 : 4, br ? o1w : n1w, br ? o2w : n2w, br == 1, frag);
@@ -1648,8 +1530,6 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
       if ((ok = need(bf->audio) && need(bf->pyr))) {
         if (h->flags & BP_FLAG_F32_MFMA) {
           launch_pyramid(bf->audio, bf->pyr, h->d_lowpass, n, s);
-        } else if (h->cqt_staged) {
-          launch_pyramid_mfma(bf->audio, bf->pyr, h->d_dec_hfrag, n, h->ext, s);
         } else {  // the planes pyramid, its levels converted to the fp32 rows the test compares
           if (n > h->cap) {
             h->err = "bp_run_stage: pyramid needs n_windows <= max_windows (internal planes buffer)";
@@ -1672,9 +1552,6 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
         if (h->flags & BP_FLAG_F32_MFMA)
           launch_filterbank(bf->audio, bf->pyr, h->d_fb_bfrag, h->d_sqrt_len, bf->lp, bf->mm, h->fb_scratch, n,
                             h->kc, h->n_cu, s);
-        else if (h->cqt_staged)
-          launch_filterbank_mfma(bf->audio, bf->pyr, h->d_fbh_bfrag, h->d_sqrt_len, bf->lp, bf->mm,
-                                 h->fb_scratch, n, h->kc, h->n_cu, h->ext, s);
         else {  // the given fp32 levels split into planes (test hook), then the planes filterbank
           if (n > h->cap) {
             h->err = "bp_run_stage: filterbank needs n_windows <= max_windows (internal planes buffer)";
@@ -1721,9 +1598,7 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
       break;
     case BP_STAGE_CONTOUR:
       if ((ok = need(bf->zp) && need(bf->contour))) {
-        if (h->fused_contour) {
-          launch_contour_branch(bf->zp, h->d_cb_wfrag, h->d_cb_wf32, bf->contour, n, h->n_cu, s);
-        } else if (n > h->cap) {
+        if (n > h->cap) {
           h->err = "bp_run_stage: contour needs n_windows <= max_windows (internal c1 buffer)";
           return BP_ERR_INVALID_ARG;
         } else {
@@ -1744,10 +1619,7 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
       break;
     case BP_STAGE_NOTE:
       if ((ok = need(bf->contour) && need(bf->note)))
-        if (h->note_ring)
-          launch_note_branch(bf->contour, h->d_note_wfrag, h->d_note_wf32, bf->note, n, h->n_cu, wlo, s);
-        else
-          launch_note_march(bf->contour, h->d_note_wfrag, h->d_note_wf32, bf->note, n, wlo, s);
+        launch_note_march(bf->contour, h->d_note_wfrag, h->d_note_wf32, bf->note, n, wlo, s);
       break;
     case BP_STAGE_ONSET:
       if ((ok = need(bf->zp) && need(bf->note) && need(bf->onset)))

@@ -1,12 +1,11 @@
-// Fused note branch and fused onset branch — split-precision matrix-core kernels (default path).
+// Fused onset branch — split-precision matrix-core kernel (default path); also home of zpack_kernel.  (The note branch,
+// which shared this skeleton in round 1, lives in note_march.hip since round 2; its workgroup kernel was retired in round 3.)
 //
-//   note  branch (basic_pitch/models.py:266-290): Conv2D 1->32, 7x7, strides (1,3), "same", ReLU on the
-//                sigmoid contour map, then Conv2D 32->1, (7,3), "same", sigmoid           -> note
 //   onset branch (basic_pitch/models.py:295-318): Conv2D 8->32, 5x5, strides (1,3), "same", folded BN,
 //                ReLU on the harmonic stack (nn.py:69-88), Concatenate([note, features]) (305),
 //                Conv2D 33->1, 3x3, "same", sigmoid                                      -> onset
 //
-// Both branches are "conv (many taps) -> 32 channels -> conv (few taps) -> 1 channel".  The 32-channel
+// The branch is "conv (many taps) -> 32 channels -> conv (few taps) -> 1 channel".  The 32-channel
 // intermediate (1.9 MB / window each way in the unfused kernels, conv_stride3.hip + conv_heads.hip) never
 // leaves the CU here:
 //
@@ -59,28 +58,6 @@ struct BranchParams {
 };
 
 // ---- branch descriptions ----------------------------------------------------------------------
-struct NoteBr {
-  static constexpr bool kOnset = false;
-  static constexpr int KS1 = 4;             // conv1 k-steps: (frame-tap pair) x 8 adjacent bins (7 + 1 zero)
-  static constexpr int PH1 = 3;             // conv1 frame padding (ONNX pads [3,2,3,2])
-  static constexpr int ND = 8;              // frame offsets touched (dt = 7 is a zero-weight dummy)
-  static constexpr int KH2 = 7, PH2 = 3;    // conv2 frames
-  static constexpr int SLOTS = kFreqN;      // slot (row, w) = contour bins 3w-2 .. 3w+5
-  static constexpr int RING = kBrRows + 2 * PH1;
-  static constexpr int QRING = kBrRows + 2 * PH2;
-  static constexpr int PIECE = 4;           // rows per staging call (2 tasks of 8 loads per thread)
-  static constexpr int DT0 = 4;             // conv2 frame taps whose projections land in lane half 0 (the rest: half 1)
-  static constexpr int RAW_ROW = kFreqC / 4;  // 16-byte units of a source row brought in by LDS-DMA (264 floats)
-  static constexpr int RAW_PAD = 1;         // units in front of the rows (slot w = 0 reads bins -2, -1: masked)
-  static constexpr int RAW_UNITS = RAW_PAD + kBrRows * RAW_ROW + 2;
-  static constexpr int CHUNKS = 2;          // time chunks per window (work items = windows x CHUNKS)
-  static constexpr int WGS = 2;             // workgroups per CU (3 chunks x 3 resident: 0.138 vs 0.130 ms, the third
-                                            // chunk's halo and prologue cost more than the third wave per SIMD hides)
-  static __device__ constexpr int d_of(int s, int h) { return 2 * s + h; }
-  static __device__ constexpr int x_of(int, int) { return 0; }
-  static __device__ __forceinline__ int lane_slot(int wc) { return wc; }
-};
-
 struct OnsetBr {
   static constexpr bool kOnset = true;
   static constexpr int KS1 = 13;            // conv1 k-steps: (tap pair of the 5x5 window) x 8 channels
@@ -132,78 +109,14 @@ __device__ __forceinline__ uint4 fp8_slot(const uint4 vh, const uint4 vl) {
 // Tasks (row, slot) are dealt round-robin to the 256 threads; a thread first ISSUES the loads of all its tasks
 // (NT x 8 in flight), then splits / packs and writes them: the global-load latency is paid once per call, not once
 // per task.  Slots that are zero for every row (onset: the two padding bins of "same") are written by init_rows.
-// note branch: the staging of NROWS contour rows as two halves (issue all loads, then split and write).  Issuing them a
-// phase (or a barrier) ahead was measured twice: with loads pending the compiler / hardware wait for them at the top of
-// every tile or at the barrier anyway, so the two halves run back to back
-template <int NROWS>
-struct NoteStage {
-  static constexpr int NT = (NROWS * kFreqN + kBrThreads - 1) / kBrThreads;
-  float v[NT][8];
-  int dst[NT];   // image slot, -1: no task
-  int edge[NT];  // 0: inside, 1: w = 0 (bins -2, -1 are padding), 2: w = 87 (bins 264 .. 266 are padding), 3: row outside
-};
-
-template <class Br, int NROWS>
-__device__ __forceinline__ void note_stage_issue(const BranchParams& p, int b, int row_first, int tid,
-                                                 NoteStage<NROWS>& st) {
-  constexpr int NT = NoteStage<NROWS>::NT;
-#pragma unroll
-  for (int k = 0; k < NT; ++k) {
-    const int e = tid + k * kBrThreads;
-    st.dst[k] = -1;
-    if (e < NROWS * kFreqN) {
-      const int rr = e / kFreqN, w = e - rr * kFreqN;
-      const int row = row_first + rr;
-      const bool rvalid = row >= 0 && row < kFrames;
-      const float* src = static_cast<const float*>(p.src) + ((int64_t)b * kFrames + (rvalid ? row : 0)) * kFreqC;
-      st.dst[k] = ((row + 64 * Br::RING) % Br::RING) * Br::SLOTS + w;
-      st.edge[k] = !rvalid ? 3 : (w == 0 ? 1 : (w == kFreqN - 1 ? 2 : 0));
-      // unconditional loads from clamped addresses; what is padding is zeroed at commit (a select right after the load
-      // would make the issue side wait for the data)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        int bin = 3 * w + i - 2;
-        bin = bin < 0 ? 0 : (bin > kFreqC - 1 ? kFreqC - 1 : bin);
-        st.v[k][i] = src[bin];
-      }
-    }
-  }
-}
-
-template <int NROWS>
-__device__ __forceinline__ void note_stage_commit(const NoteStage<NROWS>& st, uint4* __restrict__ img_hi,
-                                                  uint4* __restrict__ img_lo) {
-#pragma unroll
-  for (int k = 0; k < NoteStage<NROWS>::NT; ++k) {
-    if (st.dst[k] < 0) continue;
-    uint4 vh{0u, 0u, 0u, 0u}, vl{0u, 0u, 0u, 0u};
-    if (st.edge[k] != 3) {
-      float v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = st.v[k][i];
-      if (st.edge[k] == 1) v[0] = v[1] = 0.0f;
-      if (st.edge[k] == 2) v[5] = v[6] = v[7] = 0.0f;  // bins 264, 265 and the zero-weight dummy tap
-      split_f16x2(f32x2{v[0], v[1]}, vh.x, vl.x);
-      split_f16x2(f32x2{v[2], v[3]}, vh.y, vl.y);
-      split_f16x2(f32x2{v[4], v[5]}, vh.z, vl.z);
-      split_f16x2(f32x2{v[6], v[7]}, vh.w, vl.w);
-    }
-    img_hi[st.dst[k]] = vh;
-    img_lo[st.dst[k]] = vl;
-  }
-}
-
 template <class Br, int NROWS, bool MX = false>
 __device__ __forceinline__ void stage_rows(const BranchParams& p, int b, int row_first,
                                            uint4* __restrict__ img_hi, uint4* __restrict__ img_lo, int tid) {
   constexpr int PER_ROW = Br::kOnset ? kFreqC : Br::SLOTS;       // tasks per row
   constexpr int NT = (NROWS * PER_ROW + kBrThreads - 1) / kBrThreads;
   constexpr int ntask = NROWS * PER_ROW;
-  if constexpr (!Br::kOnset) {
-    NoteStage<NROWS> st;
-    note_stage_issue<Br, NROWS>(p, b, row_first, tid, st);
-    note_stage_commit<NROWS>(st, img_hi, img_lo);
-  } else {
+  static_assert(Br::kOnset, "the onset branch is the only tenant");
+  {
     // stack bin f -> slot f + 1; zp is zero outside the CQT and in its pad frames -1 / 172 (bp_common.h): only rows
     // further outside the window need a guard
     uint32_t u[NT][8];
@@ -282,9 +195,6 @@ __device__ __forceinline__ void raw_dma_issue(const BranchParams& p, int b, int 
     const bool rvalid = row >= -1 && row <= kFrames;
     src = reinterpret_cast<const float*>(static_cast<const uint32_t*>(p.src) + (int64_t)b * kZWin +
                                          (int64_t)((rvalid ? row : -1) + 1) * kZRow + Br::RAW_W0);
-  } else {
-    if (row < 0 || row >= kFrames) return;  // rows outside the window are zeroed at the conversion
-    src = static_cast<const float*>(p.src) + ((int64_t)b * kFrames + row) * kFreqC;
   }
   uint4* dst = raw + Br::RAW_PAD + wave * Br::RAW_ROW;
 #pragma unroll
@@ -323,22 +233,6 @@ __device__ __forceinline__ void raw_convert(int row_first, const uint4* raw_, ui
       const int dst = ((row + 64 * Br::RING) % Br::RING) * Br::SLOTS + f + 1;
       img_hi[dst] = vh;
       img_lo[dst] = MX ? fp8_slot(vh, vl) : vl;
-    } else {
-      if (row >= 0 && row < kFrames) {
-        const float* fl = reinterpret_cast<const float*>(raw + Br::RAW_PAD + rr * Br::RAW_ROW) + 3 * f - 2;
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = fl[i];
-        if (f == 0) v[0] = v[1] = 0.0f;
-        if (f == kFreqN - 1) v[5] = v[6] = v[7] = 0.0f;
-        split_f16x2(f32x2{v[0], v[1]}, vh.x, vl.x);
-        split_f16x2(f32x2{v[2], v[3]}, vh.y, vl.y);
-        split_f16x2(f32x2{v[4], v[5]}, vh.z, vl.z);
-        split_f16x2(f32x2{v[6], v[7]}, vh.w, vl.w);
-      }
-      const int dst = ((row + 64 * Br::RING) % Br::RING) * Br::SLOTS + f;
-      img_hi[dst] = vh;
-      img_lo[dst] = vl;
     }
   }
 }
@@ -752,14 +646,10 @@ static void launch_branch(const BranchParams& p, int n_cu, bool weights_have_lo,
     fprintf(stderr, "brprof %s: %d workgroups resident per CU\n", Br::kOnset ? "onset" : "note", resident);
     if (hipMalloc(&q.prof, sizeof hbuf) != hipSuccess) return;
     (void)hipMemsetAsync(q.prof, 0, sizeof hbuf, stream);
-    if constexpr (Br::kOnset) {
-      if (p.wmx)
-        hipLaunchKernelGGL((branch_kernel<Br, true, true, true>), dim3(grid), dim3(kBrThreads), 0, stream, q);
-      else
-        hipLaunchKernelGGL((branch_kernel<Br, true, true>), dim3(grid), dim3(kBrThreads), 0, stream, q);
-    } else {
+    if (p.wmx)
+      hipLaunchKernelGGL((branch_kernel<Br, true, true, true>), dim3(grid), dim3(kBrThreads), 0, stream, q);
+    else
       hipLaunchKernelGGL((branch_kernel<Br, true, true>), dim3(grid), dim3(kBrThreads), 0, stream, q);
-    }
     (void)hipMemcpyAsync(hbuf, q.prof, sizeof hbuf, hipMemcpyDeviceToHost, stream);
     (void)hipStreamSynchronize(stream);
     (void)hipFree(q.prof);
@@ -780,12 +670,6 @@ static void launch_branch(const BranchParams& p, int n_cu, bool weights_have_lo,
     hipLaunchKernelGGL((branch_kernel<Br, true>), dim3(grid), dim3(kBrThreads), 0, stream, p);
   else
     hipLaunchKernelGGL((branch_kernel<Br, false>), dim3(grid), dim3(kBrThreads), 0, stream, p);
-}
-
-void launch_note_branch(const float* contour, const void* wfrag, const float* wf32, float* note,
-                        int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream) {
-  BranchParams p{static_cast<const uint4*>(wfrag), wf32, contour, nullptr, note, n_windows, nullptr, nullptr};
-  launch_branch<NoteBr>(p, n_cu, weights_have_lo, stream);
 }
 
 // wmx: the fp8 correction fragments (pack_onset_mx) or null for the three-product f16 kernel

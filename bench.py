@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path (bp_infer_async: pyramid -> filterbank -> zpack -> 3 branches of the CNN
+One "step" = one pass of the hot path (bp_infer_async: pyramid -> filterbank + normalise -> 3 branches of the CNN
 -> three posteriorgrams) over one batch of 256 synthetic 2-second 22.05 kHz windows that is already
 resident in HBM (BASELINE.json configs[1]: "Batch=256 synthetic 2 s @ 22.05 kHz mono windows,
 1xMI355X, fp32"); outputs stay in HBM.  Every rank owns its own batch (windows are independent
@@ -38,13 +38,8 @@ BATCH = 256
 FLOP_PER_WINDOW = 1_048_159_296
 BYTES_PER_WINDOW = 478_096               # fp32 I/O: 175,376 in + 302,720 out
 C1_FLOP_PER_WINDOW = 680_030_208         # contour conv1: 2*8*8*3*39*172*264 (models.py:241-250)
-C2_FLOP_PER_WINDOW = 18_163_200          # contour conv2: 2*8*25*172*264 (models.py:254-263)
 F32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: dense f32 matrix peak (= f32 vector peak)
 F16_MFMA_PEAK_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
-# contour_branch_kernel (conv_contour.hip, BP_CONTOUR_PATH=fused) issues, per 32-position tile, 63 k-steps x 3 f16
-# MFMAs (hi*hi, lo*hi, hi*lo) of 32x32x16 for conv1 plus 4 waves x 2 for the conv2 tap projection; 186 tiles per
-# chunk, 2 chunks
-CB_EXECUTED_FLOP_PER_WINDOW = 2 * 186 * (63 * 3 + 4 * 2) * (2 * 32 * 32 * 16)
 # contour_conv1_folded_kernel (conv_contour_direct.hip) computes the 56 interior groups of every frame (bins 20..243,
 # 56/66 of conv1's products): 172 x 56 positions = 38 rounds of 256; per round each of the 8 waves issues 36 k-steps x 3
 # MFMAs (hi*hi, lo*hi, hi*lo).  BP_CONV1=full: the exact kernel over all 66 groups, 45 rounds x 8 waves x 63 x 3.
@@ -494,7 +489,7 @@ def main() -> None:
             c1_exec = 355 * 504 * (2 * 32 * 32 * 2) * B / (c1_ms * 1e-3) / 1e12
             c1_bytes = None
             c1_key = None
-        elif stage.get("contour_conv1", 0.0) > 0.0:
+        else:
             c1_ms = stage["contour_conv1"]
             folded = stage.get("contour_conv1_edge", 0.0) > 0.0
             mf = (2 / 3 if args.bf16_weights else 1)
@@ -524,15 +519,6 @@ def main() -> None:
                 c1_bytes = D1_BYTES_PER_WINDOW * B
                 c1_key = "contour_conv1_kernel"
             c1_peak = F16_MFMA_PEAK_TFLOPS
-        else:
-            c1_ms = stage["contour"]
-            c1_flop = C1_FLOP_PER_WINDOW + C2_FLOP_PER_WINDOW
-            c1_kernel = ("contour_branch_kernel (stack + Conv2D 8->8 3x39 + ReLU + Conv2D 8->1 5x5 + sigmoid fused; "
-                         "f16 MFMA 32x32x16 on hi/lo-split operands, fp32 accumulate)")
-            c1_peak = F16_MFMA_PEAK_TFLOPS
-            c1_exec = CB_EXECUTED_FLOP_PER_WINDOW * B / (c1_ms * 1e-3) / 1e12
-            c1_bytes = (214_656 + 181_632) * B
-            c1_key = "contour_branch_kernel"
         achieved = c1_flop * B / (c1_ms * 1e-3) / 1e12
         line = {
             "metric": "audio windows/sec (2 s @ 44.1 kHz) end-to-end CQT+CNN" if args.ext_cqt_44k
@@ -590,9 +576,11 @@ def main() -> None:
             "outputs_finite": ok,
         }
         if not args.ext_cqt_44k:
-            # the CQT stage (a7-a8: pyramid + filterbank, here with NormalizedLog's log fused in) against
-            # both of its rooflines; algorithmic 79,425,024 FLOP and 387,968 B (audio in + 172x309 fp32 out) per window
-            cqt_ms = stage["pyramid"] + stage["filterbank"]
+            # the CQT stage (a7-a9: pyramid + filterbank + NormalizedLog; since round 3 the filterbank
+            # launch also normalises, BatchNorms and splits the windows it owns — `zpack` is a stage of its own only when a
+            # launch has fewer windows than CUs) against both of its rooflines; algorithmic 79,425,024 FLOP and 387,968 B
+            # (audio in + 172x309 fp32 out) per window
+            cqt_ms = stage["pyramid"] + stage["filterbank"] + stage.get("zpack", 0.0)
             cqt_rate = B / (cqt_ms * 1e-3)
             # ceilings per window: HBM 387,968 B at 8 TB/s; split-f16 MFMA = 3 products x the dense matrices the two
             # kernels execute (decimators 22.4 MFLOP, filterbank 57.1 MFLOP clipped to the kernels' support) at the
@@ -600,6 +588,8 @@ def main() -> None:
             cqt_mfma_flop = 3 * (22_361_088 + 57_063_936)
             line["cqt_stage"] = {
                 "ms": cqt_ms,
+                "includes": "pyramid (planes) + filterbank + normalise / BatchNorm / split (zpack, fused into the filterbank "
+                            "launch at this batch)",
                 "windows_per_s": cqt_rate,
                 "hbm_fraction": 387_968 * cqt_rate / (HBM_PEAK_GBS * 1e9),
                 "mfma_split_f16_fraction": cqt_mfma_flop * cqt_rate / (F16_MFMA_PEAK_TFLOPS * 1e12),

@@ -171,24 +171,6 @@ def test_exact_f32_reference_path(cases):
         assert e_split <= e_f32 + 3e-5, (k, e_split, e_f32)
 
 
-def test_fused_contour_kernel_ab(cases, monkeypatch):
-    """BP_CONTOUR_PATH=fused swaps the two-kernel contour branch (conv_contour_direct.hip, default) for the
-    single fused kernel (conv_contour.hip).  Same operators, same split-precision products, different summation
-    order: the two must agree to fp32 rounding, and both with the fp64 oracle like any other path."""
-    from basic_pitch_amd import Model
-
-    x, r32, r64 = cases
-    outs = {}
-    for name in ("direct", "fused"):
-        monkeypatch.setenv("BP_CONTOUR_PATH", name)
-        m = Model(max_windows=8)
-        outs[name] = m.predict(x)
-        m.close()
-    for k in ("note", "onset", "contour"):
-        assert np.abs(outs["direct"][k] - outs["fused"][k]).max() <= 5e-6, k
-        assert np.abs(outs["fused"][k][:3] - r64[k][:3]).max() <= 1e-4, k
-
-
 def test_fp8_corrections_flag(cases):
     """BP_FLAG_FP8_CORRECTIONS (Model(fp8_corrections=True)) moves the correction products of the contour / onset conv1
     to the block-scaled fp8 instruction — an opt-in, reduced-precision mode.  On these noise-like windows both settings

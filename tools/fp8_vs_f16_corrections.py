@@ -1,4 +1,4 @@
-# How far the fp8 correction products move the three posteriorgrams (tools/): default path vs BP_FLAG_F16_CORRECTIONS on
+# How far the fp8 correction products move the three posteriorgrams (tools/): BP_FLAG_FP8_CORRECTIONS (opt-in) vs the default path (all-f16) on
 # the same windows, max and 99.9th percentile of |difference| per map, for noise-like and tonal windows.
 import os, sys
 import numpy as np
@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import make_windows
 from basic_pitch_amd import Model
-a, b = Model(max_windows=256), Model(max_windows=256, f16_corrections=True)
+a, b = Model(max_windows=256, fp8_corrections=True), Model(max_windows=256)  # fp8 opt-in mode, default (all-f16)
 for kind, n in (("uniform", 512), ("normal", 512), ("tones", 256)):
     x = make_windows(kind, n, 123)
     pa, pb = a.predict(x), b.predict(x)

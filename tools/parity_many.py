@@ -1,5 +1,5 @@
-# Whole-path deviation from the fp64 oracle over MANY noise-like windows (tools/): default path (fp8 corrections) and
-# BP_FLAG_F16_CORRECTIONS, max per map.  python tools/parity_many.py [n_windows_per_family]
+# Whole-path deviation from the fp64 oracle over MANY noise-like windows (tools/): BP_FLAG_FP8_CORRECTIONS (opt-in since round 3) and
+# the default (all-f16 split products), max per map.  python tools/parity_many.py [n_windows_per_family]
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,7 @@ from oracle import bp_oracle as O
 from basic_pitch_amd import Model
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 W = O.load_weights()
-a, b = Model(max_windows=256), Model(max_windows=256, f16_corrections=True)
+a, b = Model(max_windows=256, fp8_corrections=True), Model(max_windows=256)  # fp8 opt-in mode, default (all-f16)
 for kind in ("uniform", "normal"):
     x = make_windows(kind, n, 321)
     t0 = time.time()
