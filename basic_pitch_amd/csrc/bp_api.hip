@@ -186,6 +186,7 @@ struct bp_context {
   float *d_d1_wlds = nullptr, *d_d1_wfold = nullptr, *d_d1_wrim = nullptr, *d_d1_bias = nullptr,
         *d_d2_w = nullptr;
   bool rim_exact = false, fold_mx = false;
+  int contour_parts = 0;  // BP_CONTOUR_PARTS (0: automatic)
   float* d_d1_wfold_mx = nullptr;
   float* c1s = nullptr;  // [cap][172][kC1Row][8] relu(conv1); pad bins zeroed once at allocation
   // cqt_planes.hip: decimator / filterbank fragments (raw bytes of f16 hi / lo), the planes of a chunk [cap][2][stride] f16
@@ -213,8 +214,9 @@ struct bp_context {
 
   // stage timing: a ring of event sets, one per chunk, averaged by bp_get_stage_ms
   static constexpr int kTimedRing = 128;
-  hipEvent_t ev[kTimedRing][BP_N_STAGES + 1] = {};
-  int seq[BP_N_STAGES] = {};  // stage id of the interval between ev[.][i] and ev[.][i+1]
+  static constexpr int kMaxMarks = 32;  // a stage may be launched in parts (the contour branch): its intervals are summed
+  hipEvent_t ev[kTimedRing][kMaxMarks + 1] = {};
+  int seq[kMaxMarks] = {};  // stage id of the interval between ev[.][i] and ev[.][i+1]; -1: not a stage (skipped)
   int n_seq = 0;
   bool ev_valid = false;
   int64_t timed_chunks = 0;  // chunks recorded since the last bp_get_stage_ms
@@ -696,19 +698,24 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
   // BP_FLAG_TIME_DOMINANT: events only around the dominant kernel
   const bool dom = !timing && (h->flags & BP_FLAG_TIME_DOMINANT) && !(h->flags & BP_FLAG_F32_MFMA);
   const bool wlo = !(h->flags & BP_FLAG_BF16_WEIGHTS);  // conv weights carry an f16 lo part
-  int e = 0;
+  int e = dom ? -1 : 0;  // index of the last event recorded
   hipEvent_t* ev = h->ev[h->timed_chunks % bp_context::kTimedRing];
   if (timing) BP_HIP(hipEventRecord(ev[0], s));
+  // dominant-kernel timing: one (begin, end) pair per launch of the kernel; the interval between two pairs is no stage
 #define BP_DOM_BEGIN()                                \
   do {                                                \
-    if (dom) BP_HIP(hipEventRecord(ev[0], s));        \
+    if (dom) {                                        \
+      if (e >= 0) h->seq[e] = -1;                     \
+      BP_HIP(hipEventRecord(ev[e + 1], s));           \
+      ++e;                                            \
+    }                                                 \
   } while (0)
 #define BP_DOM_END(id)                                \
   do {                                                \
     if (dom) {                                        \
-      h->seq[0] = (id);                               \
-      BP_HIP(hipEventRecord(ev[1], s));               \
-      e = 1;                                          \
+      h->seq[e] = (id);                               \
+      BP_HIP(hipEventRecord(ev[e + 1], s));           \
+      ++e;                                            \
     }                                                 \
   } while (0)
   // closes the interval of stage `id` (the kernels launched since the previous mark)
@@ -755,29 +762,35 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
                             h->kc, h->n_bins, s);
       BP_MARK(BP_STAGE_ZPACK);
     }
-    {
+    // The contour branch can run in parts of a chunk (BP_CONTOUR_PARTS=2: rim, folded conv1, conv2 of windows 0..127, then
+    // of 128..255), so that conv1's 1.48 MB of c1 per window stay inside the 256 MB Infinity Cache until conv2 reads them.
+    // Measured in round 3 at B = 256: conv2 0.115 -> 0.107 ms, but folded conv1 0.228 -> 0.239 and rim 0.072 -> 0.081 (each
+    // part pays the kernels' prologue again): 0.852 vs 0.844 ms per step.  Kept as a tool; one part is the default.
+    const int parts = h->contour_parts > 0 ? h->contour_parts : 1;
+    for (int part = 0; part < parts; ++part) {
+      const int w0 = (int)((int64_t)n * part / parts), nw = (int)((int64_t)n * (part + 1) / parts) - w0;
+      if (nw <= 0) continue;
+      const uint32_t* zpp = reinterpret_cast<const uint32_t*>(h->zp) + (int64_t)w0 * kZWin;
+      float* c1p = h->c1s + (int64_t)w0 * kC1Win;
       if (contour_conv1_full()) BP_DOM_BEGIN();
       if (contour_conv1_full() || h->rim_exact)
-        launch_contour_conv1_exact(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wlds, h->d_d1_bias, h->c1s, n,
-                                   h->n_cu, wlo, s);
+        launch_contour_conv1_exact(zpp, h->d_d1_wlds, h->d_d1_bias, c1p, nw, h->n_cu, wlo, s);
       else
-        launch_contour_conv1_rim(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wrim, h->d_d1_bias, h->c1s, n, wlo,
-                                 s);
+        launch_contour_conv1_rim(zpp, h->d_d1_wrim, h->d_d1_bias, c1p, nw, wlo, s);
       if (!contour_conv1_full()) {
         BP_MARK(BP_STAGE_CONTOUR_CONV1_EDGE);
         BP_DOM_BEGIN();
         if (h->fold_mx && wlo) {
           const char* base = reinterpret_cast<const char*>(h->d_d1_wfold_mx);
-          launch_contour_conv1_fold_mx(reinterpret_cast<const uint32_t*>(h->zp), base, base + 36 * 64 * 16,
-                                       base + 36 * 64 * 16 + 18 * 64 * 32, h->d_d1_bias, h->c1s, n, h->n_cu, s);
+          launch_contour_conv1_fold_mx(zpp, base, base + 36 * 64 * 16, base + 36 * 64 * 16 + 18 * 64 * 32, h->d_d1_bias, c1p,
+                                       nw, h->n_cu, s);
         } else {
-          launch_contour_conv1_folded(reinterpret_cast<const uint32_t*>(h->zp), h->d_d1_wfold, h->d_d1_bias, h->c1s, n,
-                                      h->n_cu, wlo, s);
+          launch_contour_conv1_folded(zpp, h->d_d1_wfold, h->d_d1_bias, c1p, nw, h->n_cu, wlo, s);
         }
       }
       BP_DOM_END(BP_STAGE_CONTOUR_CONV1);
       BP_MARK(BP_STAGE_CONTOUR_CONV1);
-      launch_contour_conv2(h->c1s, h->d_d2_w, h->b_contour2, contour_dev, n, h->n_cu, s);
+      launch_contour_conv2(c1p, h->d_d2_w, h->b_contour2, contour_dev + (int64_t)w0 * kPlaneC, nw, h->n_cu, s);
       BP_MARK(BP_STAGE_CONTOUR_CONV2);
     }
     launch_note_march(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, wlo, s);
@@ -790,7 +803,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
 #undef BP_DOM_BEGIN
 #undef BP_DOM_END
   if (timing || dom) {
-    h->n_seq = e;
+    h->n_seq = e < 0 ? 0 : e;
     h->timed_chunks++;
   }
   BP_HIP(hipGetLastError());
@@ -976,6 +989,7 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       if ((rc = upload(h, raw, &h->d_d1_wfold_mx))) return fail(rc);
       h->fold_mx = true;
     }
+    if (const char* ep = std::getenv("BP_CONTOUR_PARTS")) h->contour_parts = std::atoi(ep) > 8 ? 8 : std::atoi(ep);
     {
       const char* er = std::getenv("BP_RIM");  // "exact": the round-1 rim kernel on the 8-channel form (A/B runs)
       // the extended 345-bin CQT (BP_FLAG_EXT_CQT_44K) feeds bins 309..344 into the high rim: its GEMM table is built for
@@ -1501,6 +1515,7 @@ int bp_get_stage_ms(bp_handle h, float* ms, int n) {
   for (int64_t c = 0; c < cnt; ++c) {
     for (int i = 0; i < h->n_seq; ++i) {
       float t = 0.f;
+      if (h->seq[i] < 0) continue;
       BP_HIP(hipEventElapsedTime(&t, h->ev[c][i], h->ev[c][i + 1]));
       acc[h->seq[i]] += t;
     }
