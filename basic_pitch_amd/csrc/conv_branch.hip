@@ -73,7 +73,10 @@ struct OnsetBr {
   static constexpr int RAW_ROW = 101;       // 16-byte units: words 20 .. 423 (bins -36 .. 263 + 101 and the tail)
   static constexpr int RAW_PAD = 0;
   static constexpr int RAW_UNITS = RAW_PAD + kBrRows * RAW_ROW;
-  static constexpr int CHUNKS = 2;
+#ifndef BP_ONSET_CHUNKS
+#define BP_ONSET_CHUNKS 2
+#endif
+  static constexpr int CHUNKS = BP_ONSET_CHUNKS;  // time chunks per window (work items = windows x CHUNKS)
   static constexpr int WGS = 2;
   static __device__ constexpr int d_of(int s, int h) { return (2 * s + h) / 5; }
   static __device__ constexpr int x_of(int s, int h) { return (2 * s + h) % 5; }

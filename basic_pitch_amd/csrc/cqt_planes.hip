@@ -484,6 +484,10 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
   __shared__ int s_off[10];
   __shared__ int s_next;
   __shared__ float2 s_mm[FUSED ? 10 * kPlTilesPerLevel : 1];
+  // FUSED: the log-power values of the four top levels (144 bins x 172 frames = 97 KB: what is left of the CU's LDS) wait
+  // for the normalise phase here instead of making the round trip through L2 / HBM
+  constexpr int kLdsBins = 4 * kBpo;
+  __shared__ float s_lp[FUSED ? kFrames * kLdsBins : 1];
 #if defined(PL_FB_PROF)
   const unsigned long long pentry = __builtin_amdgcn_s_memtime();
 #endif
@@ -611,8 +615,11 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
     // `masked` (wave-uniform): the tile has padding frames (the 11th tile) or the level has bins below the CQT's first
     // (the deepest level): 8 of 10 tasks have neither, and then only group 4's unused columns need a predicate
     const bool masked = tile == kPlTilesPerLevel - 1 || bin0 < 0;
-    auto finish = [&](auto masked_c, const f32x4& hr, const f32x4& xr, const f32x4& hi_, const f32x4& xi, int k, bool col_ok) {
-      constexpr bool kMasked = decltype(masked_c)::value;
+    const bool to_lds = FUSED && level < 4;  // wave-uniform
+    float* lds_t = s_lp + (16 * tile + 4 * kg) * kLdsBins + (3 - level) * kBpo;
+    auto finish = [&](auto masked_c, auto lds_c, const f32x4& hr, const f32x4& xr, const f32x4& hi_, const f32x4& xi, int k,
+                      bool col_ok) {
+      constexpr bool kMasked = decltype(masked_c)::value, kLds = decltype(lds_c)::value;
       const bool bin_ok = col_ok && (!kMasked || bin0 + k >= 0);
       // * sqrt(lengths) (nnaudio.py:650, before squaring) and the taps' 2^-12 in one factor: a power of two commutes
       // with the rounding of the product
@@ -627,18 +634,24 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
         const float pw = __fmul_rn(mag, mag);
         v[r] = __fmul_rn(__builtin_amdgcn_logf(__fadd_rn(pw, kc.eps)), kln2);
       }
+      auto put = [&](int r) {
+        if constexpr (kLds)
+          lds_t[r * kLdsBins + k] = v[r];
+        else
+          lp_t[r * g.n_bins + k] = v[r];
+      };
       if constexpr (kMasked) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (bin_ok && fr0 + r < kFrames) {
-            lp_t[r * g.n_bins + k] = v[r];
+            put(r);
             vmin = fminf(vmin, v[r]);
             vmax = fmaxf(vmax, v[r]);
           }
       } else if (bin_ok) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          lp_t[r * g.n_bins + k] = v[r];
+          put(r);
           vmin = fminf(vmin, v[r]);
           vmax = fmaxf(vmax, v[r]);
         }
@@ -650,14 +663,21 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
                        pl_from_lane_plus4(hh[4][3])};
     const f32x4 xi4 = {pl_from_lane_plus4(xx[4][0]), pl_from_lane_plus4(xx[4][1]), pl_from_lane_plus4(xx[4][2]),
                        pl_from_lane_plus4(xx[4][3])};
-    if (masked) {
-      finish(std::true_type{}, hh[0], xx[0], hh[1], xx[1], t, true);
-      finish(std::true_type{}, hh[2], xx[2], hh[3], xx[3], 16 + t, true);
-      finish(std::true_type{}, hh[4], xx[4], hi4, xi4, 32 + (t & 3), t < 4);
+    auto finish_all = [&](auto mc, auto lc) {
+      finish(mc, lc, hh[0], xx[0], hh[1], xx[1], t, true);
+      finish(mc, lc, hh[2], xx[2], hh[3], xx[3], 16 + t, true);
+      finish(mc, lc, hh[4], xx[4], hi4, xi4, 32 + (t & 3), t < 4);
+    };
+    if (to_lds) {
+      if (masked)
+        finish_all(std::true_type{}, std::true_type{});
+      else
+        finish_all(std::false_type{}, std::true_type{});
     } else {
-      finish(std::false_type{}, hh[0], xx[0], hh[1], xx[1], t, true);
-      finish(std::false_type{}, hh[2], xx[2], hh[3], xx[3], 16 + t, true);
-      finish(std::false_type{}, hh[4], xx[4], hi4, xi4, 32 + (t & 3), t < 4);
+      if (masked)
+        finish_all(std::true_type{}, std::false_type{});
+      else
+        finish_all(std::false_type{}, std::false_type{});
     }
     vmin = wave_min_lane63(vmin);
     vmax = wave_max_lane63(vmax);
@@ -699,20 +719,29 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
     constexpr int kZb = 7;
     const int n_items = kFrames * row_u4;
     for (int i0 = threadIdx.x; i0 < n_items; i0 += kZb * THREADS) {
+      const int lds_bin0 = g.n_bins - kLdsBins;  // bins from here on wait in LDS
       float4 v[kZb];
 #pragma unroll
       for (int k = 0; k < kZb; ++k) {
         const int i = i0 + k * THREADS;
         const int ic = i < n_items ? i : n_items - 1;
         const int t_ = ic / row_u4, g0 = 4 * (ic - t_ * row_u4);
-        v[k] = *reinterpret_cast<const float4*>(lpb + t_ * g.n_bins + g0);  // dword alignment is enough
+        v[k] = float4{0.f, 0.f, 0.f, 0.f};
+        if (g0 < lds_bin0) v[k] = *reinterpret_cast<const float4*>(lpb + t_ * g.n_bins + g0);  // dword alignment is enough
       }
 #pragma unroll
       for (int k = 0; k < kZb; ++k) {
         const int i = i0 + k * THREADS;
         if (i >= n_items) break;
         const int t_ = i / row_u4, g0 = 4 * (i - t_ * row_u4);
-        const float x4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        float x4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        if (g0 + 3 >= lds_bin0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = g0 + e - lds_bin0;
+            if (c >= 0 && c < kLdsBins) x4[e] = s_lp[t_ * kLdsBins + c];
+          }
+        }
         uint32_t u[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

@@ -31,7 +31,10 @@ namespace bp {
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
 constexpr int kNmWaves = 4;    // independent waves per workgroup
-constexpr int kNmChunks = 4;   // time chunks per window
+#ifndef BP_NOTE_CHUNKS
+#define BP_NOTE_CHUNKS 4
+#endif
+constexpr int kNmChunks = BP_NOTE_CHUNKS;   // time chunks per window
 constexpr int kNmStrips = 3;   // 32-pixel strips of a row, 30 inner pixels each
 constexpr int kNmRing = 10;    // image rows a wave keeps: r-3 .. r+4 in use, r+5 / r+6 being written
 constexpr int kNmKS1 = 4, kNmPH1 = 3, kNmPH2 = 3;
