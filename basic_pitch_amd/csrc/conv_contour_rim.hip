@@ -34,7 +34,11 @@ constexpr int kRimWaves = 5;              // M blocks of 32 rows: 20 bins x 8 ch
 constexpr int kRimBins = 144;             // z bins per frame a side reads (multiple of 16)
 constexpr int kRimStepsDt = kRimBins / 16;  // 9 k-steps per frame tap
 constexpr int kRimSteps = 3 * kRimStepsDt;  // 27
-constexpr int kRimFrames = 64;            // frames per work item: two 32-column tiles
+#ifndef BP_RIM_FRAMES
+#define BP_RIM_FRAMES 64
+#endif
+constexpr int kRimFrames = BP_RIM_FRAMES;  // frames per work item: kRimNT 32-column tiles
+constexpr int kRimNT = kRimFrames / 32;
 constexpr int kRimTiles = (kFrames + kRimFrames - 1) / kRimFrames;  // 3
 constexpr int kRimRowU = 37;              // LDS row: 18 units hi | 18 units lo | 1 pad (odd: conflict-free)
 constexpr int kRimRows = kRimFrames + 2;
@@ -96,9 +100,9 @@ __global__ __launch_bounds__(64 * kRimWaves) void contour_conv1_rim_kernel(RimPa
   }
   __syncthreads();
 
-  f32x16 acc[2], accc[2];
+  f32x16 acc[kRimNT], accc[kRimNT];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < kRimNT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = accc[j][r] = 0.0f;
 
@@ -114,22 +118,22 @@ __global__ __launch_bounds__(64 * kRimWaves) void contour_conv1_rim_kernel(RimPa
     }
     const f16x8 fah = __builtin_bit_cast(f16x8, a_hi);
     const f16x8 fal = __builtin_bit_cast(f16x8, a_lo);
-    f16x8 bh[2], bl[2];
+    f16x8 bh[kRimNT], bl[kRimNT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < kRimNT; ++j) {
       const int at = lane_u + (32 * j + dt) * kRimRowU + 2 * e;
       bh[j] = __builtin_bit_cast(f16x8, img[at]);
       bl[j] = __builtin_bit_cast(f16x8, img[at + 18]);
     }
-    // the two column tiles alternate so that no MFMA waits for the one just issued
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bh[0], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bh[1], acc[1], 0, 0, 0);
+    // the column tiles alternate so that no MFMA waits for the one just issued
+#pragma unroll
+    for (int j = 0; j < kRimNT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bh[j], acc[j], 0, 0, 0);
     if (WLO) {
-      accc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, bh[0], accc[0], 0, 0, 0);
-      accc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, bh[1], accc[1], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < kRimNT; ++j) accc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, bh[j], accc[j], 0, 0, 0);
     }
-    accc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bl[0], accc[0], 0, 0, 0);
-    accc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bl[1], accc[1], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < kRimNT; ++j) accc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bl[j], accc[j], 0, 0, 0);
   }
 
   // ---- epilogue: C row i = (r & 3) + 8 (r >> 2) + 4 kh = 8 (bin of the block) + channel -> channels 4 kh .. 4 kh + 3
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(64 * kRimWaves) void contour_conv1_rim_kernel(RimPa
 #pragma unroll
   for (int c = 0; c < 4; ++c) bias4[c] = p.bias[4 * kh + c];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < kRimNT; ++j) {
     const int t = t0 + 32 * j + n;
     if (t < kFrames) {
       float* row = p.c1 + (((int64_t)b * kFrames + t) * kC1Row + kC1Pad + rim_f0(side) + 4 * wave) * 8 + 4 * kh;

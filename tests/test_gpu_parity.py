@@ -436,6 +436,14 @@ def test_batch_invariance_and_chunking(weights):
     r32 = O.forward(x[idx], weights, np.float32)
     _noise_aware(d, r32, r64)
     big.close(), small.close()
+    # more windows than CUs in one launch: the fused filterbank's workgroups then own several windows each, and the
+    # decimators' queues wrap (the round-3 CQT kernels) — still the same bits
+    many = Model(max_windows=600)
+    x600 = np.concatenate([x, x[::-1], x[:88]])
+    e = many.predict(x600)
+    for k in a:
+        assert np.array_equal(e[k][:256], a[k]) and np.array_equal(e[k][256:512], a[k][::-1]) and np.array_equal(e[k][512:], a[k][:88]), k
+    many.close()
 
 
 def test_edge_cases():
