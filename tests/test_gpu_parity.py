@@ -311,6 +311,14 @@ def test_extended_cqt_44k_mode(weights):
     # 48 kHz stereo PCM is resampled to the handle's 44.1 kHz on the device
     pcm = rng.uniform(-0.5, 0.5, (48000, 2)).astype(np.float32)
     assert m.resample(pcm, 48000).shape == (44100,)
+    # a launch with a window for every second CU takes the fused filterbank + normalise path (10 levels, 345 bins):
+    # bit-identical to the strided path of the small handle
+    xs = np.concatenate([x, x[::-1]] * 22)[:130]
+    big = Model(max_windows=130, ext_cqt_44k=True)
+    e = big.predict(xs)
+    for k in got:
+        assert np.array_equal(e[k][:3], got[k]) and np.array_equal(e[k][3:6], got[k][::-1]), k
+    big.close()
     m.close()
 
 
