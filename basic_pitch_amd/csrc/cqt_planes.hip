@@ -227,12 +227,15 @@ __device__ __forceinline__ void pl_split8(const float4& a, const float4& c, uint
 // F32IN = true:  the input is the fp32 signal `x` (level 0): rows are split in registers, and the tile also WRITES the
 //                level-0 planes (`in_hi` is then the level-0 region to fill): its sixteen own rows are exactly the 512
 //                elements [2 o0, 2 o0 + 512); tile 0 / the last tile add the reflect padding of level 0.
-template <bool F32IN>
+// MIRROR: the outputs also go to a second image of the output level (`mir_hi` = its sample 0, lo plane `mir_stride`
+//         elements behind; no padding there): the per-window kernel keeps the levels it reads again in LDS.
+template <bool F32IN, bool MIRROR = false>
 __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, const float* __restrict__ x,
                                             uint16_t* __restrict__ in_hi, int64_t stride, int L_in,
                                             uint16_t* __restrict__ out_hi, int L_out, int tile, int n_tiles,
                                             const uint4 (&th)[kPlDmSteps], const uint4* __restrict__ tlo,
-                                            uint4* __restrict__ rows, int lane) {
+                                            uint4* __restrict__ rows, int lane, uint16_t* mir_hi = nullptr,
+                                            int mir_stride = 0) {
   // keep the lo fragments in LDS: without an opaque offset the compiler hoists the 9 item-invariant reads into registers
   asm volatile("" : "+v"(lane));
   const int m = lane & 15, kg = lane >> 4;
@@ -327,6 +330,22 @@ __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, const float
     *reinterpret_cast<uint2*>(oh) = h2;
     *reinterpret_cast<uint2*>(oh + stride) = l2;
   }
+  if constexpr (MIRROR) {
+    if (mir_hi != nullptr) {  // wave-uniform
+      uint16_t* mh = mir_hi + n0;
+      if (n0 + 3 < L_out) {
+        *reinterpret_cast<uint2*>(mh) = h2;
+        *reinterpret_cast<uint2*>(mh + mir_stride) = l2;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n0 + r < L_out) {
+            mh[r] = (uint16_t)((r < 2 ? h2.x : h2.y) >> (16 * (r & 1)));
+            mh[mir_stride + r] = (uint16_t)((r < 2 ? l2.x : l2.y) >> (16 * (r & 1)));
+          }
+      }
+    }
+  }
   // the level's last (partial) group of four, and the reflect padding: the tiles that hold samples 1..128 and
   // L-129..L-2 write their mirror images (nnaudio.py:300-301).  Wave-uniform conditions, 16-bit stores.
   const bool tail = o0 + kPlTileOut > L_out - 130 || tile == 0;
@@ -411,31 +430,54 @@ __global__ __launch_bounds__(256, 4) void pl_decimate_kernel(const float* __rest
 }
 
 // The deeper levels of one window, one workgroup of 16 waves: a level is a few dozen tiles at most and depends on the one
-// above it, so as separate launches each would pay a launch boundary and a ramp for a few microseconds of work.  A level
-// written by this workgroup is read by this workgroup after a barrier (global memory, workgroup scope: same CU, same L1).
+// above it, so as separate launches each would pay a launch boundary and a ramp for a few microseconds of work.  The
+// levels this workgroup reads again stay in LDS (hi and lo plane of levels `lds_first` .. last - 1, samples only: the
+// decimator zero-pads, the two edge tiles of a level mask whatever lies beside the samples), so the seven dependent
+// steps pay an LDS round trip and a barrier each, not a store-acknowledge + L2 read (28 us for 3 us of matrix work);
+// every level is also written to its planes in HBM for the filterbank.
 struct PlTail {
-  int first, last;
+  int first, last, lds_first;
 };
 constexpr int kPlTailThreads = 1024;
+constexpr int kPlTailGuard = kPlPad;     // elements in front of the first resident level: tile 0 reads (and masks) them
+constexpr int kPlTailLdsElems = 21760;   // per plane: guard + levels 2..7 of the 22.05 kHz pyramid (each rounded up to 8)
+
+__host__ __device__ inline int pl_tail_lds_need(const PlGeo& g, int lds_first, int last) {
+  int n = kPlTailGuard;
+  for (int k = lds_first; k < last; ++k) n += (g.len[k] + 7) & ~7;
+  return n;
+}
 
 __global__ __launch_bounds__(kPlTailThreads) void pl_decimate_tail_kernel(uint16_t* __restrict__ pl, PlGeo g, PlTail t,
                                                                        const uint4* __restrict__ tfrag) {
   __shared__ __attribute__((aligned(16))) uint4 tlo[kPlDmSteps * 64];
   __shared__ __attribute__((aligned(16))) uint4 rows_all[(kPlTailThreads / 64) * kPlRowsU];
+  __shared__ __attribute__((aligned(16))) uint16_t s_pl[2 * kPlTailLdsElems];  // hi plane, lo plane
   uint4 th[kPlDmSteps];
   pl_load_tfrag(tfrag, th, tlo);
   const int lane = threadIdx.x & 63;
   const int wave = wave_id();
   uint4* rows = rows_all + wave * kPlRowsU;
   uint16_t* w = pl + (int64_t)blockIdx.x * 2 * g.stride;
+  int loff_in = 0, loff_out = kPlTailGuard;  // LDS element of sample 0 of the input / output level (when resident)
   for (int k = t.first; k <= t.last; ++k) {
     const int tiles = (g.len[k] + kPlTileOut - 1) / kPlTileOut;
+    const bool in_lds = k - 1 >= t.lds_first, out_lds = k >= t.lds_first && k < t.last;  // workgroup-uniform
+    uint16_t* mir = out_lds ? s_pl + loff_out : nullptr;
     for (int tile = wave; tile < tiles; tile += kPlTailThreads / 64) {
-      const PlRaw<false> raw = pl_fetch_rows<false>(nullptr, w + g.off[k - 1], g.stride, g.len[k - 1], tile, lane);
-      pl_dec_tile<false>(raw, nullptr, w + g.off[k - 1], g.stride, g.len[k - 1], w + g.off[k], g.len[k], tile, tiles, th, tlo,
-                         rows, lane);
+      PlRaw<false> raw;
+      if (in_lds)
+        raw = pl_fetch_rows<false>(nullptr, s_pl + loff_in - kPlPad, kPlTailLdsElems, g.len[k - 1], tile, lane);
+      else
+        raw = pl_fetch_rows<false>(nullptr, w + g.off[k - 1], g.stride, g.len[k - 1], tile, lane);
+      pl_dec_tile<false, true>(raw, nullptr, w + g.off[k - 1], g.stride, g.len[k - 1], w + g.off[k], g.len[k], tile, tiles,
+                               th, tlo, rows, lane, mir, kPlTailLdsElems);
     }
-    __syncthreads();  // release / acquire at workgroup scope: level k is visible to every wave of this workgroup
+    __syncthreads();  // level k is complete: in LDS for this workgroup (and in L2: same CU, same L1, workgroup scope)
+    if (out_lds) {
+      loff_in = loff_out;
+      loff_out += (g.len[k] + 7) & ~7;
+    }
   }
 }
 
@@ -811,9 +853,15 @@ void launch_pyramid_planes(const float* audio, int64_t audio_stride, uint16_t* p
       hipLaunchKernelGGL(pl_decimate_kernel<false>, dim3(grid), dim3(256), 0, stream, (const float*)nullptr, (int64_t)0, pl,
                          g.stride, g.off[k - 1], g.len[k - 1], g.off[k], g.len[k], tiles, tf, n_windows);
     }
-  if (first_tail < g.n_levels)
+  if (first_tail < g.n_levels) {
+    // levels kept in LDS: as many of the deepest ones as fit (22.05 kHz: all from level 2; extended pyramid: from level 3)
+    int lds_first = first_tail;
+    while (pl_tail_lds_need(g, lds_first, g.n_levels - 1) > kPlTailLdsElems) ++lds_first;
+    int last = g.n_levels - 1;
+    if (const char* e = getenv("BP_TAIL_LAST")) last = atoi(e);  // tools only (timing of the first levels; garbage results)
     hipLaunchKernelGGL(pl_decimate_tail_kernel, dim3(n_windows), dim3(kPlTailThreads), 0, stream, pl, g,
-                       PlTail{first_tail, g.n_levels - 1}, tf);
+                       PlTail{first_tail, last, lds_first}, tf);
+  }
 }
 
 int filterbank_planes_partials(bool ext) { return make_pl_geo(ext).n_levels * kPlTilesPerLevel; }
