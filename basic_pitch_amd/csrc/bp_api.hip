@@ -67,7 +67,7 @@ void launch_contour_conv1_exact(const uint32_t* zp, const void* wlds, const floa
 void launch_contour_conv1_folded(const uint32_t* zp, const void* wfold, const float* bias, float* c1, int n_windows,
                                  int n_cu, bool weights_have_lo, hipStream_t stream);
 bool contour_conv1_full();
-void launch_contour_conv1_rim(const uint32_t* zp, const void* afrag, const float* bias, float* c1, int n_windows,
+void launch_contour_conv1_rim(const uint32_t* zp, const void* afrag, const float* bias, float* c1, int n_windows, int n_cu,
                               bool weights_have_lo, hipStream_t stream);
 void launch_contour_conv1_fold_mx(const uint32_t* zp, const void* a16, const void* amx, const void* ascale,
                                   const float* bias, float* c1, int n_windows, int n_cu, hipStream_t stream);
@@ -776,7 +776,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
       if (contour_conv1_full() || h->rim_exact)
         launch_contour_conv1_exact(zpp, h->d_d1_wlds, h->d_d1_bias, c1p, nw, h->n_cu, wlo, s);
       else
-        launch_contour_conv1_rim(zpp, h->d_d1_wrim, h->d_d1_bias, c1p, nw, wlo, s);
+        launch_contour_conv1_rim(zpp, h->d_d1_wrim, h->d_d1_bias, c1p, nw, h->n_cu, wlo, s);
       if (!contour_conv1_full()) {
         BP_MARK(BP_STAGE_CONTOUR_CONV1_EDGE);
         BP_DOM_BEGIN();
@@ -1620,7 +1620,7 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
           if (contour_conv1_full() || h->rim_exact)
             launch_contour_conv1_exact(bf->zp, h->d_d1_wlds, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
           else
-            launch_contour_conv1_rim(bf->zp, h->d_d1_wrim, h->d_d1_bias, h->c1s, n, wlo, s);
+            launch_contour_conv1_rim(bf->zp, h->d_d1_wrim, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
           if (h->fold_mx && wlo) {
             const char* base = reinterpret_cast<const char*>(h->d_d1_wfold_mx);
             launch_contour_conv1_fold_mx(bf->zp, base, base + 36 * 64 * 16, base + 36 * 64 * 16 + 18 * 64 * 32, h->d_d1_bias,

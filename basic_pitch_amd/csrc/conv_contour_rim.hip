@@ -14,10 +14,14 @@
 // 32 x 32 tile, 4.9 k matrix instructions per window — and the B operand is a plain row image of z.
 //   * low rim: f in [0, 20), z bins [0, 144) (141 used); high rim: f in [244, 264), z bins [184, 328) (125 used; bins
 //     >= 309 are zp's zero padding).
-//   * a work item is (window, side, 64 frames); a workgroup is 5 waves, wave m owns the 32 rows (4 bins x 8 channels)
-//     of M block m for both 32-frame column tiles; the A fragments (K, split hi | lo, 54 KB per M block) stream from L2,
-//     fetched three k-steps ahead; B = 16 bytes of an f16 row image in LDS (hi plane, lo plane; row stride 37 units:
-//     conflict-free for the ds_read_b128 lane groups, one frame per lane).
+//   * a work item is (window, side, 64 frames) = 5 M blocks of 32 rows (4 bins x 8 channels) x 2 column tiles; a
+//     workgroup is FOUR waves: wave w owns M block w for all 27 k-steps and a quarter of the k-steps of M block 4, whose
+//     four partial sums meet in LDS (the image's space, read out by then).  Four, not five, because a workgroup's waves
+//     go to the SIMDs round-robin: five waves put two on one SIMD, which then paces the CU with 2/5 of the work (measured:
+//     62 % of the balanced rate), and at 3 - 4 wave slots per SIMD only one or two such workgroups fit at all.
+//   * the A fragments (K, split hi | lo, 54 KB per M block) stream from L2, three k-steps ahead; B = 16 bytes of an f16
+//     row image in LDS (hi plane, lo plane; row stride 37 units: conflict-free for the ds_read_b128 lane groups, one frame
+//     per lane), read ahead of the matrix instructions and refilled in place.
 //   * epilogue from the accumulator layout: a lane holds 4 consecutive channels of 4 bins of its frame -> bias, ReLU,
 //     four 16-byte stores into c1 (the same [172][268][8] tensor the folded kernel fills the interior of).
 // Split-precision products hi*hi + (lo*hi + hi*lo) * 2^-11 with fp32 accumulation as everywhere (bp_common.h).
@@ -30,7 +34,8 @@ namespace bp {
 
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
-constexpr int kRimWaves = 5;              // M blocks of 32 rows: 20 bins x 8 channels per side
+constexpr int kRimBlocks = 5;             // M blocks of 32 rows: 20 bins x 8 channels per side
+constexpr int kRimWaves = 4;              // wave w: block w, and k-steps [rim_ks(w), rim_ks(w + 1)) of block 4
 constexpr int kRimBins = 144;             // z bins per frame a side reads (multiple of 16)
 constexpr int kRimStepsDt = kRimBins / 16;  // 9 k-steps per frame tap
 constexpr int kRimSteps = 3 * kRimStepsDt;  // 27
@@ -42,7 +47,8 @@ constexpr int kRimNT = kRimFrames / 32;
 constexpr int kRimTiles = (kFrames + kRimFrames - 1) / kRimFrames;  // 3
 constexpr int kRimRowU = 37;              // LDS row: 18 units hi | 18 units lo | 1 pad (odd: conflict-free)
 constexpr int kRimRows = kRimFrames + 2;
-constexpr int kRimPf = 6;                 // k-steps of A prefetch (L2 latency under load ~ 4 k-steps of 6 MFMAs)
+constexpr int kRimPf = 3;                 // k-steps of A prefetch (L2 latency under load ~ 4 k-steps of 6 MFMAs)
+__host__ __device__ constexpr int rim_ks(int w) { return w >= 4 ? 27 : 7 * w; }  // 7 + 7 + 7 + 6 k-steps
 __host__ __device__ constexpr int rim_j0(int side) { return side ? 184 : 0; }
 __host__ __device__ constexpr int rim_f0(int side) { return side ? 244 : 0; }
 
@@ -54,77 +60,43 @@ struct RimParams {
   int n_items;          // n_windows * 2 * kRimTiles
 };
 
-template <bool WLO>
-__global__ __launch_bounds__(64 * kRimWaves) void contour_conv1_rim_kernel(RimParams p) {
-  __shared__ __attribute__((aligned(16))) uint4 img[kRimRows * kRimRowU];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = wave_id();
-  const int kh = lane >> 5, n = lane & 31;
-
-  const int item = blockIdx.x;
-  const int b = item / (2 * kRimTiles);
-  const int rem = item - b * (2 * kRimTiles);
-  const int side = rem / kRimTiles, tile = rem - side * kRimTiles;
-  const int t0 = tile * kRimFrames;
-
-  // ---- stage frames t0 - 1 .. t0 + 64 of the side's 144 z bins as f16 planes: unit (row, u) = bins j0 + 8u .. + 7
-  const uint32_t* zwin = p.zp + (int64_t)b * kZWin + kZPadL + rim_j0(side);
-  for (int e = threadIdx.x; e < kRimRows * (kRimBins / 8); e += 64 * kRimWaves) {
-    const int row = e / (kRimBins / 8), u = e - row * (kRimBins / 8);
-    const int t = t0 - 1 + row;  // frame of this image row; zp rows -1 and 172 are zero, beyond them nothing exists
-    uint4 vh{0u, 0u, 0u, 0u}, vl{0u, 0u, 0u, 0u};
-    if (t >= -1 && t <= kFrames) {
-      const uint4* src = reinterpret_cast<const uint4*>(zwin + (int64_t)(t + 1) * kZRow + 8 * u);
-      const uint4 w0 = src[0], w1 = src[1];
-      vh.x = (w0.x & 0xffffu) | (w0.y << 16);
-      vh.y = (w0.z & 0xffffu) | (w0.w << 16);
-      vh.z = (w1.x & 0xffffu) | (w1.y << 16);
-      vh.w = (w1.z & 0xffffu) | (w1.w << 16);
-      vl.x = (w0.x >> 16) | (w0.y & 0xffff0000u);
-      vl.y = (w0.z >> 16) | (w0.w & 0xffff0000u);
-      vl.z = (w1.x >> 16) | (w1.y & 0xffff0000u);
-      vl.w = (w1.z >> 16) | (w1.w & 0xffff0000u);
-    }
-    img[row * kRimRowU + u] = vh;
-    img[row * kRimRowU + 18 + u] = vl;
+// k-steps [S0, S1) of one M block into acc / accc.  The first kRimPf A fragments are already in the ring (rim_a_prefetch).
+// B fragments are read ahead of the matrix instructions that use them (the compiler's own order reads them right in front
+// of their use and waits: the k loop then took 24 k cycles for 5 k of matrix work) and refilled IN PLACE: a step issues
+// [A_hi x B_hi], [A_lo x B_hi], then B_hi's registers take the next step's reads while [A_hi x B_lo] runs, then B_lo's.
+// One register set (16) instead of two keeps the kernel under 128 VGPRs = 4 waves per SIMD.
+template <int S0>
+__device__ __forceinline__ void rim_a_prefetch(const uint4* afr, uint4 (&ah)[kRimPf], uint4 (&al)[kRimPf]) {
+#pragma unroll
+  for (int s = S0; s < S0 + kRimPf; ++s) {
+    ah[s % kRimPf] = afr[(s * 2 + 0) * 64];
+    al[s % kRimPf] = afr[(s * 2 + 1) * 64];
   }
+}
 
-  // ---- A fragments of this wave's M block, fetched kRimPf k-steps ahead (global, L2 resident)
-  const uint4* afr = p.afrag + ((int64_t)(side * kRimWaves + wave) * kRimSteps) * 2 * 64 + lane;
-  uint4 ah[kRimPf], al[kRimPf];
-#pragma unroll
-  for (int s = 0; s < kRimPf; ++s) {
-    ah[s] = afr[(s * 2 + 0) * 64];
-    al[s] = afr[(s * 2 + 1) * 64];
-  }
-  __syncthreads();
-
-  f32x16 acc[kRimNT], accc[kRimNT];
-#pragma unroll
-  for (int j = 0; j < kRimNT; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = accc[j][r] = 0.0f;
-
-  // lane (n, kh) of column tile j reads image row (32 j + n + dt), unit 2 e + kh of the hi / lo plane
-  const int lane_u = n * kRimRowU + kh;
-#pragma unroll
-  for (int s = 0; s < kRimSteps; ++s) {
+template <bool WLO, int S0, int S1>
+__device__ __forceinline__ void rim_ksteps(const uint4* afr, const uint4* img, int lane_u, uint4 (&ah)[kRimPf],
+                                           uint4 (&al)[kRimPf], f32x16 (&acc)[kRimNT], f32x16 (&accc)[kRimNT]) {
+  static_assert(S1 - S0 >= kRimPf, "the ring is full at entry");
+  f16x8 bh[kRimNT], bl[kRimNT];
+  auto read_bh = [&](int s) {
     const int dt = s / kRimStepsDt, e = s - dt * kRimStepsDt;
+#pragma unroll
+    for (int j = 0; j < kRimNT; ++j) bh[j] = __builtin_bit_cast(f16x8, img[lane_u + (32 * j + dt) * kRimRowU + 2 * e]);
+  };
+  auto read_bl = [&](int s) {
+    const int dt = s / kRimStepsDt, e = s - dt * kRimStepsDt;
+#pragma unroll
+    for (int j = 0; j < kRimNT; ++j) bl[j] = __builtin_bit_cast(f16x8, img[lane_u + (32 * j + dt) * kRimRowU + 2 * e + 18]);
+  };
+  read_bh(S0);
+  read_bl(S0);
+#pragma unroll
+  for (int s = S0; s < S1; ++s) {
     const uint4 a_hi = ah[s % kRimPf], a_lo = al[s % kRimPf];
-    if (s + kRimPf < kRimSteps) {
-      ah[s % kRimPf] = afr[((s + kRimPf) * 2 + 0) * 64];
-      al[s % kRimPf] = afr[((s + kRimPf) * 2 + 1) * 64];
-    }
     const f16x8 fah = __builtin_bit_cast(f16x8, a_hi);
     const f16x8 fal = __builtin_bit_cast(f16x8, a_lo);
-    f16x8 bh[kRimNT], bl[kRimNT];
-#pragma unroll
-    for (int j = 0; j < kRimNT; ++j) {
-      const int at = lane_u + (32 * j + dt) * kRimRowU + 2 * e;
-      bh[j] = __builtin_bit_cast(f16x8, img[at]);
-      bl[j] = __builtin_bit_cast(f16x8, img[at + 18]);
-    }
+    __builtin_amdgcn_sched_barrier(0);
     // the column tiles alternate so that no MFMA waits for the one just issued
 #pragma unroll
     for (int j = 0; j < kRimNT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bh[j], acc[j], 0, 0, 0);
@@ -132,15 +104,111 @@ __global__ __launch_bounds__(64 * kRimWaves) void contour_conv1_rim_kernel(RimPa
 #pragma unroll
       for (int j = 0; j < kRimNT; ++j) accc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, bh[j], accc[j], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < S1) read_bh(s + 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < kRimNT; ++j) accc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bl[j], accc[j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < S1) read_bl(s + 1);
+    if (s + kRimPf < S1) {
+      ah[s % kRimPf] = afr[((s + kRimPf) * 2 + 0) * 64];
+      al[s % kRimPf] = afr[((s + kRimPf) * 2 + 1) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
+}
 
-  // ---- epilogue: C row i = (r & 3) + 8 (r >> 2) + 4 kh = 8 (bin of the block) + channel -> channels 4 kh .. 4 kh + 3
-  // of bin r >> 2; column n = frame
-  float bias4[4];
+template <bool WLO>
+__global__ __launch_bounds__(64 * kRimWaves, 4) void contour_conv1_rim_kernel(RimParams p) {
+  __shared__ __attribute__((aligned(16))) uint4 img[kRimRows * kRimRowU];
+  static_assert(sizeof(uint4) * kRimRows * kRimRowU >= sizeof(float) * kRimWaves * 32 * 64, "the partial sums fit the image");
+
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  const int kh = lane >> 5, n = lane & 31;
+
+#if defined(RIM_PROF)
+  unsigned long long pt[6], pc = __builtin_amdgcn_s_memtime();
+  const unsigned long long r_start = __builtin_amdgcn_s_memrealtime();
+#define RIM_STAMP(k)                                             \
+  {                                                              \
+    const unsigned long long now = __builtin_amdgcn_s_memtime(); \
+    pt[k] = now - pc;                                            \
+    pc = now;                                                    \
+  }
+#else
+#define RIM_STAMP(k)
+#endif
+  const int item = blockIdx.x;
+  const int b = item / (2 * kRimTiles);
+  const int rem = item - b * (2 * kRimTiles);
+  const int side = rem / kRimTiles, tile = rem - side * kRimTiles;
+  const int t0 = tile * kRimFrames;
+
+
+  // ---- stage frames t0 - 1 .. t0 + 64 of the side's 144 z bins as f16 planes: unit (row, u) = bins j0 + 8u .. + 7.
+  // All loads of a thread are in flight before the first is used (one global round trip per item, not five).
+  {
+    const uint32_t* zwin = p.zp + (int64_t)b * kZWin + kZPadL + rim_j0(side);
+    constexpr int kUnits = kRimRows * (kRimBins / 8), kPerThread = (kUnits + 64 * kRimWaves - 1) / (64 * kRimWaves);
+    uint4 w0[kPerThread], w1[kPerThread];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) bias4[c] = p.bias[4 * kh + c];
+    for (int i = 0; i < kPerThread; ++i) {
+      const int e = threadIdx.x + i * 64 * kRimWaves;
+      const int row = e / (kRimBins / 8), u = e - row * (kRimBins / 8);
+      const int t = t0 - 1 + row;  // zp rows -1 and 172 are zero; frames beyond them read the all-zero row -1:
+      const bool ok = e < kUnits && t >= -1 && t <= kFrames;  // no select behind the load
+      const uint4* src = reinterpret_cast<const uint4*>(zwin + (int64_t)((ok ? t : -1) + 1) * kZRow + 8 * (ok ? u : 0));
+      w0[i] = src[0], w1[i] = src[1];
+    }
+#pragma unroll
+    for (int i = 0; i < kPerThread; ++i) {
+      const int e = threadIdx.x + i * 64 * kRimWaves;
+      if (e >= kUnits) break;
+      const int row = e / (kRimBins / 8), u = e - row * (kRimBins / 8);
+      uint4 vh, vl;
+      vh.x = (w0[i].x & 0xffffu) | (w0[i].y << 16);
+      vh.y = (w0[i].z & 0xffffu) | (w0[i].w << 16);
+      vh.z = (w1[i].x & 0xffffu) | (w1[i].y << 16);
+      vh.w = (w1[i].z & 0xffffu) | (w1[i].w << 16);
+      vl.x = (w0[i].x >> 16) | (w0[i].y & 0xffff0000u);
+      vl.y = (w0[i].z >> 16) | (w0[i].w & 0xffff0000u);
+      vl.z = (w1[i].x >> 16) | (w1[i].y & 0xffff0000u);
+      vl.w = (w1[i].z >> 16) | (w1[i].w & 0xffff0000u);
+      img[row * kRimRowU + u] = vh;
+      img[row * kRimRowU + 18 + u] = vl;
+    }
+  }
+  // ---- A fragments of this wave's own M block: on their way (L2) across the barrier
+  const uint4* afr = p.afrag + ((int64_t)(side * kRimBlocks + wave) * kRimSteps) * 2 * 64 + lane;
+  uint4 ah[kRimPf], al[kRimPf];
+  rim_a_prefetch<0>(afr, ah, al);
+  RIM_STAMP(0);
+  lds_barrier();
+  RIM_STAMP(1);
+
+  f32x16 acc[kRimNT], accc[kRimNT];
+  auto clear = [&]() {
+#pragma unroll
+    for (int j = 0; j < kRimNT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = accc[j][r] = 0.0f;
+  };
+  // lane (n, kh) of column tile j reads image row (32 j + n + dt), unit 2 e + kh of the hi / lo plane
+  const int lane_u = n * kRimRowU + kh;
+
+  // ---- phase 1: the wave's own M block, all 27 k-steps
+  clear();
+  rim_ksteps<WLO, 0, kRimSteps>(afr, img, lane_u, ah, al, acc, accc);
+
+#if defined(RIM_PROF)
+  asm volatile("" : "+v"(acc[0][0]), "+v"(accc[kRimNT - 1][15]));
+#endif
+  RIM_STAMP(2);
+  // ---- epilogue of a full block: C row i = (r & 3) + 8 (r >> 2) + 4 kh = 8 (bin of the block) + channel -> channels
+  // 4 kh .. 4 kh + 3 of bin r >> 2; column n = frame
+  const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + 4 * kh);
 #pragma unroll
   for (int j = 0; j < kRimNT; ++j) {
     const int t = t0 + 32 * j + n;
@@ -156,10 +224,65 @@ __global__ __launch_bounds__(64 * kRimWaves) void contour_conv1_rim_kernel(RimPa
       }
     }
   }
+
+  // ---- phase 2: a quarter of M block 4's k-steps; the four partial sums meet in LDS
+  RIM_STAMP(3);
+  const uint4* afr4 = p.afrag + ((int64_t)(side * kRimBlocks + 4) * kRimSteps) * 2 * 64 + lane;
+  clear();
+#define RIM_QUARTER(w)                                                                              \
+  case w:                                                                                           \
+    rim_a_prefetch<rim_ks(w)>(afr4, ah, al);                                                        \
+    rim_ksteps<WLO, rim_ks(w), rim_ks(w + 1)>(afr4, img, lane_u, ah, al, acc, accc);                \
+    break;
+  switch (wave) {
+    RIM_QUARTER(0)
+    RIM_QUARTER(1)
+    RIM_QUARTER(2)
+    RIM_QUARTER(3)
+  }
+#undef RIM_QUARTER
+#if defined(RIM_PROF)
+  asm volatile("" : "+v"(acc[0][0]), "+v"(accc[kRimNT - 1][15]));
+#endif
+  RIM_STAMP(4);
+  lds_barrier();  // every wave is done with the image: its space takes the partial sums [wave][32 values][64 lanes]
+  float* part = reinterpret_cast<float*>(img);
+#pragma unroll
+  for (int j = 0; j < kRimNT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      part[(wave * 32 + 16 * j + r) * 64 + lane] = __builtin_fmaf(accc[j][r], kLoUnscale, acc[j][r]);
+  lds_barrier();
+  // wave w finishes column tile w >> 1, bins 2 (w & 1) and 2 (w & 1) + 1 of the block (values r = 8 (w & 1) .. + 7)
+  {
+    const int j = wave >> 1, r0 = 8 * (wave & 1);
+    const int t = t0 + 32 * j + n;
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      float sum = 0.0f;
+#pragma unroll
+      for (int w = 0; w < kRimWaves; ++w) sum += part[(w * 32 + 16 * j + r0 + r) * 64 + lane];
+      v[r] = fmaxf(sum + bias4[r & 3], 0.0f);
+    }
+    if (t < kFrames) {
+      float* row = p.c1 + (((int64_t)b * kFrames + t) * kC1Row + kC1Pad + rim_f0(side) + 16 + 2 * (wave & 1)) * 8 + 4 * kh;
+      *reinterpret_cast<f32x4*>(row) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(row + 8) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+  RIM_STAMP(5);
+#if defined(RIM_PROF)
+  if (lane == 0 && (blockIdx.x % 61 == 0 || blockIdx.x < 4) && p.n_items > 1000)
+    printf("RIMQ wg %d wave %d real %llu stage %llu bar %llu k1 %llu epi %llu k2 %llu red %llu\n", (int)blockIdx.x, wave, r_start,
+           pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]);
+#endif
+#undef RIM_STAMP
 }
 
-void launch_contour_conv1_rim(const uint32_t* zp, const void* afrag, const float* bias, float* c1, int n_windows,
+void launch_contour_conv1_rim(const uint32_t* zp, const void* afrag, const float* bias, float* c1, int n_windows, int n_cu,
                               bool weights_have_lo, hipStream_t stream) {
+  (void)n_cu;
   RimParams p{zp, static_cast<const uint4*>(afrag), bias, c1, n_windows * 2 * kRimTiles};
   if (p.n_items <= 0) return;
   if (weights_have_lo)
