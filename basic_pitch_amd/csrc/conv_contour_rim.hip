@@ -120,9 +120,9 @@ __device__ __forceinline__ void rim_ksteps(const uint4* afr, const uint4* img, i
 }
 
 template <bool WLO>
-__global__ __launch_bounds__(64 * kRimWaves, 4) void contour_conv1_rim_kernel(RimParams p) {
+__global__ __launch_bounds__(64 * kRimWaves, kRimNT <= 2 ? 4 : 2) void contour_conv1_rim_kernel(RimParams p) {
   __shared__ __attribute__((aligned(16))) uint4 img[kRimRows * kRimRowU];
-  static_assert(sizeof(uint4) * kRimRows * kRimRowU >= sizeof(float) * kRimWaves * 32 * 64, "the partial sums fit the image");
+  static_assert(sizeof(uint4) * kRimRows * kRimRowU >= sizeof(float) * kRimWaves * 16 * kRimNT * 64, "the partial sums fit the image");
 
   const int lane = threadIdx.x & 63;
   const int wave = wave_id();
@@ -207,7 +207,9 @@ __global__ __launch_bounds__(64 * kRimWaves, 4) void contour_conv1_rim_kernel(Ri
 #endif
   RIM_STAMP(2);
   // ---- epilogue of a full block: C row i = (r & 3) + 8 (r >> 2) + 4 kh = 8 (bin of the block) + channel -> channels
-  // 4 kh .. 4 kh + 3 of bin r >> 2; column n = frame
+  // 4 kh .. 4 kh + 3 of bin r >> 2; column n = frame.  (Sending the block's 32 frames x 128 contiguous bytes through a
+  // wave-private LDS tile so that they leave as whole rows — 8 frames per store instruction instead of 32 partial lines —
+  // measured the same 51 us: the stores are not what paces this kernel.)
   const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + 4 * kh);
 #pragma unroll
   for (int j = 0; j < kRimNT; ++j) {
@@ -245,31 +247,31 @@ __global__ __launch_bounds__(64 * kRimWaves, 4) void contour_conv1_rim_kernel(Ri
   asm volatile("" : "+v"(acc[0][0]), "+v"(accc[kRimNT - 1][15]));
 #endif
   RIM_STAMP(4);
-  lds_barrier();  // every wave is done with the image: its space takes the partial sums [wave][32 values][64 lanes]
+  lds_barrier();  // every wave is done with the image: its space takes the partial sums [wave][16 NT values][64 lanes]
   float* part = reinterpret_cast<float*>(img);
+  constexpr int kVals = 16 * kRimNT;
 #pragma unroll
   for (int j = 0; j < kRimNT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      part[(wave * 32 + 16 * j + r) * 64 + lane] = __builtin_fmaf(accc[j][r], kLoUnscale, acc[j][r]);
+      part[(wave * kVals + 16 * j + r) * 64 + lane] = __builtin_fmaf(accc[j][r], kLoUnscale, acc[j][r]);
   lds_barrier();
-  // wave w finishes column tile w >> 1, bins 2 (w & 1) and 2 (w & 1) + 1 of the block (values r = 8 (w & 1) .. + 7)
-  {
-    const int j = wave >> 1, r0 = 8 * (wave & 1);
-    const int t = t0 + 32 * j + n;
-    float v[8];
+  // the 4 NT (column tile, bin) pairs of the block are dealt to the waves: wave w finishes pairs w NT .. w NT + NT - 1, each
+  // the four channels 4 kh .. 4 kh + 3 of one bin = one 16-byte store
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+  for (int i = 0; i < kRimNT; ++i) {
+    const int sidx = wave * kRimNT + i, j = sidx >> 2, fb = sidx & 3;
+    const int t = t0 + 32 * j + n;
+    f32x4 v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
       float sum = 0.0f;
 #pragma unroll
-      for (int w = 0; w < kRimWaves; ++w) sum += part[(w * 32 + 16 * j + r0 + r) * 64 + lane];
-      v[r] = fmaxf(sum + bias4[r & 3], 0.0f);
+      for (int w = 0; w < kRimWaves; ++w) sum += part[(w * kVals + 16 * j + 4 * fb + c) * 64 + lane];
+      v[c] = fmaxf(sum + bias4[c], 0.0f);
     }
-    if (t < kFrames) {
-      float* row = p.c1 + (((int64_t)b * kFrames + t) * kC1Row + kC1Pad + rim_f0(side) + 16 + 2 * (wave & 1)) * 8 + 4 * kh;
-      *reinterpret_cast<f32x4*>(row) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(row + 8) = f32x4{v[4], v[5], v[6], v[7]};
-    }
+    if (t < kFrames)
+      *reinterpret_cast<f32x4*>(p.c1 + (((int64_t)b * kFrames + t) * kC1Row + kC1Pad + rim_f0(side) + 16 + fb) * 8 + 4 * kh) = v;
   }
   RIM_STAMP(5);
 #if defined(RIM_PROF)
