@@ -229,7 +229,10 @@ __device__ __forceinline__ void pl_split8(const float4& a, const float4& c, uint
 //                elements [2 o0, 2 o0 + 512); tile 0 / the last tile add the reflect padding of level 0.
 // MIRROR: the outputs also go to a second image of the output level (`mir_hi` = its sample 0, lo plane `mir_stride`
 //         elements behind; no padding there): the per-window kernel keeps the levels it reads again in LDS.
-template <bool F32IN, bool MIRROR = false>
+// PF:     k-steps of LDS fragment reads kept ahead of the matrix instructions (0 = the compiler's own order, which reads
+//         each fragment right in front of its use and waits: fine where four waves per SIMD and a prefetched next item
+//         cover it, 1.5 k cycles per tile where a tile's latency is the critical path — the per-window kernel).
+template <bool F32IN, bool MIRROR = false, int PF = 0>
 __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, const float* __restrict__ x,
                                             uint16_t* __restrict__ in_hi, int64_t stride, int L_in,
                                             uint16_t* __restrict__ out_hi, int L_out, int tile, int n_tiles,
@@ -304,13 +307,33 @@ __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, const float
 
   f32x4 hh = {0.f, 0.f, 0.f, 0.f}, xx = hh;
   const uint4* tl = tlo + lane;
+  if constexpr (PF == 0) {
 #pragma unroll
-  for (int s = 0; s < kPlDmSteps; ++s) {
-    const uint4 xh = rh[s * kPlRowU], xl = rl[s * kPlRowU];
-    const uint4 tls = tl[s * 64];
-    hh = BP_PL_MFMA16(th[s], xh, hh);
-    xx = BP_PL_MFMA16(tls, xh, xx);
-    xx = BP_PL_MFMA16(th[s], xl, xx);
+    for (int s = 0; s < kPlDmSteps; ++s) {
+      const uint4 xh = rh[s * kPlRowU], xl = rl[s * kPlRowU];
+      const uint4 tls = tl[s * 64];
+      hh = BP_PL_MFMA16(th[s], xh, hh);
+      xx = BP_PL_MFMA16(tls, xh, xx);
+      xx = BP_PL_MFMA16(th[s], xl, xx);
+    }
+  } else {
+    uint4 xh[PF + 1], xl[PF + 1], tls[PF + 1];
+    auto rd = [&](int s) {
+      xh[s % (PF + 1)] = rh[s * kPlRowU];
+      xl[s % (PF + 1)] = rl[s * kPlRowU];
+      tls[s % (PF + 1)] = tl[s * 64];
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) rd(s);
+#pragma unroll
+    for (int s = 0; s < kPlDmSteps; ++s) {
+      if (s + PF < kPlDmSteps) rd(s + PF);
+      __builtin_amdgcn_sched_barrier(0);
+      hh = BP_PL_MFMA16(th[s], xh[s % (PF + 1)], hh);
+      xx = BP_PL_MFMA16(tls[s % (PF + 1)], xh[s % (PF + 1)], xx);
+      xx = BP_PL_MFMA16(th[s], xl[s % (PF + 1)], xx);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   // the rows are read: the next tile of this wave may overwrite them
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -470,7 +493,7 @@ __global__ __launch_bounds__(kPlTailThreads) void pl_decimate_tail_kernel(uint16
         raw = pl_fetch_rows<false>(nullptr, s_pl + loff_in - kPlPad, kPlTailLdsElems, g.len[k - 1], tile, lane);
       else
         raw = pl_fetch_rows<false>(nullptr, w + g.off[k - 1], g.stride, g.len[k - 1], tile, lane);
-      pl_dec_tile<false, true>(raw, nullptr, w + g.off[k - 1], g.stride, g.len[k - 1], w + g.off[k], g.len[k], tile, tiles,
+      pl_dec_tile<false, true, 3>(raw, nullptr, w + g.off[k - 1], g.stride, g.len[k - 1], w + g.off[k], g.len[k], tile, tiles,
                                th, tlo, rows, lane, mir, kPlTailLdsElems);
     }
     __syncthreads();  // level k is complete: in LDS for this workgroup (and in L2: same CU, same L1, workgroup scope)
