@@ -29,6 +29,7 @@ SOURCES = [
     "conv_heads.hip",
     "conv_branch.hip",
     "note_march.hip",
+    "onset_march.hip",
     "audio_ingest.hip",
     "note_decode.cpp",
     "flac_decode.cpp",

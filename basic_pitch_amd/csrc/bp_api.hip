@@ -69,6 +69,8 @@ void launch_contour_conv1_folded(const uint32_t* zp, const void* wfold, const fl
 bool contour_conv1_full();
 void launch_contour_conv1_rim(const uint32_t* zp, const void* afrag, const float* bias, float* c1, int n_windows, int n_cu,
                               bool weights_have_lo, hipStream_t stream);
+void launch_onset_march(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, float* onset,
+                        int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
 void launch_contour_conv1_fold_mx(const uint32_t* zp, const void* a16, const void* amx, const void* ascale,
                                   const float* bias, float* c1, int n_windows, int n_cu, hipStream_t stream);
 void launch_contour_conv2(const float* c1, const float* w2, float bias, float* contour, int n_windows, int n_cu,
@@ -77,6 +79,19 @@ void launch_note_march(const float* contour, const void* wfrag, const float* wf3
                        bool weights_have_lo, hipStream_t stream);
 void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, const void* wmx,
                          float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
+// the onset branch: the wave-private march by default; the workgroup kernel for the fp8-correction mode (it carries the
+// block-scaled products) and behind BP_ONSET=ring (A/B runs)
+static void launch_onset(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, const void* wmx,
+                         float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream) {
+  static const bool ring = [] {
+    const char* e = std::getenv("BP_ONSET");
+    return e && std::strcmp(e, "ring") == 0;
+  }();
+  if (wmx || ring)
+    launch_onset_branch(zp, note, wfrag, wf32, wmx, onset, n_windows, n_cu, weights_have_lo, stream);
+  else
+    launch_onset_march(zp, note, wfrag, wf32, onset, n_windows, n_cu, weights_have_lo, stream);
+}
 }  // namespace bp
 
 using namespace bp;
@@ -795,8 +810,8 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
     }
     launch_note_march(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, wlo, s);
     BP_MARK(BP_STAGE_NOTE);
-    launch_onset_branch(reinterpret_cast<const uint32_t*>(h->zp), note_dev, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx,
-                        onset_dev, n, h->n_cu, wlo, s);
+    launch_onset(reinterpret_cast<const uint32_t*>(h->zp), note_dev, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, onset_dev,
+                 n, h->n_cu, wlo, s);
     BP_MARK(BP_STAGE_ONSET);
   }
 #undef BP_MARK
@@ -1638,8 +1653,7 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
       break;
     case BP_STAGE_ONSET:
       if ((ok = need(bf->zp) && need(bf->note) && need(bf->onset)))
-        launch_onset_branch(bf->zp, bf->note, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, bf->onset, n, h->n_cu, wlo,
-                            s);
+        launch_onset(bf->zp, bf->note, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, bf->onset, n, h->n_cu, wlo, s);
       break;
     default:
       h->err = "bp_run_stage: unknown stage";

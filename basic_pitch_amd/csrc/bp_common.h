@@ -93,22 +93,21 @@ __device__ __forceinline__ float wave_max_lane63(float v) {
 }
 #undef BP_DPP_STEP
 
-// lo halves of a split pair: rn_f16(v 2^11 - hi 2^11) as ONE mixed-precision FMA per value (v_fma_mixlo / mixhi_f16 read
-// the f16 hi straight from its half of the packed register and round the fp32 result to f16 into the matching half):
-// 2 operations per value for the whole split instead of 3 (cvt back to f32, packed subtract + scale, packed cvt).  The
-// same bits as rn_f16((v - float(hi)) * 2^11): v - hi is exact either way and the scaling is a power of two.
-__device__ __forceinline__ uint32_t split_lo_mix(uint32_t hi2, f32x2 v) {
+// lo halves of a split pair: rn_f16((v - float(hi)) * 2^11), on the packed-f32 pipe.
+// (Round 3 tried ONE mixed-precision FMA per value instead — v_fma_mixlo_f16 / v_fma_mixhi_f16 through inline assembly,
+// reading the f16 hi straight from its half of the packed register: two VALU operations per value fewer, bit-identical in
+// the note, onset and CQT kernels, 1 % faster.  In a new kernel (onset_march.hip with three accumulator chains) the same
+// helper produced lo halves that were off — the map moved by 7e-5, deterministically, and only in some instruction
+// neighbourhoods; compiled without the assembly the kernel was bit-identical to its reference again.  The compiler's
+// hazard recognizer cannot see into inline assembly; which wait state the sequence needs we did not find.  Removed.)
+__device__ __forceinline__ uint32_t split_lo(uint32_t hi2, f32x2 v) {
   uint32_t l = 0;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(BP_SPLIT_NO_MIX)  // A/B builds (tools/build_variant.sh): the round-2 form
+#if defined(__HIP_DEVICE_COMPILE__)
   const f16x2 h = __builtin_bit_cast(f16x2, hi2);
   const f32x2 hf = {(float)h.x, (float)h.y};
   const f32x2 d = (v - hf) * f32x2{2048.0f, 2048.0f};
   const f16x2 lh = {(_Float16)d.x, (_Float16)d.y};
   l = __builtin_bit_cast(uint32_t, lh);
-#elif defined(__HIP_DEVICE_COMPILE__)
-  const f32x2 V = v * f32x2{2048.0f, 2048.0f};
-  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi2), "s"(-2048.0f), "v"(V.x));
-  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi2), "s"(-2048.0f), "v"(V.y));
 #endif
   return l;
 }
@@ -119,7 +118,7 @@ __device__ __forceinline__ void split_f16x2_rn(f32x2 v, uint32_t& hi2, uint32_t&
 #if defined(__HIP_DEVICE_COMPILE__)
   const f16x2 h = {(_Float16)v.x, (_Float16)v.y};  // one v_cvt_pk_f16_f32
   hi2 = __builtin_bit_cast(uint32_t, h);
-  lo2 = split_lo_mix(hi2, v);
+  lo2 = split_lo(hi2, v);
 #endif
 }
 
@@ -129,7 +128,7 @@ __device__ __forceinline__ void split_f16x2_rn(f32x2 v, uint32_t& hi2, uint32_t&
 __device__ __forceinline__ void split_f16x2(f32x2 v, uint32_t& hi2, uint32_t& lo2) {
 #if defined(__HIP_DEVICE_COMPILE__)
   hi2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
-  lo2 = split_lo_mix(hi2, v);
+  lo2 = split_lo(hi2, v);
 #endif
 }
 
