@@ -793,3 +793,22 @@ def test_predict_and_save_sharded_two_workers_on_one_gpu(tmp_path):
     for r in rep:
         assert open(r["outputs"]["midi"], "rb").read() == want
         assert open(r["outputs"]["note_events"]).read() == open(out1 / "clip_0_basic_pitch.csv").read()
+
+
+def test_onset_march_equals_workgroup_kernel(tmp_path):
+    """The default onset kernel (wave-private march, onset_march.hip) and the round-2 workgroup kernel (BP_ONSET=ring, also
+    the fp8 mode's kernel) are the same arithmetic in a different decomposition: bit-identical maps on random stack
+    images and note maps, through the C ABI stage hook in two processes (the choice is read once per process)."""
+    import subprocess
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "experiments", "onset_ab.py")
+    outs = []
+    for name, env in (("march", {}), ("ring", {"BP_ONSET": "ring"})):
+        out = str(tmp_path / f"{name}.npy")
+        e = dict(os.environ, **env)
+        e.pop("BASIC_PITCH_AMD_LIB", None)
+        subprocess.run([sys.executable, tool, out], check=True, env=e, timeout=300)
+        outs.append(np.load(out))
+    assert np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0], outs[1])

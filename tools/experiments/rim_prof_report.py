@@ -1,20 +1,19 @@
-"""Medians of the RIM_PROF phase clocks (tools/experiments/rim_prof.py output): first round of workgroups vs later."""
+"""Medians of the RIM_PROF phase clocks (tools/experiments/rim_prof.py output, built with tools/build_variant.sh rimprof
+conv_contour_rim.hip -DRIM_PROF): workgroups of the first round vs later ones, and when the sampled workgroups started."""
 import re, statistics as st, sys
+
 rows = []
 for l in open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/rim_prof.txt"):
-    m = re.match(r"RIM wg (\d+) wave (\d+) hw (\w+) real (\d+) stage (\d+) bar (\d+) k (\d+) epi (\d+)", l)
+    m = re.match(r"RIMQ wg (\d+) wave (\d+) real (\d+) stage (\d+) bar (\d+) k1 (\d+) epi (\d+) k2 (\d+) red (\d+)", l)
     if m:
-        rows.append(tuple(int(x, 16) if i == 2 else int(x) for i, x in enumerate(m.groups())))
-rows.sort(key=lambda r: r[3])
-n = len(rows) // 3
+        rows.append(tuple(int(x) for x in m.groups()))
+rows.sort(key=lambda r: r[2])
+n = len(rows) // 3  # the tool runs three steps; the last one is steady state
 L = rows[-n:]
-t0 = min(r[3] for r in L)
-first = [r for r in L if (r[3] - t0) < 300]
-later = [r for r in L if (r[3] - t0) >= 300]
-for nm, S in (("first round", first), ("later", later)):
-    if not S:
-        continue
-    print(nm, len(S), {k: int(st.median([r[i] for r in S])) for k, i in (("stage", 4), ("bar", 5), ("k", 6), ("epi", 7))},
-          "total", int(st.median([sum(r[4:8]) for r in S])))
-starts = sorted(set(round((r[3] - t0) / 100.0, 1) for r in L))
-print("start times (us):", starts[:40])
+t0 = min(r[2] for r in L)
+names = ["stage", "bar", "k1", "epi", "k2", "red"]
+for nm, S in (("first round", [r for r in L if r[2] - t0 < 300]), ("later", [r for r in L if r[2] - t0 >= 300])):
+    if S:
+        print(nm, len(S), {k: int(st.median([r[3 + i] for r in S])) for i, k in enumerate(names)},
+              "total", int(st.median([sum(r[3:]) for r in S])))
+print("start of the sampled workgroups (us):", sorted(set((r[0], round((r[2] - t0) / 100, 1)) for r in L)))
