@@ -96,10 +96,11 @@ __device__ __forceinline__ float wave_max_lane63(float v) {
 // lo halves of a split pair: rn_f16((v - float(hi)) * 2^11), on the packed-f32 pipe.
 // (Round 3 tried ONE mixed-precision FMA per value instead — v_fma_mixlo_f16 / v_fma_mixhi_f16 through inline assembly,
 // reading the f16 hi straight from its half of the packed register: two VALU operations per value fewer, bit-identical in
-// the note, onset and CQT kernels, 1 % faster.  In a new kernel (onset_march.hip with three accumulator chains) the same
-// helper produced lo halves that were off — the map moved by 7e-5, deterministically, and only in some instruction
-// neighbourhoods; compiled without the assembly the kernel was bit-identical to its reference again.  The compiler's
-// hazard recognizer cannot see into inline assembly; which wait state the sequence needs we did not find.  Removed.)
+// the note, onset and CQT kernels, 1 % faster.  In a new kernel the same helper produced lo halves that were off (the
+// onset map moved by 7e-5, deterministically).  Cause: a VALU write of ONE 16-bit half of a register needs a wait state
+// before the next instruction that touches that register (gfx940's destination-select forwarding hazard) — the compiler
+// inserts it for its own instructions and cannot see into inline assembly; with `s_nop 1` behind each of the two
+// instructions the kernel was bit-identical again.  With the nops the form saves nothing measurable: removed.)
 __device__ __forceinline__ uint32_t split_lo(uint32_t hi2, f32x2 v) {
   uint32_t l = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
