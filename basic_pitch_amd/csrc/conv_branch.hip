@@ -1,5 +1,7 @@
-// Fused onset branch — split-precision matrix-core kernel (default path); also home of zpack_kernel.  (The note branch,
-// which shared this skeleton in round 1, lives in note_march.hip since round 2; its workgroup kernel was retired in round 3.)
+// Fused onset branch, workgroup form — the kernel of the fp8-correction mode (BP_FLAG_FP8_CORRECTIONS) and the A/B reference
+// of the default wave-private march (onset_march.hip, round 3; BP_ONSET=ring selects this one); also home of zpack_kernel.
+// (The note branch, which shared this skeleton in round 1, lives in note_march.hip since round 2; its workgroup kernel was
+// retired in round 3.)
 //
 //   onset branch (basic_pitch/models.py:295-318): Conv2D 8->32, 5x5, strides (1,3), "same", folded BN,
 //                ReLU on the harmonic stack (nn.py:69-88), Concatenate([note, features]) (305),
