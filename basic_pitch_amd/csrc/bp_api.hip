@@ -231,8 +231,10 @@ struct bp_context {
   static constexpr int kTimedRing = 128;
   static constexpr int kMaxMarks = 32;  // a stage may be launched in parts (the contour branch): its intervals are summed
   hipEvent_t ev[kTimedRing][kMaxMarks + 1] = {};
-  int seq[kMaxMarks] = {};  // stage id of the interval between ev[.][i] and ev[.][i+1]; -1: not a stage (skipped)
-  int n_seq = 0;
+  // per ring slot (the mark sequence depends on the chunk: zpack only below half a window per CU, contour parts):
+  // stage id of the interval between ev[c][i] and ev[c][i+1]; -1: not a stage (skipped)
+  int seq[kTimedRing][kMaxMarks] = {};
+  int n_seq[kTimedRing] = {};
   bool ev_valid = false;
   int64_t timed_chunks = 0;  // chunks recorded since the last bp_get_stage_ms
 };
@@ -714,13 +716,15 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
   const bool dom = !timing && (h->flags & BP_FLAG_TIME_DOMINANT) && !(h->flags & BP_FLAG_F32_MFMA);
   const bool wlo = !(h->flags & BP_FLAG_BF16_WEIGHTS);  // conv weights carry an f16 lo part
   int e = dom ? -1 : 0;  // index of the last event recorded
-  hipEvent_t* ev = h->ev[h->timed_chunks % bp_context::kTimedRing];
+  const int ring_slot = (int)(h->timed_chunks % bp_context::kTimedRing);
+  hipEvent_t* ev = h->ev[ring_slot];
+  int* seq = h->seq[ring_slot];
   if (timing) BP_HIP(hipEventRecord(ev[0], s));
   // dominant-kernel timing: one (begin, end) pair per launch of the kernel; the interval between two pairs is no stage
 #define BP_DOM_BEGIN()                                \
   do {                                                \
     if (dom) {                                        \
-      if (e >= 0) h->seq[e] = -1;                     \
+      if (e >= 0) seq[e] = -1;                        \
       BP_HIP(hipEventRecord(ev[e + 1], s));           \
       ++e;                                            \
     }                                                 \
@@ -728,7 +732,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
 #define BP_DOM_END(id)                                \
   do {                                                \
     if (dom) {                                        \
-      h->seq[e] = (id);                               \
+      seq[e] = (id);                                  \
       BP_HIP(hipEventRecord(ev[e + 1], s));           \
       ++e;                                            \
     }                                                 \
@@ -737,7 +741,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
 #define BP_MARK(id)                                \
   do {                                             \
     if (timing) {                                  \
-      h->seq[e] = (id);                            \
+      seq[e] = (id);                               \
       BP_HIP(hipEventRecord(ev[++e], s));          \
     }                                              \
   } while (0)
@@ -818,7 +822,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
 #undef BP_DOM_BEGIN
 #undef BP_DOM_END
   if (timing || dom) {
-    h->n_seq = e < 0 ? 0 : e;
+    h->n_seq[ring_slot] = e < 0 ? 0 : e;
     h->timed_chunks++;
   }
   BP_HIP(hipGetLastError());
@@ -1528,11 +1532,11 @@ int bp_get_stage_ms(bp_handle h, float* ms, int n) {
   const int64_t cnt = h->timed_chunks < bp_context::kTimedRing ? h->timed_chunks : bp_context::kTimedRing;
   double acc[BP_N_STAGES] = {0};
   for (int64_t c = 0; c < cnt; ++c) {
-    for (int i = 0; i < h->n_seq; ++i) {
+    for (int i = 0; i < h->n_seq[c]; ++i) {
       float t = 0.f;
-      if (h->seq[i] < 0) continue;
+      if (h->seq[c][i] < 0) continue;
       BP_HIP(hipEventElapsedTime(&t, h->ev[c][i], h->ev[c][i + 1]));
-      acc[h->seq[i]] += t;
+      acc[h->seq[c][i]] += t;
     }
   }
   for (int i = 0; i < BP_N_STAGES; ++i) ms[i] = (float)(acc[i] / (double)cnt);
