@@ -30,6 +30,7 @@ SOURCES = [
     "conv_branch.hip",
     "note_march.hip",
     "onset_march.hip",
+    "onset_march16.hip",
     "audio_ingest.hip",
     "note_decode.cpp",
     "flac_decode.cpp",
@@ -65,6 +66,10 @@ FLAGS = [
     # the fully unrolled 63-k-step MFMA loops exceed clang's default size limit for `#pragma unroll`
     "-mllvm",
     "-pragma-unroll-threshold=400000",
+    # no SLP packing of adjacent f32 operations into v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: beside matrix instructions
+    # a packed-f32 operation costs ~3.5 x a plain VALU operation (profiles/r04_ubench_shadow.md); note march -5 %,
+    # filterbank -3 %, onset -2 % (round 4, same-box A/B)
+    "-fno-slp-vectorize",
 ]
 
 

@@ -71,6 +71,8 @@ void launch_contour_conv1_rim(const uint32_t* zp, const void* afrag, const float
                               bool weights_have_lo, hipStream_t stream);
 void launch_onset_march(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, float* onset,
                         int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
+void launch_onset_march16(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, float* onset,
+                          int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
 void launch_contour_conv1_fold_mx(const uint32_t* zp, const void* a16, const void* amx, const void* ascale,
                                   const float* bias, float* c1, int n_windows, int n_cu, hipStream_t stream);
 void launch_contour_conv2(const float* c1, const float* w2, float bias, float* contour, int n_windows, int n_cu,
@@ -79,18 +81,20 @@ void launch_note_march(const float* contour, const void* wfrag, const float* wf3
                        bool weights_have_lo, hipStream_t stream);
 void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, const void* wmx,
                          float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
-// the onset branch: the wave-private march by default; the workgroup kernel for the fp8-correction mode (it carries the
-// block-scaled products) and behind BP_ONSET=ring (A/B runs)
+// the onset branch: the wave-private march on 16x16x32 by default (round 4); its 32x32x16 form behind BP_ONSET=march32,
+// the workgroup kernel for the fp8-correction mode (it carries the block-scaled products) and behind BP_ONSET=ring (A/B runs)
 static void launch_onset(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, const void* wmx,
-                         float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream) {
-  static const bool ring = [] {
+                         const void* w16, float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream) {
+  static const int kind = [] {
     const char* e = std::getenv("BP_ONSET");
-    return e && std::strcmp(e, "ring") == 0;
+    return e && std::strcmp(e, "ring") == 0 ? 2 : (e && std::strcmp(e, "march32") == 0 ? 1 : 0);
   }();
-  if (wmx || ring)
+  if (wmx || kind == 2)
     launch_onset_branch(zp, note, wfrag, wf32, wmx, onset, n_windows, n_cu, weights_have_lo, stream);
-  else
+  else if (kind == 1 || !w16)
     launch_onset_march(zp, note, wfrag, wf32, onset, n_windows, n_cu, weights_have_lo, stream);
+  else
+    launch_onset_march16(zp, note, w16, wf32, onset, n_windows, n_cu, weights_have_lo, stream);
 }
 }  // namespace bp
 
@@ -195,7 +199,7 @@ struct bp_context {
   float *d_lowpass = nullptr, *d_sqrt_len = nullptr, *d_fb_bfrag = nullptr;
   // fused branches (conv_branch.hip): f16 hi/lo A fragments (raw bytes) + {bias1[32], extra[9], bias2}
   float *d_note_wfrag = nullptr, *d_note_wf32 = nullptr, *d_onset_wfrag = nullptr, *d_onset_wf32 = nullptr,
-        *d_onset_wmx = nullptr;
+        *d_onset_wmx = nullptr, *d_onset_w16 = nullptr;
   float* zp = nullptr;  // uint32 [cap][kZRowsP][kZRow] pre-split z, zero padded (bp_common.h)
   // contour branch, two-kernel form (conv_contour_direct.hip): LDS weight image, bias[8], conv2 taps [5][5][8]
   float *d_d1_wlds = nullptr, *d_d1_wfold = nullptr, *d_d1_wrim = nullptr, *d_d1_bias = nullptr,
@@ -642,6 +646,33 @@ void pack_branch(int ks1, const Tensor* w1, const Tensor* w2, bool onset, std::v
       }
 }
 
+// onset_march16.hip: conv1 (8 -> 32, 5 x 5, models.py:295-304) and the 3 x 3 head's feature channels (305-318) as
+// v_mfma_f32_16x16x32_f16 A fragments: [A1 hi: (2 s + mb) x 64 lanes][A1 lo: 14 + ...][A2 hi][A2 lo] x 8 f16.
+// A1: lane (m = lane & 15, g = lane >> 4), element e: out channel 16 mb + m, stack channel e, tap onset16_{dt,dw}(s, g).
+// A2: row rho = lane & 15 = 4 dt + dw (dt, dw < 3), K index 8 g + e <-> conv1 channel 4 g + e (e < 4) or 16 + 4 g + e - 4:
+// the order in which conv1's C layout leaves a pixel's channels in a lane.
+void pack_onset16(const Tensor* w1, const Tensor* w2, std::vector<uint16_t>& out) {
+  const size_t frag = 64 * 8, a1h = 0, a1l = 2 * kOnset16KSteps * frag, a2h = 2 * a1l, a2l = a2h + frag;
+  out.assign(a2l + frag, 0);
+  for (int s = 0; s < kOnset16KSteps; ++s)
+    for (int mb = 0; mb < 2; ++mb)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const int m = lane & 15, g = lane >> 4;
+          const int q = onset16_dt(s, g) * 5 + onset16_dw(s, g);
+          const float v = onset16_live(s, g) ? w1->data[((16 * mb + m) * 8 + e) * 25 + q] : 0.f;
+          put_split(out, a1h, a1l, ((size_t)(2 * s + mb) * 64 + lane) * 8 + e, v, 2048.0f);
+        }
+  for (int lane = 0; lane < 64; ++lane)
+    for (int e = 0; e < 8; ++e) {
+      const int rho = lane & 15, g = lane >> 4;
+      const int dt = rho >> 2, dw = rho & 3;
+      const int ch = e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4);
+      const float v = (dt < 3 && dw < 3) ? w2->data[((1 + ch) * 3 + dt) * 3 + dw] : 0.f;  // channel 0 of the concat is the note map
+      put_split(out, a2h, a2l, (size_t)lane * 8 + e, v, 2048.0f);
+    }
+}
+
 // cqt_planes.hip decimator (transposed: the filter is the A operand): T[u][i] = h[i - 2u - 1] — the input window starts one
 // sample before the reference's (an 8-sample aligned element of the padded plane) — as [hi: 9 steps][lo: 9 steps] x 64
 // lanes x 8 f16; lane (u = lane & 15, kg = lane >> 4), element e: i = 32 s + 8 kg + e.
@@ -683,7 +714,7 @@ void pack_filterbank_planes(const Tensor* re, const Tensor* im, std::vector<uint
 }
 
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->planes, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wrim, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->planes, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->d_onset_w16, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wrim, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->fb_scratch, h->pcm_dev, h->mono_dev, h->res_dev, reinterpret_cast<float*>(h->taps_dev)};
@@ -814,7 +845,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
     }
     launch_note_march(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, wlo, s);
     BP_MARK(BP_STAGE_NOTE);
-    launch_onset(reinterpret_cast<const uint32_t*>(h->zp), note_dev, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, onset_dev,
+    launch_onset(reinterpret_cast<const uint32_t*>(h->zp), note_dev, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->d_onset_w16, onset_dev,
                  n, h->n_cu, wlo, s);
     BP_MARK(BP_STAGE_ONSET);
   }
@@ -1026,6 +1057,10 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       if ((rc = upload(h, raw_of(frag), br ? &h->d_onset_wfrag : &h->d_note_wfrag)) ||
           (rc = upload(h, f32, br ? &h->d_onset_wf32 : &h->d_note_wf32)))
         return fail(rc);
+    }
+    {  // the onset march on 16x16x32 (the default): its own fragment order
+      pack_onset16(o1w, o2w, frag);
+      if ((rc = upload(h, raw_of(frag), &h->d_onset_w16))) return fail(rc);
     }
     // onset conv1: fp8 corrections under BP_FLAG_FP8_CORRECTIONS like the folded contour conv1 (BP_ONSET=f16: not this layer)
     if (const char* eo = std::getenv("BP_ONSET"); !(eo && std::strcmp(eo, "f16") == 0) && fp8_ok && !(flags & BP_FLAG_BF16_WEIGHTS)) {
@@ -1657,7 +1692,7 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
       break;
     case BP_STAGE_ONSET:
       if ((ok = need(bf->zp) && need(bf->note) && need(bf->onset)))
-        launch_onset(bf->zp, bf->note, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, bf->onset, n, h->n_cu, wlo, s);
+        launch_onset(bf->zp, bf->note, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->d_onset_w16, bf->onset, n, h->n_cu, wlo, s);
       break;
     default:
       h->err = "bp_run_stage: unknown stage";

@@ -58,6 +58,15 @@ __host__ __device__ constexpr int harm_shift(int c) {
   return s[c];
 }
 
+// Tap order of the onset conv1 on v_mfma_f32_16x16x32_f16 (onset_march16.hip; shared with the host packer in bp_api.hip):
+// k-step s, lane group g = lane >> 4 takes tap (dt, dw) of the 5 x 5 window (models.py:295-304) for its 8 channels.
+// k-steps 0..4: image row dt = s, dw = {0, 3, 1, 4}[g]; k-step 5: dw = 2 of rows dt = g; k-step 6: (4, 2) and three
+// zero-weight dummies that read the same slot.  Lane pairs (g even, g odd) differ by dw 0 or +3: conflict-free reads.
+constexpr int kOnset16KSteps = 7;
+__host__ __device__ constexpr int onset16_dt(int s, int g) { return s < 5 ? s : (s == 5 ? g : 4); }
+__host__ __device__ constexpr int onset16_dw(int s, int g) { return s < 5 ? (g == 0 ? 0 : (g == 1 ? 3 : (g == 2 ? 1 : 4))) : 2; }
+__host__ __device__ constexpr bool onset16_live(int s, int g) { return s < 6 || g == 0; }
+
 // Split-precision operands: x = hi + lo / kLoScale with hi = rn_f16(x), lo = rn_f16((x - hi) * kLoScale).
 // The scale keeps the residual (<= 2^-12 |x|) inside f16's normal exponent range; products are
 // hi*hi + (lo*hi + hi*lo) * kLoUnscale, accumulated in fp32 (separate accumulators per scale).
@@ -104,10 +113,12 @@ __device__ __forceinline__ float wave_max_lane63(float v) {
 __device__ __forceinline__ uint32_t split_lo(uint32_t hi2, f32x2 v) {
   uint32_t l = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
+  // plain f32 operations on purpose: beside matrix instructions a v_pk_add_f32 / v_pk_mul_f32 costs ~3.5 x a plain VALU
+  // operation (tools/ubench/mfma_shadow.hip, profiles/r04_ubench_shadow.md); the files are built with -fno-slp-vectorize
   const f16x2 h = __builtin_bit_cast(f16x2, hi2);
-  const f32x2 hf = {(float)h.x, (float)h.y};
-  const f32x2 d = (v - hf) * f32x2{2048.0f, 2048.0f};
-  const f16x2 lh = {(_Float16)d.x, (_Float16)d.y};
+  const float d0 = (v.x - (float)h.x) * 2048.0f;
+  const float d1 = (v.y - (float)h.y) * 2048.0f;
+  const f16x2 lh = {(_Float16)d0, (_Float16)d1};
   l = __builtin_bit_cast(uint32_t, lh);
 #endif
   return l;
