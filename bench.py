@@ -266,6 +266,103 @@ def run_files(args) -> None:
                    + how, "host_threads": min(16, os.cpu_count() or 1), "note_events": n_events},
     }), flush=True)
 
+STEP_ALGORITHMIC_BYTES_PER_WINDOW = BYTES_PER_WINDOW  # fp32 audio in + three fp32 posteriorgrams out
+
+
+def pmc_step_traffic(batch: int):
+    """Whole-step HBM bytes (every kernel of one step: PMC read x 2 + written, the committed profile) and their ratio to
+    the step's algorithmic bytes (audio in + posteriorgrams out): what the implementation moves beyond what the path
+    has to.  None when no profile for this batch is committed."""
+    path = os.path.join(ROOT, "profiles", PMC_PROFILE + "_pmc.json")
+    if batch != 256 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        prof = json.load(f)
+    total = sum((v.get("hbm_read_bytes", 0.0) + v.get("hbm_write_bytes", 0.0)) * v.get("launches_per_step", 1)
+                for v in prof.values() if isinstance(v, dict))
+    alg = STEP_ALGORITHMIC_BYTES_PER_WINDOW * batch
+    return {"bytes_per_step": total, "algorithmic_bytes_per_step": alg, "ratio": total / alg,
+            "source": "profiles/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % PMC_PROFILE}
+
+
+def config_extras(torch, local_rank: int, steps: int = 4) -> dict:
+    """The other BASELINE.json configs and the reference's own call pattern, a few steps each, AFTER the timed region
+    (rank 0 only): beside `value`, never instead of it.  Every entry: windows/s and ms per step (per call)."""
+    from basic_pitch_amd.inference import Model
+
+    dev = torch.device("cuda", local_rank)
+    out = {}
+
+    def windows_mode(key, B, note, **kw):
+        g = torch.Generator(device=dev)
+        g.manual_seed(4321)
+        win = 87688 if kw.get("ext_cqt_44k") else 43844
+        audio = (torch.rand((B, win), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0).contiguous()
+        o = {"note": torch.empty((B, 172, 88), device=dev), "onset": torch.empty((B, 172, 88), device=dev),
+             "contour": torch.empty((B, 172, 264), device=dev)}
+        m = Model(device=local_rank, max_windows=B, **kw)
+        for _ in range(2):
+            m._predict_device(audio, out=o, sync=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m._predict_device(audio, out=o, sync=False)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        m.close()
+        out[key] = {"windows_per_s": B * steps / el, "ms_per_step": el / steps * 1e3, "batch": B, "steps": steps,
+                    "config": note}
+        del audio, o
+
+    windows_mode("b1024", 1024, "fp32, batch 1024 (configs[1] at 4 x the batch)")
+    windows_mode("bf16_b1024", 1024, "bf16 CNN weights + fp32 CQT, batch 1024 (configs[3])", bf16_weights=True)
+    windows_mode("ext44k_b512", 512, "44.1 kHz windows, extended 345-bin CQT, batch 512 (configs[4]; one GPU's share)",
+                 ext_cqt_44k=True)
+    windows_mode("b16", 16, "fp32, batch 16 (small-batch latency)")
+
+    # configs[2] on one GPU: 256 synthetic 3-minute tracks (110 windows each), 64 per bp_infer_tracks call, device in/out
+    m = Model(device=local_rank, max_windows=256)
+    n_samples = 180 * 22050
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    pool = [(torch.rand((n_samples,), generator=g, device=dev) * 2.0 - 1.0).contiguous() for _ in range(4)]
+    n_win = int(m._lib.bp_track_n_windows(n_samples))
+    m.predict_tracks([pool[j % 4] for j in range(16)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        m.predict_tracks([pool[j % 4] for j in range(64)])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out["tracks_256x3min"] = {"windows_per_s": 256 * n_win / el, "tracks_per_s": 256 / el, "windows_per_track": n_win,
+                              "config": "256 synthetic 3-minute tracks through bp_infer_tracks, 64 per call, device "
+                                        "in/out (configs[2], one GPU's share)"}
+    m.close()
+    del pool
+    return out
+
+
+def seam_b1_host(calls: int = 30) -> dict:
+    """The reference's real call pattern (basic_pitch/inference.py:308-310, 173-180): one host window per
+    `session.run([...], {input: x[n:n+1]})` through the onnxruntime-shaped seam — H2D, all kernels at batch 1, D2H, three
+    fresh numpy arrays per call."""
+    from basic_pitch_amd import ort_shim
+    from basic_pitch_amd.inference import ICASSP_2022_MODEL_PATH
+
+    sess = ort_shim.InferenceSession(str(ICASSP_2022_MODEL_PATH), max_windows=1)
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, (1, 43844, 1)).astype(np.float32)
+    names = ["StatefulPartitionedCall:1", "StatefulPartitionedCall:2", "StatefulPartitionedCall:0"]
+    for _ in range(3):
+        sess.run(names, {ort_shim.INPUT_NAME: x})
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        sess.run(names, {ort_shim.INPUT_NAME: x})
+    el = time.perf_counter() - t0
+    return {"windows_per_s": calls / el, "ms_per_call": el / calls * 1e3, "calls": calls,
+            "config": "ort_shim.InferenceSession.run on ONE host window per call (the reference's batch-1 loop, "
+                      "inference.py:308-310): PCIe in, batch-1 kernels, PCIe out"}
+
 
 def main() -> None:
     ap = argparse.ArgumentParser()
@@ -294,6 +391,8 @@ def main() -> None:
                     help="BP_FLAG_FP8_CORRECTIONS (opt-in, reduced precision): the contour / onset conv1 corrections on "
                          "block-scaled fp8 MFMA; not the headline line")
     ap.add_argument("--no-fp8-extra", action="store_true", help="skip the extra fp8-corrections rate (profiling runs)")
+    ap.add_argument("--no-config-extras", action="store_true",
+                    help="skip the side rates of the other BASELINE.json configs and of the batch-1 host seam (profiling runs)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="all ranks use device 0 (exercising the N > 1 path on a one-GPU box; the numbers mean nothing)")
     ap.add_argument("--control-backend", choices=["gloo", "nccl"], default="gloo",
@@ -558,6 +657,9 @@ def main() -> None:
                 "frac": achieved / c1_peak,
                 "traffic": pmc_traffic(c1_key, B) if c1_key else None,
                 "traffic_unit": "bytes per launch (PMC, profiles/%s_pmc.md)" % PMC_PROFILE,
+                # the kernel's own ratio above is ~1; the STEP moves far more than the path's algorithmic I/O (c1 round trip,
+                # pyramid planes, lp): that ratio belongs on the line too
+                "step_traffic": pmc_step_traffic(B) if c1_key else None,
                 "algorithmic_bytes_per_launch": c1_bytes,
                 "executed_mfma_tflops": c1_exec,  # incl. the 3-product split and Toeplitz padding
                 "executed_frac": c1_exec / c1_peak,
@@ -599,6 +701,13 @@ def main() -> None:
                 "algorithmic_flop_per_window": 79_425_024,
             }
         line.update(extras)
+        if (not args.no_config_extras and not args.exact_f32 and not args.fp8_corrections
+                and not (args.bf16_weights or args.ext_cqt_44k) and B == BATCH):
+            model.close()
+            del audio, out
+            torch.cuda.empty_cache()
+            line["configs"] = config_extras(torch, local_rank)
+            line["seam_b1_host"] = seam_b1_host()
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()  # rank 0's host cores, after the timed region, for any N
         print(json.dumps(line), flush=True)

@@ -57,3 +57,9 @@ def test_bench_single_rank_line_has_the_contract_keys():
     assert line["fp8_corrections_windows_per_s"] > 0 and line["exact_f32_windows_per_s"] > 0
     r = line["roofline"]
     assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # every BASELINE.json config and the reference's batch-1 host call pattern are in the driver's record (round 4)
+    for k in ("b1024", "bf16_b1024", "ext44k_b512", "tracks_256x3min", "b16"):
+        assert line["configs"][k]["windows_per_s"] > 0, k
+    assert line["seam_b1_host"]["windows_per_s"] > 0 and line["seam_b1_host"]["ms_per_call"] > 0
+    st = r["step_traffic"]
+    assert st is None or (st["ratio"] > 1.0 and st["bytes_per_step"] > st["algorithmic_bytes_per_step"])

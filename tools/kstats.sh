@@ -3,7 +3,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ks_$$
-env $2 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$$ -o b -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustained-s 0 --no-exact-f32 --no-fp8-extra $1 > /tmp/ks_$$.log 2>&1
+env $2 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$$ -o b -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustained-s 0 --no-exact-f32 --no-config-extras --no-fp8-extra $1 > /tmp/ks_$$.log 2>&1
 grep '^{' /tmp/ks_$$.log | python -c "
 import json,sys
 for l in sys.stdin:

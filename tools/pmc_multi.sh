@@ -8,7 +8,7 @@ i=0
 while [ $# -gt 0 ]; do
   grp=""; n=0
   while [ $# -gt 0 ] && [ $n -lt 7 ]; do grp="$grp $1"; shift; n=$((n+1)); done
-  env $envs rocprofv3 --pmc $grp --output-format csv -d /tmp/pmcm_$$_$i -o b -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --sustained-s 0 --no-exact-f32 > /dev/null 2>&1
+  env $envs rocprofv3 --pmc $grp --output-format csv -d /tmp/pmcm_$$_$i -o b -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --sustained-s 0 --no-exact-f32 --no-config-extras > /dev/null 2>&1
   i=$((i+1))
 done
 python - "$pat" /tmp/pmcm_$$_ <<'PY'

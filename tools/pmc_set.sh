@@ -3,7 +3,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmcs_$$
-env ${3:-X=1} rocprofv3 --pmc $2 --output-format csv -d /tmp/pmcs_$$ -o b -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --sustained-s 0 --no-exact-f32 --no-fp8-extra > /tmp/pmcs_$$.log 2>&1
+env ${3:-X=1} rocprofv3 --pmc $2 --output-format csv -d /tmp/pmcs_$$ -o b -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --sustained-s 0 --no-exact-f32 --no-config-extras --no-fp8-extra > /tmp/pmcs_$$.log 2>&1
 python - "$1" /tmp/pmcs_$$ <<'PY'
 import csv, sys, glob, collections
 pat, d = sys.argv[1], sys.argv[2]

@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --sustained-s 0 --no-exact-f32 --no-fp8-extra"
+CMD="python $ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --sustained-s 0 --no-exact-f32 --no-config-extras --no-fp8-extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o bench -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o bench -- $CMD > $OUT/write.log 2>&1
