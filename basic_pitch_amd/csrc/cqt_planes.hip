@@ -881,7 +881,9 @@ void launch_pyramid_planes(const float* audio, int64_t audio_stride, uint16_t* p
     int lds_first = first_tail;
     while (pl_tail_lds_need(g, lds_first, g.n_levels - 1) > kPlTailLdsElems) ++lds_first;
     int last = g.n_levels - 1;
-    if (const char* e = getenv("BP_TAIL_LAST")) last = atoi(e);  // tools only (timing of the first levels; garbage results)
+#ifdef BP_PLANES_DEBUG_HOOKS  // tools only (tools/build_variant.sh ... -DBP_PLANES_DEBUG_HOOKS): garbage results
+    if (const char* e = getenv("BP_TAIL_LAST")) last = atoi(e);  // timing of the first levels
+#endif
     hipLaunchKernelGGL(pl_decimate_tail_kernel, dim3(n_windows), dim3(kPlTailThreads), 0, stream, pl, g,
                        PlTail{first_tail, last, lds_first}, tf);
   }
@@ -895,11 +897,13 @@ int filterbank_planes_partials(bool ext) { return make_pl_geo(ext).n_levels * kP
 bool launch_filterbank_planes(const uint16_t* pl, const void* bfrag, const float* sqrt_len, float* lp, float* scratch,
                               uint32_t* zp, int n_windows, LogConsts kc, int n_cu, bool ext, hipStream_t stream) {
   PlGeo g = make_pl_geo(ext);
-  if (const char* e = getenv("BP_FB_ONLY_LEVEL")) {  // tools only (timing of one level's tasks; results are garbage)
+#ifdef BP_PLANES_DEBUG_HOOKS  // tools only: timing of one level's tasks; results are garbage
+  if (const char* e = getenv("BP_FB_ONLY_LEVEL")) {
     const int k = atoi(e);
     g.hop0 >>= k, g.off[0] = g.off[k], g.len[0] = g.len[k], g.n_levels = 1;
     zp = nullptr;
   }
+#endif
   const int tasks = n_windows * g.n_levels * kPlTilesPerLevel;
   static const int variant = [] {  // BP_FB_WAVES=16 / 12 / 11: waves per workgroup (A/B runs); default 16
     const char* e = getenv("BP_FB_WAVES");

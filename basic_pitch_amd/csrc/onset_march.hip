@@ -1,5 +1,6 @@
-// Onset branch, wave-private march (round 3; the workgroup kernel of conv_branch.hip stays for the fp8-correction mode
-// and as the A/B reference, BP_ONSET=ring).
+// Onset branch, wave-private march on 32x32x16 (round 3; since round 4 behind BP_ONSET=march32: the default is its
+// 16x16x32 form, onset_march16.hip.  The workgroup kernel of conv_branch.hip stays for the fp8-correction mode and as the
+// A/B reference, BP_ONSET=ring).
 //
 //   basic_pitch/models.py:295-318: Conv2D 8->32, 5x5, strides (1,3), "same", folded BN, ReLU on the harmonic stack
 //   (nn.py:69-88), Concatenate([note, features]) (305), Conv2D 33->1, 3x3, "same", sigmoid -> onset
@@ -151,6 +152,10 @@ __global__ __launch_bounds__(64 * kOmWaves, 2) void onset_march_kernel(OnsetMarc
         ring[(slot * 2 + 0) * kOmSlots + 64 + lane] = vh;
         ring[(slot * 2 + 1) * kOmSlots + 64 + lane] = vl;
       }
+      // the ring is written lane-private and read across lanes: order the wave's LDS writes before the reads that follow
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     auto note_at = [&](int row) {  // unconditional load from a clamped address, masked where it is used
       const int rc = row < 0 ? 0 : (row > kFrames - 1 ? kFrames - 1 : row);

@@ -145,6 +145,7 @@ def _post(queue, rank: int, produce: Callable[[], Any]) -> None:
     except BaseException as e:  # the parent must not wait forever for a rank that died early
         try:
             payload = pickle.dumps(e)
+            pickle.loads(payload)  # an exception class with a multi-argument __init__ dumps fine and fails to LOAD
         except Exception:
             payload = pickle.dumps(RuntimeError(f"rank {rank}: {type(e).__name__}: {e}"))
     queue.put((rank, payload))
@@ -174,7 +175,10 @@ def _collect(procs, queue, what: str, poll_s: float = 0.5) -> Dict[int, Any]:
                             f"{what}: worker {r} exited with code {procs[r].exitcode} without posting a result")
             continue
         pending.discard(rank)
-        part = pickle.loads(payload)
+        try:
+            part = pickle.loads(payload)
+        except Exception as e:  # never abort the collection: the other workers are still running and must be joined
+            part = RuntimeError(f"{what}: the result of worker {rank} could not be unpickled: {type(e).__name__}: {e}")
         if isinstance(part, BaseException):
             failed = failed or part
         else:

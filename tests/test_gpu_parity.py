@@ -341,8 +341,8 @@ def test_tonal_windows_distribution(weights):
     """Tonal input (music) is where fp32 evaluations of this graph scatter most (the per-window minimum of the log-power
     sits on a cancellation-noise bin).  Over 32 tonal windows + a loud and a quiet 440 Hz sine the path is held to the
     fp32 oracle's own distribution: worst window within 2x the oracle's worst, median distance to fp64 not above the
-    oracle's, SURVEY.md 8c's per-window bound max(1e-4, 2 x the fp32 oracle's own distance) on at least 90 % of the
-    windows — the two evaluations are independent draws of a heavy-tailed noise, so a per-window bound on EVERY window
+    oracle's, SURVEY.md 8c's per-window bound max(1e-4, 2 x the fp32 oracle's own distance) on all but at most one of the
+    34 windows (and that one within 1.5 x the bound) — the two evaluations are independent draws of a heavy-tailed noise, so a per-window bound on EVERY window
     holds only for a lucky summation order (it did for the round-2 CQT kernels, it does not for the round-3 ones; see
     profiles/r03_parity_bench_batch.md for the same effect on white noise).  |hip - fp32 oracle| is printed (SURVEY.md
     §8c asks for it) — it is the sum of two independent noises and not a parity criterion."""
@@ -364,7 +364,11 @@ def test_tonal_windows_distribution(weights):
           f"max {o64.max():.2e}; |hip-fp32| median {np.median(h32):.2e} max {h32.max():.2e}")
     bound = np.maximum(1e-4, 2.0 * o64)
     print(f"tonal: within max(1e-4, 2 x fp32 oracle): {(h64 <= bound).sum()}/{len(x)}; worst ratio {(h64 / bound).max():.2f}")
-    assert (h64 <= bound).mean() >= 0.9, (h64, o64)
+    # the gate sits at the measured level (33 / 34 windows inside the bound, worst ratio 1.28: rounds 3 and 4), not at a
+    # loose fraction: at most ONE of the 34 windows outside, and by no more than a factor 1.5
+    outside = int((h64 > bound).sum())
+    assert outside <= 1, (outside, h64, o64)
+    assert (h64 / bound).max() <= 1.5, (h64 / bound).max()
     assert h64.max() <= 2.0 * o64.max(), (h64.max(), o64.max())
     assert np.median(h64) <= np.median(o64)
     assert h64[33] <= 1e-4  # the quiet sine: no cancellation floor, plain 1e-4
