@@ -50,11 +50,14 @@ void launch_planes_split(const float* src, int64_t src_stride, int level, uint16
                          hipStream_t stream);
 void launch_planes_unsplit(const uint16_t* pl, int level, float* dst, int64_t dst_stride, int n_windows, bool ext,
                            hipStream_t stream);
+void launch_planes_edge_rows(const float* audio, int64_t audio_stride, uint16_t* pl, int n_windows, bool ext,
+                             hipStream_t stream);
 void launch_pyramid_planes(const float* audio, int64_t audio_stride, uint16_t* pl, const void* tfrag, int n_windows,
                            int n_cu, bool ext, hipStream_t stream);
 int filterbank_planes_partials(bool ext);
 void launch_mm_reduce(const float* scratch, int* mm, int n_windows, int n_partials, hipStream_t stream);
-bool launch_filterbank_planes(const uint16_t* pl, const void* bfrag, const float* sqrt_len, float* lp, float* scratch,
+bool launch_filterbank_planes(const uint16_t* pl, const float* audio, int64_t audio_stride, const void* bfrag,
+                              const float* sqrt_len, float* lp, float* scratch,
                               uint32_t* zp, int n_windows, LogConsts kc, int n_cu, bool ext, hipStream_t stream);
 void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc, int n_bins,
                   hipStream_t s);
@@ -788,7 +791,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
     launch_pyramid_planes(audio_dev, h->win_len, pl, h->d_pl_tfrag, n, h->n_cu, h->ext, s);
     BP_MARK(BP_STAGE_PYRAMID);
     // with at least half a window per CU the kernel also normalises / BatchNorms / splits its windows (`zp` complete)
-    zp_done = launch_filterbank_planes(pl, h->d_pl_bfrag, h->d_sqrt_len, h->lp, h->fb_scratch,
+    zp_done = launch_filterbank_planes(pl, audio_dev, h->win_len, h->d_pl_bfrag, h->d_sqrt_len, h->lp, h->fb_scratch,
                                        reinterpret_cast<uint32_t*>(h->zp), n, h->kc, h->n_cu, h->ext, s);
     BP_MARK(BP_STAGE_FILTERBANK);
   }
@@ -1627,13 +1630,13 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
             return BP_ERR_INVALID_ARG;
           }
           uint16_t* pl = reinterpret_cast<uint16_t*>(h->planes);
-          launch_planes_split(bf->audio, h->win_len, 0, pl, n, h->ext, s);
+          launch_planes_edge_rows(bf->audio, h->win_len, pl, n, h->ext, s);  // level 0: fp32, straight from the audio
           const int n_lev = h->ext ? kOctavesExt : kOctaves;
           for (int k = 1; k < n_lev; ++k) {
             const int64_t off = h->ext ? ((k == 1) ? 0 : kAudioN + pyr_off(k - 1)) : pyr_off(k);
             launch_planes_split(bf->pyr + off, h->pyr_stride, k, pl, n, h->ext, s);
           }
-          (void)launch_filterbank_planes(pl, h->d_pl_bfrag, h->d_sqrt_len, bf->lp, h->fb_scratch, nullptr, n, h->kc, h->n_cu,
+          (void)launch_filterbank_planes(pl, bf->audio, h->win_len, h->d_pl_bfrag, h->d_sqrt_len, bf->lp, h->fb_scratch, nullptr, n, h->kc, h->n_cu,
                                          h->ext, s);
           launch_mm_reduce(h->fb_scratch, bf->mm, n, filterbank_planes_partials(h->ext), s);
         }

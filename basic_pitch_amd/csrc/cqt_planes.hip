@@ -25,6 +25,7 @@
 // Arithmetic is unchanged: x = hi + lo 2^-11 (rn), products hi*hi + (lo*hi + hi*lo) 2^-11 on v_mfma_f32_16x16x32_f16,
 // fp32 accumulation, taps pre-scaled by 2^10 (decimator) / 2^12 (CQT kernels) — see cqt_mfma.hip's header.
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "bp_common.h"
@@ -72,6 +73,39 @@ PlGeo make_pl_geo(bool ext) {
 }
 
 int64_t planes_elements_per_window(bool ext) { return 2 * make_pl_geo(ext).stride; }
+
+// Level 0's "edge rows" (fp32, where the level-0 planes used to be: element 0 of the window's hi plane).  Frame f's
+// 256-sample window reads samples f hop - 128 .. f hop + 127 with reflection at both ends (nnaudio.py:229, 300-301).  The
+// filterbank takes a frame straight from the audio when its taps 16..239 lie inside the signal; row 0 holds frame 0's
+// window, rows 1.. those of the frames from pl_edge_frame() to 175 (the 11th tile's padding frames included: finite
+// values nobody's result depends on), all with the reflection applied.
+__host__ __device__ inline int pl_edge_frame(int L0, int hop0) { return (L0 - 111 + hop0 - 1) / hop0; }  // first f with f hop + 111 >= L0
+constexpr int kPlEdgeRowsMax = 1 + 8;
+
+__device__ __forceinline__ void pl_write_edge_rows(const float* __restrict__ x, int L, float* __restrict__ rows, int hop0,
+                                                   bool head, int lane) {
+  const int f_edge = pl_edge_frame(L, hop0);
+  const int r0 = head ? 0 : 1, r1 = head ? 1 : 1 + kPlTilesPerLevel * 16 - f_edge;
+  for (int r = r0; r < r1; ++r) {
+    const int f = r == 0 ? 0 : f_edge + r - 1;
+    for (int j = lane; j < 256; j += 64) {
+      int i = f * hop0 + j - kPlPad;
+      i = i < 0 ? -i : i;                     // reflection without repeating the edge sample
+      i = i >= L ? 2 * (L - 1) - i : i;
+      const bool ok = i >= 0 && i < L;        // beyond one reflection: the padding frames' slack
+      rows[r * 256 + j] = ok ? x[ok ? i : 0] : 0.0f;
+    }
+  }
+}
+
+// the same as a launch of its own (the per-stage test hook, whose planes come from pl_split_kernel)
+__global__ __launch_bounds__(64) void pl_edge_rows_kernel(const float* __restrict__ audio, int64_t audio_stride, int L,
+                                                          uint16_t* __restrict__ pl, int64_t stride, int off0, int hop0) {
+  const float* x = audio + (int64_t)blockIdx.x * audio_stride;
+  float* rows = reinterpret_cast<float*>(pl + (int64_t)blockIdx.x * 2 * stride + off0);
+  pl_write_edge_rows(x, L, rows, hop0, true, threadIdx.x);
+  pl_write_edge_rows(x, L, rows, hop0, false, threadIdx.x);
+}
 
 #define BP_PL_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0)
 
@@ -184,6 +218,12 @@ __device__ __forceinline__ PlRaw<F32IN> pl_fetch_rows(const float* __restrict__ 
   const int m = lane & 15, kg = lane >> 4;
   const int base = 2 * kPlTileOut * tile + 32 * m + 8 * kg;
   PlRaw<F32IN> r;
+#if defined(PL_ABLATE) && (PL_ABLATE & 4)  // tools only: no input loads (timing)
+  if constexpr (F32IN) {
+    r.a0 = r.a1 = r.b0 = r.b1 = float4{1.f * tile, 2.f, 3.f * lane, 4.f};
+    return r;
+  }
+#endif
   if constexpr (F32IN) {
     auto row = [&](int g0, float4& lo4, float4& hi4) {
       if (!pl_tile_is_edge(tile, L_in)) {
@@ -238,7 +278,7 @@ __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, const float
                                             uint16_t* __restrict__ out_hi, int L_out, int tile, int n_tiles,
                                             const uint4 (&th)[kPlDmSteps], const uint4* __restrict__ tlo,
                                             uint4* __restrict__ rows, int lane, uint16_t* mir_hi = nullptr,
-                                            int mir_stride = 0) {
+                                            int mir_stride = 0, int hop0 = 0) {
   // keep the lo fragments in LDS: without an opaque offset the compiler hoists the 9 item-invariant reads into registers
   asm volatile("" : "+v"(lane));
   const int m = lane & 15, kg = lane >> 4;
@@ -270,43 +310,18 @@ __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, const float
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   if constexpr (F32IN) {
-    // level-0 planes: this lane's own row is 8 of the 512 elements [2 o0, 2 o0 + 512) the tile owns
-    const bool partial = tile == 0 || 2 * o0 + 512 > kPlPad + L_in;  // some of them lie outside the signal (padding)
-    uint16_t* w0 = in_hi + base;
-    if (!partial) {
-      *reinterpret_cast<uint4*>(w0) = ah;
-      *reinterpret_cast<uint4*>(w0 + stride) = al;
-    } else {
-      const uint32_t hw[4] = {ah.x, ah.y, ah.z, ah.w}, lw[4] = {al.x, al.y, al.z, al.w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int g = base + e - kPlPad;
-        if (g >= 0 && g < L_in) {
-          w0[e] = (uint16_t)(hw[e >> 1] >> (16 * (e & 1)));
-          w0[stride + e] = (uint16_t)(lw[e >> 1] >> (16 * (e & 1)));
-        }
-      }
-    }
-    // reflect padding of level 0 (nnaudio.py:300-301): 128 elements either side, mirrored from the signal itself
-    if (tile == 0 || tile == n_tiles - 1) {
-      for (int side = 0; side < 2; ++side) {
-        if ((side == 0 && tile != 0) || (side == 1 && tile != n_tiles - 1)) continue;
-        for (int j = (lane & 63) + 1; j <= kPlPad; j += 64) {
-          const int g = side == 0 ? j : L_in - 1 - j;                     // mirrored sample
-          const int q = side == 0 ? kPlPad - j : kPlPad + L_in - 1 + j;    // element it lands on
-          if (g >= 0 && g < L_in) {
-            uint16_t h1, l1;
-            pl_split1(x[g], h1, l1);
-            in_hi[q] = h1;
-            in_hi[stride + q] = l1;
-          }
-        }
-      }
-    }
+    // level 0 has no planes since round 4 (the filterbank splits its level-0 samples itself, straight from the fp32
+    // audio); what it cannot read from the audio are the windows that are mirrored at the ends of the signal: the first
+    // tile of a window leaves frame 0's reflect-padded window, the last tile those of the frames from `edge_frame` on, as
+    // fp32 rows where the level-0 planes used to be
+    if (tile == 0 || tile == n_tiles - 1) pl_write_edge_rows(x, L_in, reinterpret_cast<float*>(in_hi), hop0, tile == 0, lane);
   }
 
   f32x4 hh = {0.f, 0.f, 0.f, 0.f}, xx = hh;
   const uint4* tl = tlo + lane;
+#if defined(PL_ABLATE) && (PL_ABLATE & 1)  // tools only: no matrix work (timing; garbage results)
+  hh[0] = __builtin_bit_cast(float, rh[0].x);
+#else
   if constexpr (PF == 0) {
 #pragma unroll
     for (int s = 0; s < kPlDmSteps; ++s) {
@@ -335,6 +350,7 @@ __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, const float
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+#endif
   // the rows are read: the next tile of this wave may overwrite them
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -349,7 +365,11 @@ __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, const float
   split_f16x2_rn(f32x2{v[0], v[1]}, h2.x, l2.x);
   split_f16x2_rn(f32x2{v[2], v[3]}, h2.y, l2.y);
   uint16_t* oh = out_hi + kPlPad + n0;
+#if defined(PL_ABLATE) && (PL_ABLATE & 2)  // tools only: no output stores unless impossible (timing)
+  if (n0 + 3 < L_out && h2.x == 0x12345678u) {
+#else
   if (n0 + 3 < L_out) {
+#endif
     *reinterpret_cast<uint2*>(oh) = h2;
     *reinterpret_cast<uint2*>(oh + stride) = l2;
   }
@@ -413,7 +433,8 @@ template <bool F32IN>
 __global__ __launch_bounds__(256, 4) void pl_decimate_kernel(const float* __restrict__ audio, int64_t audio_stride,
                                                              uint16_t* __restrict__ pl, int64_t stride, int off_in, int L_in,
                                                              int off_out, int L_out, int tiles,
-                                                             const uint4* __restrict__ tfrag, int n_windows) {
+                                                             const uint4* __restrict__ tfrag, int n_windows,
+                                                             int hop0) {
   __shared__ __attribute__((aligned(16))) uint4 tlo[kPlDmSteps * 64];
   __shared__ __attribute__((aligned(16))) uint4 rows_all[4 * kPlRowsU];
   uint4 th[kPlDmSteps];
@@ -432,23 +453,28 @@ __global__ __launch_bounds__(256, 4) void pl_decimate_kernel(const float* __rest
     const int it = blockIdx.x + gridDim.x * __builtin_amdgcn_readfirstlane(j);
     return it < n_items ? it : -1;
   };
+  // rows of TWO items ahead in flight (round 4: with one, a wave had ~3 KB outstanding and the launch sat at the
+  // latency-bandwidth product of 16 waves per CU, not at the HBM rate — dropping the level-0 plane writes did not move it)
+  auto fetch = [&](int it) {
+    const int fb = it / tiles, ft = it - fb * tiles;
+    return pl_fetch_rows<F32IN>(audio + (int64_t)fb * audio_stride, pl + (int64_t)fb * 2 * stride + off_in, stride, L_in, ft,
+                                lane);
+  };
   int item = grab();
   if (item < 0) return;
-  int nitem = grab();
-  int b = item / tiles, tile = item - b * tiles;
-  PlRaw<F32IN> raw = pl_fetch_rows<F32IN>(audio + (int64_t)b * audio_stride, pl + (int64_t)b * 2 * stride + off_in, stride,
-                                          L_in, tile, lane);
+  int item1 = grab();
+  int item2 = item1 >= 0 ? grab() : -1;
+  PlRaw<F32IN> raw = fetch(item);
+  PlRaw<F32IN> raw1 = fetch(item1 >= 0 ? item1 : item);
   for (;;) {
-    const bool more = nitem >= 0;
-    const int nnitem = more ? grab() : -1;
-    const int nb = more ? nitem / tiles : b, ntile = more ? nitem - nb * tiles : tile;
-    const PlRaw<F32IN> nraw = pl_fetch_rows<F32IN>(audio + (int64_t)nb * audio_stride,
-                                                   pl + (int64_t)nb * 2 * stride + off_in, stride, L_in, ntile, lane);
+    const int item3 = item2 >= 0 ? grab() : -1;
+    const PlRaw<F32IN> raw2 = fetch(item2 >= 0 ? item2 : item);
+    const int b = item / tiles, tile = item - b * tiles;
     uint16_t* w = pl + (int64_t)b * 2 * stride;
     pl_dec_tile<F32IN>(raw, audio + (int64_t)b * audio_stride, w + off_in, stride, L_in, w + off_out, L_out, tile, tiles, th,
-                       tlo, rows, lane);
-    if (!more) break;
-    raw = nraw, item = nitem, b = nb, tile = ntile, nitem = nnitem;
+                       tlo, rows, lane, nullptr, 0, hop0);
+    if (item1 < 0) break;
+    raw = raw1, raw1 = raw2, item = item1, item1 = item2, item2 = item3;
   }
 }
 
@@ -471,7 +497,8 @@ __host__ __device__ inline int pl_tail_lds_need(const PlGeo& g, int lds_first, i
   return n;
 }
 
-__global__ __launch_bounds__(kPlTailThreads) void pl_decimate_tail_kernel(uint16_t* __restrict__ pl, PlGeo g, PlTail t,
+__global__ __launch_bounds__(kPlTailThreads) void pl_decimate_tail_kernel(const float* __restrict__ audio, int64_t audio_stride,
+                                                                       uint16_t* __restrict__ pl, PlGeo g, PlTail t,
                                                                        const uint4* __restrict__ tfrag) {
   __shared__ __attribute__((aligned(16))) uint4 tlo[kPlDmSteps * 64];
   __shared__ __attribute__((aligned(16))) uint4 rows_all[(kPlTailThreads / 64) * kPlRowsU];
@@ -487,6 +514,25 @@ __global__ __launch_bounds__(kPlTailThreads) void pl_decimate_tail_kernel(uint16
     const int tiles = (g.len[k] + kPlTileOut - 1) / kPlTileOut;
     const bool in_lds = k - 1 >= t.lds_first, out_lds = k >= t.lds_first && k < t.last;  // workgroup-uniform
     uint16_t* mir = out_lds ? s_pl + loff_out : nullptr;
+    if (k == 1) {
+      // level 0 -> 1 straight from the fp32 audio (round 4: the wide launch that did this spent 18 of its 35 us on per-item
+      // bookkeeping — queue draws, 64-bit addresses, edge predicates — with nothing to do: ablation in DESIGN.md §7).  Here a
+      // wave walks tiles wave, wave + 16, ... of its workgroup's window, the next tile's rows in flight during the current
+      // one's matrix work; level 1 goes to its planes in HBM (level 2 reads it back through L2 after the barrier below).
+      const float* x = audio + (int64_t)blockIdx.x * audio_stride;
+      int tile = wave;
+      if (tile < tiles) {
+        PlRaw<true> raw = pl_fetch_rows<true>(x, nullptr, 0, g.len[0], tile, lane);
+        for (;;) {
+          const int ntile = tile + kPlTailThreads / 64;
+          const PlRaw<true> nraw = pl_fetch_rows<true>(x, nullptr, 0, g.len[0], ntile < tiles ? ntile : tile, lane);
+          pl_dec_tile<true, false, 1>(raw, x, w + g.off[0], g.stride, g.len[0], w + g.off[1], g.len[1], tile, tiles, th, tlo,
+                                      rows, lane, nullptr, 0, g.hop0);
+          if (ntile >= tiles) break;
+          raw = nraw, tile = ntile;
+        }
+      }
+    } else
     for (int tile = wave; tile < tiles; tile += kPlTailThreads / 64) {
       PlRaw<false> raw;
       if (in_lds)
@@ -539,9 +585,9 @@ static_assert(pl_fb_item(kPlFbFrags - 1).s == 6 && pl_fb_item(kPlFbFrags).s == -
 // workgroups, extrema partials to `mmp` (launches with fewer windows than CUs, and the per-stage test hook).
 template <int THREADS, int APF, bool FUSED>
 __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
-    const uint16_t* __restrict__ pl, const uint4* __restrict__ bfrag, const float* __restrict__ sqrt_len,
-    float* __restrict__ lp, float2* __restrict__ mmp, uint32_t* __restrict__ zp, int n_windows, LogConsts kc, PlGeo g,
-    unsigned per_window_magic) {
+    const uint16_t* __restrict__ pl, const float* __restrict__ audio, int64_t audio_stride,
+    const uint4* __restrict__ bfrag, const float* __restrict__ sqrt_len, float* __restrict__ lp, float2* __restrict__ mmp,
+    uint32_t* __restrict__ zp, int n_windows, LogConsts kc, PlGeo g, unsigned per_window_magic) {
   __shared__ __attribute__((aligned(16))) uint4 bfr[kPlFbFrags * 2 * 64];
   // sqrt(lengths) and the level offsets from LDS, not from global / constant memory: a wave's memory counters are in
   // order, so a global load in the epilogue would wait for every A fragment prefetched for the next task before it
@@ -586,12 +632,35 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
     const int b_ = (int)__umulhi((unsigned)task_, per_window_magic);
     return Pos{b_, task_ - b_ * per_window};
   };
-  // address of a task's first A fragment for this lane (hi plane; the lo plane is g.stride elements behind it)
-  auto frag0 = [&](Pos p) -> const uint16_t* {
+  // Where a task's A fragments come from.  Planes: 16 bytes of the hi plane per k-step (32 elements apart), the lo
+  // plane g.stride elements behind it.  Level 0 (round 4): the fp32 audio itself — 8 samples = two 16-byte loads per
+  // k-step, split to hi / lo in registers when the k-step is consumed (every level-0 sample feeds at most one frame: hop
+  // >= window, so nothing is split twice); level 0 has no planes any more: -45 MB written and -45 MB read per 256 windows.
+  struct Src {
+    const char* p;     // this lane's first fragment
+    int step;          // bytes between k-steps
+    int64_t second;    // bytes from the first to the second 16-byte half (lo plane / samples 4..7)
+    bool raw;          // fp32 samples: split at consumption
+  };
+  const int f_edge = pl_edge_frame(g.len[0], g.hop0);
+  auto src_of = [&](Pos p) -> Src {
     const int level_ = (p.rem * 745) >> 13;  // rem / 11 for rem < 2700
     const int tile_ = p.rem - level_ * kPlTilesPerLevel;
-    return pl + (int64_t)p.b * 2 * g.stride + s_off[level_] + (16 * tile_ + (lane & 15)) * (g.hop0 >> level_) + 16 +
-           8 * (lane >> 4);
+    if (audio != nullptr && level_ == 0) {  // wave-uniform
+      const int f = 16 * tile_ + (lane & 15);
+      const float* a = audio + (int64_t)p.b * audio_stride + f * g.hop0 - kPlPad;
+      if (f == 0 || f >= f_edge)  // a mirrored window: the edge rows the decimator left where level 0's planes were
+        a = reinterpret_cast<const float*>(pl + (int64_t)p.b * 2 * g.stride + s_off[0]) + 256 * (f == 0 ? 0 : 1 + f - f_edge);
+      return Src{reinterpret_cast<const char*>(a + 16 + 8 * (lane >> 4)), 128, 16, true};
+    }
+    const uint16_t* q = pl + (int64_t)p.b * 2 * g.stride + s_off[level_] + (16 * tile_ + (lane & 15)) * (g.hop0 >> level_) + 16 +
+                        8 * (lane >> 4);
+    return Src{reinterpret_cast<const char*>(q), 64, 2 * g.stride, false};
+  };
+  auto load16 = [](const char* p) {
+    uint4 v;
+    __builtin_memcpy(&v, __builtin_assume_aligned(p, 2), 16);  // 2-byte alignment at the hop-1 level; dword at least elsewhere
+    return v;
   };
   static_assert(kPlTilesPerLevel == 11, "the multiply-shift above divides by 11");
   for (; win < (FUSED ? n_windows : blockIdx.x + 1); win += gridDim.x) {
@@ -603,12 +672,12 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
   // before); step s + APF is fetched when step s has been consumed — for s + APF >= 7 that is step s + APF - 7 of the NEXT
   // task.  APF = 7: every load has a whole task's matrix work to land (a level-0 / level-1 task streams from HBM).
   uint4 ah[7], al[7];
+  Src src = src_of(pos);
   {
-    const uint16_t* p0 = frag0(pos);
 #pragma unroll
     for (int s = 0; s < APF; ++s) {
-      ah[s] = pl_load16(p0 + 32 * s);
-      al[s] = pl_load16(p0 + g.stride + 32 * s);
+      ah[s] = load16(src.p + src.step * s);
+      al[s] = load16(src.p + src.second + src.step * s);
     }
   }
 #if defined(PL_FB_PROF)
@@ -624,11 +693,10 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
     const int b = pos.b, rem = pos.rem;
     const int level = (rem * 745) >> 13, tile = rem - level * kPlTilesPerLevel;
     const int t = lane & 15, kg = lane >> 4;
-    const uint16_t* ph = frag0(pos);
     const uint4* bl = bfr + lane;
     const bool more = ntask >= 0;
     const Pos npos = more ? pos_of(ntask) : pos;
-    const uint16_t* pn = frag0(npos);
+    const Src nsrc = more ? src_of(npos) : src;
 
     f32x4 hh[5], xx[5];
 #pragma unroll
@@ -650,6 +718,10 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
         bh[i + kBPf] = bl[(2 * item(i + kBPf).f) * 64];
         bw[i + kBPf] = bl[(2 * item(i + kBPf).f + 1) * 64];
       }
+      if (src.raw && (i == 0 || item(i - 1).s != s)) {  // first product of k-step s of a level-0 task (wave-uniform): the
+        const float4 a = __builtin_bit_cast(float4, ah[s]), c = __builtin_bit_cast(float4, al[s]);  // slot holds 8 samples
+        pl_split8(a, c, ah[s], al[s]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       hh[q] = BP_PL_MFMA16(ah[s], bh[i], hh[q]);
       xx[q] = BP_PL_MFMA16(al[s], bh[i], xx[q]);
@@ -657,11 +729,11 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
       if (i + 1 == kPlFbFrags || item(i + 1).s != s) {  // last product of k-step s: its ring slot takes step s + APF
         const int sn = s + APF;
         if (sn < 7) {
-          ah[sn] = pl_load16(ph + 32 * sn);
-          al[sn] = pl_load16(ph + g.stride + 32 * sn);
+          ah[sn] = load16(src.p + src.step * sn);
+          al[sn] = load16(src.p + src.second + src.step * sn);
         } else {
-          ah[sn - 7] = pl_load16(pn + 32 * (sn - 7));
-          al[sn - 7] = pl_load16(pn + g.stride + 32 * (sn - 7));
+          ah[sn - 7] = load16(nsrc.p + nsrc.step * (sn - 7));
+          al[sn - 7] = load16(nsrc.p + nsrc.second + nsrc.step * (sn - 7));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -759,7 +831,7 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
     }
 #endif
     if (!more) break;
-    pos = npos, task = ntask, ntask = nntask;
+    pos = npos, src = nsrc, task = ntask, ntask = nntask;
   }
   }  // if (task >= 0)
   if constexpr (!FUSED) break;
@@ -841,6 +913,13 @@ void launch_planes_split(const float* src, int64_t src_stride, int level, uint16
                      g.len[level], pl, g.stride, g.off[level], g.rlen[level]);
 }
 
+void launch_planes_edge_rows(const float* audio, int64_t audio_stride, uint16_t* pl, int n_windows, bool ext,
+                             hipStream_t stream) {
+  const PlGeo g = make_pl_geo(ext);
+  hipLaunchKernelGGL(pl_edge_rows_kernel, dim3(n_windows), dim3(64), 0, stream, audio, audio_stride, g.len[0], pl, g.stride,
+                     g.off[0], g.hop0);
+}
+
 void launch_planes_unsplit(const uint16_t* pl, int level, float* dst, int64_t dst_stride, int n_windows, bool ext,
                            hipStream_t stream) {
   const PlGeo g = make_pl_geo(ext);
@@ -853,19 +932,23 @@ void launch_pyramid_planes(const float* audio, int64_t audio_stride, uint16_t* p
                            bool ext, hipStream_t stream) {
   const PlGeo g = make_pl_geo(ext);
   const uint4* tf = static_cast<const uint4*>(tfrag);
-  {
-    // tiles: enough for the level-1 outputs AND for the level-0 elements the tiles write (512 each, pad included)
-    int tiles = (g.len[1] + kPlTileOut - 1) / kPlTileOut;
-    const int cover = (kPlPad + g.len[0] + 2 * kPlTileOut - 1) / (2 * kPlTileOut);
-    if (tiles < cover) tiles = cover;
+  // with at least half a window per CU the whole pyramid is ONE launch (a workgroup per window, level 1 from the audio
+  // included); BP_PYR=wide keeps the wide level-0 -> 1 launch in front (A/B runs)
+  static const bool wide = [] {
+    const char* e = getenv("BP_PYR");
+    return e && strcmp(e, "wide") == 0;
+  }();
+  const bool one_launch = !wide && n_windows >= n_cu / 2;
+  if (!one_launch) {
+    const int tiles = (g.len[1] + kPlTileOut - 1) / kPlTileOut;
     const int items = tiles * n_windows;
     int grid = (items + 3) / 4;
     if (grid > pl_resident_waves(n_cu) / 4) grid = pl_resident_waves(n_cu) / 4;
     hipLaunchKernelGGL(pl_decimate_kernel<true>, dim3(grid), dim3(256), 0, stream, audio, audio_stride, pl, g.stride, g.off[0],
-                       g.len[0], g.off[1], g.len[1], tiles, tf, n_windows);
+                       g.len[0], g.off[1], g.len[1], tiles, tf, n_windows, g.hop0);
   }
   // with fewer windows than CUs the per-window kernel would leave most of the chip idle on the long levels: those run wide
-  int first_tail = 2;
+  int first_tail = one_launch ? 1 : 2;
   if (n_windows < n_cu / 2)
     for (; first_tail < g.n_levels && g.len[first_tail] > 16 * kPlTileOut; ++first_tail) {
       const int k = first_tail;
@@ -874,17 +957,17 @@ void launch_pyramid_planes(const float* audio, int64_t audio_stride, uint16_t* p
       int grid = (items + 3) / 4;
       if (grid > pl_resident_waves(n_cu) / 4) grid = pl_resident_waves(n_cu) / 4;
       hipLaunchKernelGGL(pl_decimate_kernel<false>, dim3(grid), dim3(256), 0, stream, (const float*)nullptr, (int64_t)0, pl,
-                         g.stride, g.off[k - 1], g.len[k - 1], g.off[k], g.len[k], tiles, tf, n_windows);
+                         g.stride, g.off[k - 1], g.len[k - 1], g.off[k], g.len[k], tiles, tf, n_windows, 0);
     }
   if (first_tail < g.n_levels) {
     // levels kept in LDS: as many of the deepest ones as fit (22.05 kHz: all from level 2; extended pyramid: from level 3)
-    int lds_first = first_tail;
+    int lds_first = first_tail < 2 ? 2 : first_tail;
     while (pl_tail_lds_need(g, lds_first, g.n_levels - 1) > kPlTailLdsElems) ++lds_first;
     int last = g.n_levels - 1;
 #ifdef BP_PLANES_DEBUG_HOOKS  // tools only (tools/build_variant.sh ... -DBP_PLANES_DEBUG_HOOKS): garbage results
     if (const char* e = getenv("BP_TAIL_LAST")) last = atoi(e);  // timing of the first levels
 #endif
-    hipLaunchKernelGGL(pl_decimate_tail_kernel, dim3(n_windows), dim3(kPlTailThreads), 0, stream, pl, g,
+    hipLaunchKernelGGL(pl_decimate_tail_kernel, dim3(n_windows), dim3(kPlTailThreads), 0, stream, audio, audio_stride, pl, g,
                        PlTail{first_tail, last, lds_first}, tf);
   }
 }
@@ -894,14 +977,18 @@ int filterbank_planes_partials(bool ext) { return make_pl_geo(ext).n_levels * kP
 // zp != null and enough windows to give every CU its own: the fused kernel (filterbank + normalise / BatchNorm / split of
 // whole windows per workgroup) — returns true, `zp` is complete; otherwise tasks strided over the chip, extrema partials in
 // `scratch` (fold them with launch_zpack_partials or launch_mm_reduce) — returns false.
-bool launch_filterbank_planes(const uint16_t* pl, const void* bfrag, const float* sqrt_len, float* lp, float* scratch,
-                              uint32_t* zp, int n_windows, LogConsts kc, int n_cu, bool ext, hipStream_t stream) {
+// `audio` (may be null: every level from the planes): the fp32 signal the level-0 planes were made from; the interior tiles
+// of level 0 then read it directly and the level-0 planes need to hold the two edge tiles only.
+bool launch_filterbank_planes(const uint16_t* pl, const float* audio, int64_t audio_stride, const void* bfrag,
+                              const float* sqrt_len, float* lp, float* scratch, uint32_t* zp, int n_windows, LogConsts kc,
+                              int n_cu, bool ext, hipStream_t stream) {
   PlGeo g = make_pl_geo(ext);
 #ifdef BP_PLANES_DEBUG_HOOKS  // tools only: timing of one level's tasks; results are garbage
   if (const char* e = getenv("BP_FB_ONLY_LEVEL")) {
     const int k = atoi(e);
     g.hop0 >>= k, g.off[0] = g.off[k], g.len[0] = g.len[k], g.n_levels = 1;
     zp = nullptr;
+    if (k > 0) audio = nullptr;
   }
 #endif
   const int tasks = n_windows * g.n_levels * kPlTilesPerLevel;
@@ -923,11 +1010,11 @@ bool launch_filterbank_planes(const uint16_t* pl, const void* bfrag, const float
 #define BP_PL_FB_LAUNCH(T, A, W)                                                                                         \
   do {                                                                                                                   \
     if (fused)                                                                                                           \
-      hipLaunchKernelGGL((cqt_filterbank_planes_kernel<T, A, true>), dim3(grid_for(W)), dim3(T), 0, stream, pl, bf,      \
-                         sqrt_len, lp, mm, zp, n_windows, kc, g, magic);                                                 \
+      hipLaunchKernelGGL((cqt_filterbank_planes_kernel<T, A, true>), dim3(grid_for(W)), dim3(T), 0, stream, pl, audio,   \
+                         audio_stride, bf, sqrt_len, lp, mm, zp, n_windows, kc, g, magic);                               \
     else                                                                                                                 \
-      hipLaunchKernelGGL((cqt_filterbank_planes_kernel<T, A, false>), dim3(grid_for(W)), dim3(T), 0, stream, pl, bf,     \
-                         sqrt_len, lp, mm, zp, n_windows, kc, g, magic);                                                 \
+      hipLaunchKernelGGL((cqt_filterbank_planes_kernel<T, A, false>), dim3(grid_for(W)), dim3(T), 0, stream, pl, audio,  \
+                         audio_stride, bf, sqrt_len, lp, mm, zp, n_windows, kc, g, magic);                               \
   } while (0)
   if (variant == 11)
     BP_PL_FB_LAUNCH(704, 7, 11);

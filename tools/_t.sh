@@ -1,10 +1,9 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python bench.py > gpurun_out/bench_r04_a.json 2> gpurun_out/bench_r04_a.err; tail -3 gpurun_out/bench_r04_a.err
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/bench_r04_a.json').read().strip().splitlines()[-1])
-print('value', d['value'], 'ms', d['ms_per_step'], 'sustained', d.get('sustained',{}).get('windows_per_s'))
-print(json.dumps(d['configs'], indent=1)); print(d['seam_b1_host']); print(d['roofline']['step_traffic']); print(d['stage_ms']); print(d['cpu_baseline'])
-PY
-python -m pytest tests/test_bench_gpu.py -x -q 2>&1 | tail -3
+python -m pytest tests/test_gpu_parity.py -x -q -k "stage_pyramid or batch_invariance or ext or end_to_end or track_path" 2>&1 | tail -3
+for i in 1 2; do
+echo "== default (one launch, pf1)"; tools/ab_run.sh
+echo "== pf0"; BASIC_PITCH_AMD_LIB=$PWD/basic_pitch_amd/lib/var_pf0.so tools/ab_run.sh
+echo "== wide"; BP_PYR=wide tools/ab_run.sh
+done
+tools/kstats.sh | grep -i "decimate\|filterbank\|bench"
