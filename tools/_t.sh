@@ -1,9 +1,10 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_parity.py -x -q -k "stage_pyramid or batch_invariance or ext or end_to_end or track_path" 2>&1 | tail -3
+python -m pytest tests/test_gpu_parity.py -x -q -k "fused_branch or batch_invariance or end_to_end or edge_cases or track_path" 2>&1 | tail -3
 for i in 1 2; do
-echo "== default (one launch, pf1)"; tools/ab_run.sh
-echo "== pf0"; BASIC_PITCH_AMD_LIB=$PWD/basic_pitch_amd/lib/var_pf0.so tools/ab_run.sh
-echo "== wide"; BP_PYR=wide tools/ab_run.sh
+echo "== default (dma, 5 wps)"; tools/ab_run.sh
+echo "== classic"; BP_CONV2=classic tools/ab_run.sh
+echo "== dma 6 wps"; BP_CONV2_WPS=6 tools/ab_run.sh
+echo "== dma 4 wps"; BP_CONV2_WPS=4 tools/ab_run.sh
+echo "== dma 3 wps"; BP_CONV2_WPS=3 tools/ab_run.sh
 done
-tools/kstats.sh | grep -i "decimate\|filterbank\|bench"
