@@ -24,6 +24,7 @@ SOURCES = [
     "conv_contour1.hip",
     "conv_contour_direct.hip",
     "conv_contour_rim.hip",
+    "conv_contour_march.hip",
     "conv_contour_fold_mx.hip",
     "conv_stride3.hip",
     "conv_heads.hip",

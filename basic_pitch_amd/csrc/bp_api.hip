@@ -70,6 +70,9 @@ void launch_contour_conv1_exact(const uint32_t* zp, const void* wlds, const floa
 void launch_contour_conv1_folded(const uint32_t* zp, const void* wfold, const float* bias, float* c1, int n_windows,
                                  int n_cu, bool weights_have_lo, hipStream_t stream);
 bool contour_conv1_full();
+bool contour_conv1_use_march();
+void launch_contour_conv1_march(const uint32_t* zp, const void* wfrag, const float* bias, float* c1, int n_windows, int n_cu,
+                                bool weights_have_lo, hipStream_t stream);
 void launch_contour_conv1_rim(const uint32_t* zp, const void* afrag, const float* bias, float* c1, int n_windows, int n_cu,
                               bool weights_have_lo, hipStream_t stream);
 void launch_onset_march(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, float* onset,
@@ -205,7 +208,7 @@ struct bp_context {
         *d_onset_wmx = nullptr, *d_onset_w16 = nullptr;
   float* zp = nullptr;  // uint32 [cap][kZRowsP][kZRow] pre-split z, zero padded (bp_common.h)
   // contour branch, two-kernel form (conv_contour_direct.hip): LDS weight image, bias[8], conv2 taps [5][5][8]
-  float *d_d1_wlds = nullptr, *d_d1_wfold = nullptr, *d_d1_wrim = nullptr, *d_d1_bias = nullptr,
+  float *d_d1_wlds = nullptr, *d_d1_wfold = nullptr, *d_d1_wmarch = nullptr, *d_d1_wrim = nullptr, *d_d1_bias = nullptr,
         *d_d2_w = nullptr;
   bool rim_exact = false, fold_mx = false;
   int contour_parts = 0;  // BP_CONTOUR_PARTS (0: automatic)
@@ -409,6 +412,32 @@ void pack_contour_folded(const Tensor* w1, std::vector<uint16_t>& out) {
         const size_t base_lo = (((size_t)(dt * 12 + e) * 2 + 1) * 64 + lane) * 8;
         for (int el = 0; el < 8; ++el) {
           const int g = 16 * e + 8 * kh + el - j - 56;
+          const float v = (g >= -55 && g <= 120) ? (float)keff[((size_t)o * 3 + dt) * 176 + g + 55] : 0.0f;
+          put_split(out, base_hi, base_lo, el, v, 2048.0f);
+        }
+      }
+}
+
+// The same folded kernel for the vertical march (conv_contour_march.hip): M = 16 rows = (2-bin offset j, out channel o),
+// a position is a pair of bins, K = 6 k-steps of 32 taps per frame tap.  A fragments [3 dt][6 k-steps][hi|lo][64 lanes] x
+// (8 x f16): lane (row i = 8 j + o = lane & 15, gq = lane >> 4), element el -> tap' = 32 s + 8 gq + el, g = tap' - j - 56.
+void pack_contour_march(const Tensor* w1, std::vector<uint16_t>& out) {
+  static const int shifts[8] = {-36, 0, 36, 57, 72, 84, 93, 101};  // nn.py:51-54 (bp_common.h harm_shift)
+  std::vector<double> keff((size_t)8 * 3 * 176, 0.0);               // [o][dt][g + 55]
+  for (int o = 0; o < 8; ++o)
+    for (int c = 0; c < 8; ++c)
+      for (int dt = 0; dt < 3; ++dt)
+        for (int df = 0; df < 39; ++df)
+          keff[((size_t)o * 3 + dt) * 176 + (df - 19 + shifts[c] + 55)] += (double)w1->data[((o * 8 + c) * 3 + dt) * 39 + df];
+  out.assign((size_t)18 * 2 * 64 * 8, 0);
+  for (int dt = 0; dt < 3; ++dt)
+    for (int s = 0; s < 6; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int gq = lane >> 4, i = lane & 15, j = i >> 3, o = i & 7;
+        const size_t base_hi = (((size_t)(dt * 6 + s) * 2 + 0) * 64 + lane) * 8;
+        const size_t base_lo = (((size_t)(dt * 6 + s) * 2 + 1) * 64 + lane) * 8;
+        for (int el = 0; el < 8; ++el) {
+          const int g = 32 * s + 8 * gq + el - j - 56;
           const float v = (g >= -55 && g <= 120) ? (float)keff[((size_t)o * 3 + dt) * 176 + g + 55] : 0.0f;
           put_split(out, base_hi, base_lo, el, v, 2048.0f);
         }
@@ -717,7 +746,7 @@ void pack_filterbank_planes(const Tensor* re, const Tensor* im, std::vector<uint
 }
 
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->planes, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->d_onset_w16, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wrim, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->planes, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->d_onset_w16, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wmarch, h->d_d1_wrim, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->fb_scratch, h->pcm_dev, h->mono_dev, h->res_dev, reinterpret_cast<float*>(h->taps_dev)};
@@ -837,6 +866,8 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
           const char* base = reinterpret_cast<const char*>(h->d_d1_wfold_mx);
           launch_contour_conv1_fold_mx(zpp, base, base + 36 * 64 * 16, base + 36 * 64 * 16 + 18 * 64 * 32, h->d_d1_bias, c1p,
                                        nw, h->n_cu, s);
+        } else if (contour_conv1_use_march()) {
+          launch_contour_conv1_march(zpp, h->d_d1_wmarch, h->d_d1_bias, c1p, nw, h->n_cu, wlo, s);
         } else {
           launch_contour_conv1_folded(zpp, h->d_d1_wfold, h->d_d1_bias, c1p, nw, h->n_cu, wlo, s);
         }
@@ -1021,6 +1052,8 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       return fail(rc);
     pack_contour_folded(c1w, frag);
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wfold))) return fail(rc);
+    pack_contour_march(c1w, frag);
+    if ((rc = upload(h, raw_of(frag), &h->d_d1_wmarch))) return fail(rc);
     pack_contour_rim(c1w, frag);
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wrim))) return fail(rc);
     // folded conv1: all three split-precision products on f16 by default (fp32-class); BP_FLAG_FP8_CORRECTIONS opts into
@@ -1682,6 +1715,8 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
             const char* base = reinterpret_cast<const char*>(h->d_d1_wfold_mx);
             launch_contour_conv1_fold_mx(bf->zp, base, base + 36 * 64 * 16, base + 36 * 64 * 16 + 18 * 64 * 32, h->d_d1_bias,
                                          h->c1s, n, h->n_cu, s);
+          } else if (contour_conv1_use_march()) {
+            launch_contour_conv1_march(bf->zp, h->d_d1_wmarch, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
           } else {
             launch_contour_conv1_folded(bf->zp, h->d_d1_wfold, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
           }

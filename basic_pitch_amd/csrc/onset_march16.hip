@@ -184,7 +184,12 @@ __global__ __launch_bounds__(64 * kO16Waves, 2) void onset_march16_kernel(Onset1
         ring[slot * kO16Row + 64 + lane] = vh;
         ring[slot * kO16Row + kO16Lo + 64 + lane] = vl;
       }
-      // the ring is written lane-private and read across lanes: order the wave's LDS writes before the reads that follow
+    };
+    // The ring is written lane-private and read across lanes: a wavefront fence orders the two.  Not right behind the commit
+    // (there it exposes the LDS write latency once per row): the row committed at the end of step r is image row (r + 1) + 2
+    // of the next step and first read by that step's k-step 4 — the fence sits in front of that read, three k-steps of matrix
+    // work behind the writes.
+    auto ring_fence = [] {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -226,6 +231,7 @@ __global__ __launch_bounds__(64 * kO16Waves, 2) void onset_march16_kernel(Onset1
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < kO16KS; ++s) {
+        if (s + kO16Pf == 4) ring_fence();  // the next read touches the row committed at the end of the last step
         if (s + kO16Pf < kO16KS) issue(s + kO16Pf);
         __builtin_amdgcn_sched_barrier(0);
         // three passes over the four (tile, block) accumulator pairs: dependent instructions sit 4 and 8 apart
@@ -305,6 +311,7 @@ __global__ __launch_bounds__(64 * kO16Waves, 2) void onset_march16_kernel(Onset1
       stage_issue(r_first + 2, ub);
       stage_commit(3, ua);
       stage_commit(4, ub);
+      ring_fence();
     }
     float note_nx[2] = {note_at(r_first, 0), note_at(r_first, 1)};
     float C[2] = {0.0f, 0.0f};  // the vertical sum in flight: group 0: q0(r), group 1: q0(r - 1) + q1(r)
