@@ -13,7 +13,7 @@ from .inference import (  # noqa: F401
     unwrap_output,
     window_audio_file,
 )
-from .inference import predict, predict_and_save, predict_and_save_many, predict_many  # noqa: F401
+from .inference import predict, predict_and_save, predict_and_save_many, predict_many, transcribe_files  # noqa: F401
 from .sharding import predict_and_save_sharded, predict_many_sharded  # noqa: F401
 
 __version__ = "0.1.0"

@@ -90,6 +90,27 @@ class bp_note_params(C.Structure):
     ]
 
 
+class bp_transcribe_params(C.Structure):
+    _fields_ = [
+        ("notes", bp_note_params),
+        ("midi_tempo", C.c_double),
+        ("multiple_pitch_bends", C.c_int32),
+        ("save_midi", C.c_int32),
+        ("save_notes", C.c_int32),
+        ("threads", C.c_int32),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
+class bp_file_report(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32),
+        ("n_note_events", C.c_int32),
+        ("n_frames", C.c_int64),
+        ("message", C.c_char * 240),
+    ]
+
+
 class bp_note_event(C.Structure):
     _fields_ = [
         ("start_s", C.c_double),
@@ -136,6 +157,13 @@ EXPORTED_SYMBOLS = [
     "bp_flac_info",
     "bp_flac_decode",
     "bp_audio_last_error",
+    "bp_transcribe_params_default",
+    "bp_transcribe_files",
+    "bp_notes_to_midi",
+    "bp_notes_to_csv",
+    "bp_wav_info",
+    "bp_wav_decode",
+    "bp_files_last_error",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -220,6 +248,21 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bp_flac_decode.restype = C.c_int
     lib.bp_audio_last_error.argtypes = []
     lib.bp_audio_last_error.restype = C.c_char_p
+    lib.bp_transcribe_params_default.argtypes = [C.POINTER(bp_transcribe_params)]
+    lib.bp_transcribe_params_default.restype = None
+    lib.bp_transcribe_files.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_char_p), i64, C.c_char_p,
+                                        C.POINTER(bp_transcribe_params), C.POINTER(bp_file_report)]
+    lib.bp_transcribe_files.restype = C.c_int
+    lib.bp_notes_to_midi.argtypes = [C.c_void_p, i64, C.c_void_p, C.c_int, C.c_double, C.c_void_p, i64]
+    lib.bp_notes_to_midi.restype = i64
+    lib.bp_notes_to_csv.argtypes = [C.c_void_p, i64, C.c_void_p, C.c_void_p, i64]
+    lib.bp_notes_to_csv.restype = i64
+    lib.bp_wav_info.argtypes = [C.c_char_p, C.c_size_t, pi, pi, pi, C.POINTER(i64)]
+    lib.bp_wav_info.restype = C.c_int
+    lib.bp_wav_decode.argtypes = [C.c_char_p, C.c_size_t, fp, i64, C.POINTER(i64)]
+    lib.bp_wav_decode.restype = C.c_int
+    lib.bp_files_last_error.argtypes = []
+    lib.bp_files_last_error.restype = C.c_char_p
     if path is None:
         _lib = lib
     return lib

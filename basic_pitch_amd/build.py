@@ -35,6 +35,7 @@ SOURCES = [
     "audio_ingest.hip",
     "note_decode.cpp",
     "flac_decode.cpp",
+    "file_pipeline.cpp",
 ]
 
 

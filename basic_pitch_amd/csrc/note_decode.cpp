@@ -20,6 +20,7 @@
 // float64, round-half-even where it calls np.round.
 #include "../../include/basic_pitch_amd.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -72,21 +73,34 @@ inline double np_maximum(double a, double b) {
   return a > b ? a : b;
 }
 
-// Tournament tree over a double array: index of the maximum, ties -> lowest index (np.argmax).
+// Tournament tree for the melodia trick: index of the maximum of `val`, ties -> lowest index (np.argmax), cells can only
+// be zeroed.  The loop that uses it stops at the first maximum that is not above the frame threshold, so only cells above
+// the threshold can ever be returned: the tree is built over THOSE (in index order, a few per cent of a 3-minute map after
+// the peak-picking pass) instead of all T x 88 cells — building the full 2^21-leaf tree was 40 % of a decode.  A cell's leaf
+// is found by binary search in the sorted candidate list.
 class MaxTree {
  public:
-  explicit MaxTree(std::vector<double>& v) : val_(v), n_((int64_t)v.size()) {
+  MaxTree(std::vector<double>& v, double thresh, std::vector<int32_t>& cand, std::vector<int32_t>& node)
+      : val_(v), cand_(cand), node_(node) {
+    cand_.clear();
+    const int64_t n = (int64_t)v.size();
+    for (int64_t i = 0; i < n; ++i)
+      if (v[i] > thresh) cand_.push_back((int32_t)i);
+    nc_ = (int64_t)cand_.size();
     size_ = 1;
-    while (size_ < n_) size_ <<= 1;
-    node_.assign(2 * size_, -1);
-    for (int64_t i = 0; i < n_; ++i) node_[size_ + i] = (int32_t)i;
+    while (size_ < nc_) size_ <<= 1;
+    node_.assign((size_t)(2 * size_), -1);
+    for (int64_t i = 0; i < nc_; ++i) node_[size_ + i] = cand_[(size_t)i];
     for (int64_t i = size_ - 1; i >= 1; --i) node_[i] = better(node_[2 * i], node_[2 * i + 1]);
   }
-  int32_t argmax() const { return node_[1]; }
+  // the maximum cell, or -1 when no cell above the threshold is left
+  int32_t argmax() const { return nc_ ? node_[1] : -1; }
   void set_zero(int64_t idx) {
     if (val_[idx] == 0.0) return;
     val_[idx] = 0.0;
-    for (int64_t i = (size_ + idx) >> 1; i >= 1; i >>= 1) node_[i] = better(node_[2 * i], node_[2 * i + 1]);
+    const auto it = std::lower_bound(cand_.begin(), cand_.end(), (int32_t)idx);
+    if (it == cand_.end() || *it != (int32_t)idx) return;  // never a candidate: not in the tree
+    for (int64_t i = (size_ + (it - cand_.begin())) >> 1; i >= 1; i >>= 1) node_[i] = better(node_[2 * i], node_[2 * i + 1]);
   }
 
  private:
@@ -96,9 +110,18 @@ class MaxTree {
     return (val_[b] > val_[a]) ? b : a;  // a < b always (left child first): ties keep the lower index
   }
   std::vector<double>& val_;
-  int64_t n_, size_;
-  std::vector<int32_t> node_;
+  std::vector<int32_t>& cand_;
+  std::vector<int32_t>& node_;
+  int64_t nc_ = 0, size_ = 1;
 };
+
+// per-thread scratch: a 3-minute track needs 11 MB per T x 88 double map; a worker thread of the file pipeline decodes
+// hundreds of tracks and would otherwise fault those pages in again for every one of them
+struct Scratch {
+  std::vector<double> on, fd, energy;
+  std::vector<int32_t> cand, node;
+};
+thread_local Scratch g_scratch;
 
 thread_local std::string g_notes_error;
 
@@ -154,11 +177,13 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
   }
 
   // ---- onsets (float64 from here on when inferred, note_creation.py:289-311)
-  std::vector<double> on((size_t)T * kF);
+  std::vector<double>& on = g_scratch.on;
+  on.resize((size_t)T * kF);
   if (prm->infer_onsets) {
     float max_on = onset[0];
     for (int64_t i = 1; i < T * kF; ++i) max_on = (onset[i] > max_on || std::isnan(onset[i])) ? onset[i] : max_on;
-    std::vector<double> fd((size_t)T * kF, 0.0);
+    std::vector<double>& fd = g_scratch.fd;
+    fd.assign((size_t)T * kF, 0.0);
     double max_fd = 0.0;  // rows 0, 1 are zero, every entry is >= 0
     for (int64_t t = 2; t < T; ++t)
       for (int f = 0; f < kF; ++f) {
@@ -184,7 +209,8 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
   std::vector<Raw> notes;
 
   // ---- peak picking (scipy.signal.argrelmax, axis 0) + threshold, visited backwards in time
-  std::vector<double> energy((size_t)T * kF);
+  std::vector<double>& energy = g_scratch.energy;
+  energy.resize((size_t)T * kF);
   for (int64_t i = 0; i < T * kF; ++i) energy[i] = (double)note[i];
   const int energy_tol = prm->energy_tol;
   const double frame_thresh = prm->frame_threshold, onset_thresh = prm->onset_threshold;
@@ -217,10 +243,10 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
 
   // ---- melodia trick (note_creation.py:449-509)
   if (prm->melodia_trick) {
-    MaxTree tree(energy);
+    MaxTree tree(energy, frame_thresh, g_scratch.cand, g_scratch.node);
     while (true) {
       const int32_t am = tree.argmax();
-      if (!(energy[am] > frame_thresh)) break;
+      if (am < 0 || !(energy[am] > frame_thresh)) break;
       const int64_t i_mid = am / kF;
       const int f = am % kF;
       tree.set_zero(am);

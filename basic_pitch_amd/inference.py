@@ -695,6 +695,66 @@ def predict_and_save_many(
     return report
 
 
+def transcribe_files(
+    audio_path_list,
+    output_directory: Union[pathlib.Path, str],
+    save_midi: bool = True,
+    save_notes: bool = True,
+    model_or_model_path: Union[Model, str, pathlib.Path] = ICASSP_2022_MODEL_PATH,
+    onset_threshold: float = DEFAULT_ONSET_THRESHOLD,
+    frame_threshold: float = DEFAULT_FRAME_THRESHOLD,
+    minimum_note_length: float = DEFAULT_MINIMUM_NOTE_LENGTH_MS,
+    minimum_frequency: Optional[float] = None,
+    maximum_frequency: Optional[float] = None,
+    multiple_pitch_bends: bool = False,
+    melodia_trick: bool = True,
+    midi_tempo: float = DEFAULT_MINIMUM_MIDI_TEMPO,
+    models: Optional[Sequence[Model]] = None,
+    lanes: int = 2,
+    threads: int = 0,
+) -> List[Dict[str, Any]]:
+    """The batch job of `predict_and_save` (inference.py:509-604) for WAV / FLAC input and MIDI / note-event output, run
+    natively: ONE call into the library (`bp_transcribe_files`, csrc/file_pipeline.cpp), C++ worker threads from the
+    file's bytes to its outputs, no Python in the loop.  Same bytes as `predict_and_save(..., save_midi, False, False,
+    save_notes)`.  `models` (or `lanes` models built from `model_or_model_path`) are the GPU lanes the workers queue
+    for.  Returns per file `{"status": 0 | bp_status, "n_note_events": k, "n_frames": T, "message": str}`; per-file
+    failures are reported, not raised (the reference's per-file try / except)."""
+    own: List[Model] = []
+    if models is None:
+        if isinstance(model_or_model_path, Model):
+            models = [model_or_model_path]
+        else:
+            own = [Model(model_or_model_path, max_windows=128) for _ in range(max(1, int(lanes)))]
+            models = own
+    try:
+        lib = models[0]._lib
+        verify_output_dir(output_directory)
+        paths = [os.fsencode(str(p)) for p in audio_path_list]
+        n = len(paths)
+        prm = _native.bp_transcribe_params()
+        lib.bp_transcribe_params_default(C.byref(prm))
+        prm.notes.onset_threshold, prm.notes.frame_threshold = float(onset_threshold), float(frame_threshold)
+        prm.notes.min_note_len = int(np.round(minimum_note_length / 1000 * (AUDIO_SAMPLE_RATE / FFT_HOP)))
+        prm.notes.melodia_trick = int(bool(melodia_trick))
+        prm.notes.min_freq_hz = float(minimum_frequency) if minimum_frequency is not None else 0.0
+        prm.notes.max_freq_hz = float(maximum_frequency) if maximum_frequency is not None else 0.0
+        prm.midi_tempo = float(midi_tempo)
+        prm.multiple_pitch_bends = int(bool(multiple_pitch_bends))
+        prm.save_midi, prm.save_notes, prm.threads = int(bool(save_midi)), int(bool(save_notes)), int(threads)
+        handles = (C.c_void_p * len(models))(*[m._handle for m in models])
+        cpaths = (C.c_char_p * max(1, n))(*paths)
+        reports = (_native.bp_file_report * max(1, n))()
+        rc = lib.bp_transcribe_files(handles, len(models), cpaths, n, os.fsencode(str(output_directory)), C.byref(prm), reports)
+        if rc != _native.BP_OK:
+            raise ValueError(f"bp_transcribe_files: {lib.bp_files_last_error().decode(errors='replace')}")
+        return [{"status": int(reports[i].status), "n_note_events": int(reports[i].n_note_events),
+                 "n_frames": int(reports[i].n_frames), "message": reports[i].message.decode(errors="replace")}
+                for i in range(n)]
+    finally:
+        for m in own:
+            m.close()
+
+
 def duplicate_output_stems(paths: Sequence[Union[pathlib.Path, str]]) -> Dict[int, IOError]:
     """Indices of inputs whose output name `<stem>_basic_pitch.*` (build_output_path) an EARLIER input of the list
     already claims, with the IOError the reference's sequential loop would give them (inference.py:401-404)."""

@@ -221,7 +221,30 @@ def run_files(args) -> None:
             paths.append(p)
         model = Model(max_windows=256)
         windows = sum(int(model._lib.bp_track_n_windows(int(np.ceil(n / 2)))) for _ in paths)
-        if args.save_workers > 0:
+        if args.native:
+            # the native pipeline: one bp_transcribe_files call, C++ worker threads from the file's bytes to its .mid + .csv
+            from basic_pitch_amd import transcribe_files
+
+            model.close()
+            lanes = [Model(max_windows=128) for _ in range(args.lanes)]
+            out_dir, warm_dir = os.path.join(d, "out"), os.path.join(d, "warm")
+            os.mkdir(out_dir)
+            os.mkdir(warm_dir)
+            transcribe_files(paths[: min(8, len(paths))], warm_dir, models=lanes, threads=args.native_threads)  # warm-up
+            t0 = time.perf_counter()
+            rep = transcribe_files(paths, out_dir, models=lanes, threads=args.native_threads)
+            el = time.perf_counter() - t0
+            bad = [r for r in rep if r["status"] != 0]
+            if bad:
+                raise SystemExit(f"native pipeline: {len(bad)} files failed: {bad[0]}")
+            n_events = sum(r["n_note_events"] for r in rep)
+            for m in lanes:
+                m.close()
+            how = (f"bp_transcribe_files: {args.lanes} GPU lanes (handles), "
+                   f"{args.native_threads or 'one per usable core'} C++ worker threads, each file from its bytes to its .mid + .csv "
+                   "without Python (WAV decode, PCM over PCIe, device resampling, CQT + CNN, posteriorgrams back, note decoding, "
+                   "MIDI / CSV encoding, file writes)")
+        elif args.save_workers > 0:
             # the batch job: predict_and_save_sharded, `--save-workers` host processes on the one GPU, every worker writes
             # its own MIDI + note CSV (nothing but small reports crosses process boundaries)
             from basic_pitch_amd import predict_and_save_sharded
@@ -376,6 +399,10 @@ def main() -> None:
     ap.add_argument("--exact-f32", action="store_true", help="contour conv1 on the exact-f32 MFMA kernel (A/B)")
     ap.add_argument("--files", type=int, default=64, help="files in the job (--workload files)")
     ap.add_argument("--file-seconds", type=float, default=180.0, help="length of each file (--workload files)")
+    ap.add_argument("--native", action="store_true",
+                    help="--workload files: the native pipeline (bp_transcribe_files: C++ worker threads, no Python in the loop)")
+    ap.add_argument("--lanes", type=int, default=3, help="--native: GPU lanes (handles) the workers queue for")
+    ap.add_argument("--native-threads", type=int, default=0, help="--native: C++ worker threads (0: one per hardware thread)")
     ap.add_argument("--save-workers", type=int, default=0,
                     help="--workload files: run the job as predict_and_save_sharded with this many host processes on the GPU")
     ap.add_argument("--workload", choices=["windows", "tracks", "files"], default="windows",

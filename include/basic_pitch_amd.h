@@ -323,6 +323,48 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
                     int64_t max_bends, int64_t* n_events, int64_t* n_bends);
 const char* bp_notes_last_error(void);
 
+/* ---- whole files, natively: decode -> posteriorgrams -> note events -> .mid / .csv (host C++ threads) ----------
+ * Replaces the per-file Python loop of predict_and_save (basic_pitch/inference.py:509-604) for WAV and FLAC input:
+ * librosa.load (239: decode; downmix + resampling on the device), run_inference (282-330), model_output_to_notes
+ * (note_creation.py:52-116), note_events_to_midi + pretty_midi write (222-267; inference.py:586) and save_note_events
+ * (inference.py:409-428).  A worker thread owns a file from its bytes to its outputs; the handles are GPU lanes the
+ * workers queue for (two or three handles overlap one file's transfers with another's kernels).  Outputs are named
+ * <out_dir>/<stem>_basic_pitch.mid / .csv and never overwritten (inference.py:401-404): an existing file, and every
+ * later input with the stem of an earlier one, is reported instead of written.  Per-file failures do not stop the job
+ * (the reference's per-file try / except, 548-604): reports[i].status / message.  Bytes are identical to what
+ * basic_pitch_amd.predict_and_save writes (tests/test_file_pipeline.py). */
+typedef struct bp_transcribe_params {
+  bp_note_params notes;         /* bp_note_params_default */
+  double midi_tempo;            /* predict(midi_tempo=120)                               inference.py:443 */
+  int32_t multiple_pitch_bends; /* 0                                                     inference.py:439 */
+  int32_t save_midi;            /* 1 */
+  int32_t save_notes;           /* 1 */
+  int32_t threads;              /* host worker threads; <= 0: one per hardware thread (at most 64) */
+  int32_t reserved[4];
+} bp_transcribe_params;
+
+typedef struct bp_file_report {
+  int32_t status;               /* BP_OK or the bp_status of the step that failed */
+  int32_t n_note_events;
+  int64_t n_frames;             /* rows of the file's posteriorgrams */
+  char message[240];            /* empty on success */
+} bp_file_report;
+
+void bp_transcribe_params_default(bp_transcribe_params* p);
+int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* paths, int64_t n_files, const char* out_dir,
+                        const bp_transcribe_params* params, bp_file_report* reports);
+/* The pieces on their own (host only; the CPU tests pin them to the Python writers and readers).
+ * bp_notes_to_midi / bp_notes_to_csv return the number of bytes of the file (written to `out` if it fits `capacity`; call
+ * with out = NULL to size the buffer), or a negative bp_status.  `bends` may be NULL (no pitch bends).
+ * bp_wav_info / bp_wav_decode: RIFF/WAVE PCM 8 / 16 / 24 / 32 and IEEE float 32 / 64 -> float32 [n_frames, channels] in
+ * [-1, 1), the scaling of libsndfile's float read that librosa.load uses (inference.py:239). */
+int64_t bp_notes_to_midi(const bp_note_event* events, int64_t n_events, const int32_t* bends, int multiple_pitch_bends,
+                         double midi_tempo, uint8_t* out, int64_t capacity);
+int64_t bp_notes_to_csv(const bp_note_event* events, int64_t n_events, const int32_t* bends, char* out, int64_t capacity);
+int bp_wav_info(const void* file, size_t nbytes, int* channels, int* sample_rate, int* bits_per_sample, int64_t* n_frames);
+int bp_wav_decode(const void* file, size_t nbytes, float* pcm, int64_t max_frames, int64_t* n_frames);
+const char* bp_files_last_error(void); /* thread-local */
+
 #ifdef __cplusplus
 }
 #endif
