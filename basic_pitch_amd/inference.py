@@ -674,23 +674,45 @@ def predict_and_save_many(
     IOError — decided up front, so concurrent writers never race on the exists-check."""
     model = Model(model_or_model_path) if isinstance(model_or_model_path, (str, os.PathLike)) else model_or_model_path
     paths = [pathlib.Path(p) for p in audio_path_list]
-    dup = duplicate_output_stems(paths)
+    saving = save_midi or sonify_midi or save_model_outputs or save_notes
+    # two inputs with the same stem would write the same files.  The map is made up front only so that concurrent writers
+    # never race on the exists-check; what it MEANS follows the reference's sequential loop (inference.py:548-604): every
+    # earlier file is predicted and written first, the later one then finds the outputs and gets the IOError — if the
+    # earlier file really produced them — and nothing can collide when nothing is saved.
+    dup = duplicate_output_stems(paths) if saving else {}
+    if dup and not return_exceptions:
+        paths = paths[: min(dup)]  # the loop would never get past the first duplicate: predict and write what precedes it
     todo = [i for i in range(len(paths)) if i not in dup]
 
-    def finish(j: int, res):
-        written = _save_outputs(paths[todo[j]], output_directory, res, save_midi, sonify_midi, save_model_outputs,
-                                save_notes, sonification_samplerate)
-        return {"n_note_events": len(res[2]), "outputs": written}
+    def finish_for(ids):
+        def finish(j: int, res):
+            written = _save_outputs(paths[ids[j]], output_directory, res, save_midi, sonify_midi, save_model_outputs,
+                                    save_notes, sonification_samplerate)
+            return {"n_note_events": len(res[2]), "outputs": written}
+        return finish
+
+    def run(ids):
+        return predict_many([paths[i] for i in ids], model, onset_threshold, frame_threshold, minimum_note_length,
+                            minimum_frequency, maximum_frequency, multiple_pitch_bends, melodia_trick, midi_tempo, group=group,
+                            decode_threads=decode_threads, return_exceptions=return_exceptions, _finish=finish_for(ids))
 
     report: List[Any] = [None] * len(paths)
-    for i, e in dup.items():
-        if not return_exceptions:
-            raise e
-        report[i] = e
-    done = predict_many([paths[i] for i in todo], model, onset_threshold, frame_threshold, minimum_note_length,
-                        minimum_frequency, maximum_frequency, multiple_pitch_bends, melodia_trick, midi_tempo, group=group,
-                        decode_threads=decode_threads, return_exceptions=return_exceptions, _finish=finish)
-    for i, r in zip(todo, done):
+    for i, r in zip(todo, run(todo)):
+        report[i] = r
+    if dup and not return_exceptions:
+        raise dup[min(dup)]  # every file in front of it has been written, like the reference's `raise e`
+    # a duplicate whose earlier namesake FAILED (nothing was written under that stem) is an ordinary file after all
+    first_of: Dict[str, int] = {}
+    retry: List[int] = []
+    for i in range(len(paths)):
+        stem, _ = os.path.splitext(os.path.basename(str(paths[i])))
+        if i not in dup:
+            first_of.setdefault(stem, i)
+        elif isinstance(report[first_of.get(stem, i)], BaseException) and stem not in {os.path.splitext(os.path.basename(str(paths[k])))[0] for k in retry}:
+            retry.append(i)
+        else:
+            report[i] = dup[i]
+    for i, r in zip(retry, run(retry) if retry else []):
         report[i] = r
     return report
 

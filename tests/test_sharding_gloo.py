@@ -292,8 +292,25 @@ def test_predict_and_save_many_is_one_pipeline_and_resolves_duplicate_stems(tmp_
     assert calls == [2, 2, 1]  # 5 unique files in groups of 2 through ONE predict_many call
     assert isinstance(rep[5], IOError) and "clip_1" in str(rep[5])
     assert all(r["n_note_events"] > 0 and os.path.exists(r["outputs"]["midi"]) for r in rep[:5])
-    with pytest.raises(IOError):
-        predict_and_save_many(paths, tmp_path / "out2", True, False, False, False, model_or_model_path=FakeModel(0))
+    # return_exceptions=False follows the reference's sequential loop (inference.py:548-604): everything in
+    # front of the duplicate is predicted and written, THEN its IOError is raised
+    out2 = tmp_path / "out2"
+    out2.mkdir()
+    with pytest.raises(IOError, match="clip_1"):
+        predict_and_save_many(paths, out2, True, False, False, False, model_or_model_path=FakeModel(0))
+    assert sorted(os.listdir(out2)) == [f"clip_{i}_basic_pitch.mid" for i in range(5)]
+    # nothing is saved: nothing can collide
+    rep_ns = predict_and_save_many(paths, tmp_path, False, False, False, False, model_or_model_path=FakeModel(0))
+    assert all(isinstance(r, dict) and r["outputs"] == {} for r in rep_ns)
+    # the earlier namesake could not be read and wrote nothing: the later file is an ordinary file after all
+    broken = tmp_path / "broken"
+    broken.mkdir()
+    (broken / "clip_1.wav").write_bytes(b"not audio")
+    out4 = tmp_path / "out4"
+    out4.mkdir()
+    rep4 = predict_and_save_many([str(broken / "clip_1.wav"), paths[1]], out4, True, False, False, False,
+                                 model_or_model_path=FakeModel(0), return_exceptions=True)
+    assert isinstance(rep4[0], Exception) and isinstance(rep4[1], dict) and os.path.exists(rep4[1]["outputs"]["midi"])
     out3 = tmp_path / "out3"
     out3.mkdir()
     rep3 = predict_and_save_sharded(paths, out3, True, False, False, True, gpus=2, model_factory=fake_factory, group=2,
