@@ -12,7 +12,7 @@ units: file/window sharding, no collective on the data path — SURVEY.md §8e),
 and `value` = windows processed by all ranks / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (contour_conv1_folded_kernel: Conv2D 8->8 3x39, 65 % of the path's FLOPs): algorithmic FLOP
+  roofline      dominant kernel (contour_conv1_march_kernel: Conv2D 8->8 3x39, 65 % of the path's FLOPs): algorithmic FLOP
                 per launch / mean launch duration measured with HIP events on the kernel's stream over the
                 timed steps, against the dense f16 MFMA peak (2.5 PFLOP/s; the kernel spends three f16 MFMAs per
                 product — hi*hi + lo*hi + hi*lo, the fp32-class split — on a folded operator with 528 instead of 936
@@ -50,6 +50,10 @@ F1_EXECUTED_FLOP_PER_WINDOW = 38 * 8 * 36 * 3 * (2 * 32 * 32 * 16)
 # the fp8 instruction does 4x the MACs of the f16 one in 2x its cycles, so its FLOPs count half.
 FX_EXECUTED_FLOP_PER_WINDOW = 38 * 8 * (36 * (2 * 32 * 32 * 16) + 18 * (2 * 32 * 32 * 64) // 2)
 F1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 224 * 8 * 4  # zp read + interior c1 written
+# contour_conv1_march_kernel (conv_contour_march.hip, the default since round 4): 7 strips of 32 bins x 4 frame chunks per
+# window; a chunk of 43 frames marches over 45 z rows (2 rows of warm-up), 54 v_mfma_f32_16x16x32_f16 per row (3 frame taps
+# x 6 k-steps x 3 split products)
+M1_EXECUTED_FLOP_PER_WINDOW = 7 * 4 * (43 + 2) * 54 * (2 * 16 * 16 * 32)
 D1_EXECUTED_FLOP_PER_WINDOW = 45 * 8 * 63 * 3 * (2 * 32 * 32 * 16)
 D1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 264 * 8 * 4  # zp read + c1 written
 HBM_PEAK_GBS = 8000.0
@@ -58,7 +62,7 @@ DTYPE_DEFAULT = DTYPE_F16  # since round 3 the default IS the all-f16 split (fp3
 DTYPE_FP8 = ("f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands; OPT-IN reduced precision (--fp8-corrections): contour "
              "conv1 interior and onset conv1 issue hi*hi on f16 and the two correction products (<= 2^-11 of a product) on "
              "block-scaled fp8 MFMA")
-PMC_PROFILE = "r03_e"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
+PMC_PROFILE = "r04_a"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
 
 
 def pmc_traffic(kernel_key: str, batch: int):
@@ -629,6 +633,15 @@ def main() -> None:
                 c1_exec = FX_EXECUTED_FLOP_PER_WINDOW * B / (c1_ms * 1e-3) / 1e12
                 c1_bytes = F1_BYTES_PER_WINDOW * B
                 c1_key = "contour_conv1_fold_mx_kernel"
+            elif folded and os.environ.get("BP_CONV1") != "rounds":
+                c1_flop = C1_FLOP_PER_WINDOW * F1_SHARE
+                c1_kernel = ("contour_conv1_march_kernel (interior 56/66 of harmonic stack + Conv2D 8->8 3x39 + ReLU with the 8 "
+                             "shifted channels folded into one 176-tap kernel; wave-private vertical march on f16 MFMA 16x16x32: "
+                             "hi/lo-split weights resident in registers, each z fragment read once from LDS for all three frame "
+                             "taps, fp32 accumulate; algorithmic FLOPs = the reference's 8-channel products it replaces)")
+                c1_exec = M1_EXECUTED_FLOP_PER_WINDOW * mf * B / (c1_ms * 1e-3) / 1e12
+                c1_bytes = F1_BYTES_PER_WINDOW * B
+                c1_key = "contour_conv1_march_kernel"
             elif folded:
                 c1_flop = C1_FLOP_PER_WINDOW * F1_SHARE
                 c1_kernel = ("contour_conv1_folded_kernel (interior 56/66 of harmonic stack + Conv2D 8->8 3x39 + ReLU with the 8 "
