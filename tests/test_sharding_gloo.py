@@ -317,3 +317,33 @@ def test_predict_and_save_many_is_one_pipeline_and_resolves_duplicate_stems(tmp_
                                     decode_threads=1)
     assert isinstance(rep3[5], IOError)
     assert [r["n_note_events"] for r in rep3[:5]] == [r["n_note_events"] for r in rep[:5]]
+
+
+def test_save_shard_native_routes_through_transcribe_files(tmp_path, monkeypatch):
+    """`predict_and_save_sharded(..., native=True)`: a worker's share goes through `inference.transcribe_files` (the native
+    pipeline; stubbed here — it needs a GPU, tests/test_file_pipeline.py covers it there) and its per-file statuses come
+    back as the reports of the Python pipeline: dicts with the output paths, or the exception of the file."""
+    from basic_pitch_amd import inference, sharding
+
+    paths = _write_clips(tmp_path, 3)
+    seen = {}
+
+    def fake_transcribe(audio_paths, out_dir, save_midi, save_notes, models=None, threads=0, **kw):
+        seen.update(paths=list(audio_paths), threads=threads, kw=kw, lanes=len(models))
+        return [{"status": 0, "n_note_events": 7, "n_frames": 100, "message": ""},
+                {"status": -7, "n_note_events": 0, "n_frames": 0, "message": "x: not a WAV or FLAC file"},
+                {"status": -1, "n_note_events": 0, "n_frames": 0, "message": "y already exists and would be overwritten."}]
+
+    monkeypatch.setattr(inference, "transcribe_files", fake_transcribe)
+    out = tmp_path / "o"
+    out.mkdir()
+    rep = sharding._save_shard(paths, [0, 1, 2], 0, None, fake_factory, out,
+                               {"save_midi": True, "sonify_midi": False, "save_model_outputs": False, "save_notes": True},
+                               {"native": True, "native_threads": 4, "onset_threshold": 0.6, "group": 8, "decode_threads": 2})
+    assert seen["paths"] == paths and seen["threads"] == 4 and seen["kw"] == {"onset_threshold": 0.6} and seen["lanes"] == 1
+    assert rep[0] == {"n_note_events": 7, "outputs": {"midi": str(out / "clip_0_basic_pitch.mid"),
+                                                       "note_events": str(out / "clip_0_basic_pitch.csv")}}
+    assert isinstance(rep[1], ValueError) and isinstance(rep[2], IOError)
+    with pytest.raises(ValueError, match="native=True"):
+        sharding._save_shard(paths, [0], 0, None, fake_factory, out,
+                             {"save_midi": True, "sonify_midi": True, "save_model_outputs": False, "save_notes": True}, {"native": True})

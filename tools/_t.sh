@@ -1,6 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-tools/profile_gpu.sh r04_a 20 5 > gpurun_out/prof_r04_a.log 2>&1
-python bench.py > gpurun_out/r04_a_bench.json 2> gpurun_out/r04_a_bench.err
-tail -2 gpurun_out/r04_a_bench.err
-cut -c1-300 gpurun_out/r04_a_bench.json
+L=$PWD/basic_pitch_amd/lib
+for i in 1 2; do
+echo "== default"; tools/ab_run.sh | tail -1
+for v in nc2 nc3 nc6 cmc3 cmc5 cmc6 cmpf2 cmpf0; do echo "== $v"; BASIC_PITCH_AMD_LIB=$L/var_$v.so tools/ab_run.sh | tail -1; done
+done
