@@ -181,3 +181,31 @@ def test_transcribe_files_equals_predict_and_save(tmp_path):
     assert rep[0]["n_note_events"] == 28  # the reference's golden clip
     again = transcribe_files(good[:1], out_dir, models=[model])
     assert again[0]["status"] != 0 and "already exists" in again[0]["message"]
+
+
+@pytest.mark.gpu
+def test_sharded_batch_job_through_the_native_pipeline(tmp_path):
+    """predict_and_save_sharded(native=True): two worker processes on the one GPU, each running its LPT shard through
+    bp_transcribe_files; same bytes as the single-process Python job, reports in input order."""
+    import shutil
+
+    from basic_pitch_amd import Model, predict_and_save, predict_and_save_sharded
+
+    src = tmp_path / "in"
+    src.mkdir()
+    paths = []
+    for i in range(4):
+        p = src / f"c{i}.wav"
+        shutil.copy(os.path.join(GOLDEN, "vocadito_10.wav"), p)
+        paths.append(str(p))
+    ref_dir, out_dir = tmp_path / "ref", tmp_path / "out"
+    ref_dir.mkdir(), out_dir.mkdir()
+    m = Model(max_windows=64)
+    predict_and_save(paths[:1], ref_dir, True, False, False, True, m)
+    m.close()
+    rep = predict_and_save_sharded(paths, out_dir, True, False, False, True, gpus=1, workers_per_gpu=2, native=True,
+                                   native_threads=2, native_lanes=1)
+    assert [r["n_note_events"] for r in rep] == [28] * 4
+    for i in range(4):
+        for ext in ("mid", "csv"):
+            assert (out_dir / f"c{i}_basic_pitch.{ext}").read_bytes() == (ref_dir / f"c0_basic_pitch.{ext}").read_bytes()
