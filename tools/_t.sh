@@ -1,7 +1,11 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-L=$PWD/basic_pitch_amd/lib
-for i in 1 2; do
-echo "== default"; tools/ab_run.sh | tail -1
-for v in nc2 nc3 nc6 cmc3 cmc5 cmc6 cmpf2 cmpf0; do echo "== $v"; BASIC_PITCH_AMD_LIB=$L/var_$v.so tools/ab_run.sh | tail -1; done
+for i in 1 2 3; do
+echo "== default"; python bench.py --no-cpu-baseline --sustained-s 1 --no-config-extras --no-exact-f32 --no-fp8-extra 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('value %.0f ms %.4f sustained %.0f' % (d['value'], d['ms_per_step'], d['sustained']['windows_per_s']))"
+echo "== rim on side stream"; BP_RIM_STREAM=1 python bench.py --no-cpu-baseline --sustained-s 1 --no-config-extras --no-exact-f32 --no-fp8-extra 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('value %.0f ms %.4f sustained %.0f' % (d['value'], d['ms_per_step'], d['sustained']['windows_per_s']))"
 done
+BP_RIM_STREAM=1 python -m pytest tests/test_gpu_parity.py -x -q -k "batch_invariance or end_to_end or track_path" 2>&1 | tail -2
