@@ -62,7 +62,8 @@ struct ContourMarchParams {
   const float* bias;   // [8]
   const uint32_t* zp;  // [n][kZRowsP][kZRow] packed (hi | lo << 16) words, zero padded (bp_common.h)
   float* c1;           // [n][172][kC1Row][8]
-  int n_tasks;         // n_windows * kCmChunks * kCmStrips
+  int n_tasks;         // n_windows * chunks * kCmStrips
+  int chunks;          // frame chunks per window: kCmChunks at full batches, more when few windows must fill the chip
 };
 
 template <bool WLO>
@@ -93,10 +94,10 @@ __global__ __launch_bounds__(64 * kCmWaves, 2) void contour_conv1_march_kernel(C
   const int total_waves = gridDim.x * kCmWaves;
 #pragma unroll 1
   for (int task = blockIdx.x * kCmWaves + wave; task < p.n_tasks; task += total_waves) {  // wave-uniform; no barriers
-    const int b = task / (kCmChunks * kCmStrips);
-    const int rem = task - b * (kCmChunks * kCmStrips);
+    const int b = task / (p.chunks * kCmStrips);
+    const int rem = task - b * (p.chunks * kCmStrips);
     const int ci = rem / kCmStrips, strip = rem - ci * kCmStrips;
-    const int T0 = (ci * kFrames) / kCmChunks, T1 = ((ci + 1) * kFrames) / kCmChunks;
+    const int T0 = (ci * kFrames) / p.chunks, T1 = ((ci + 1) * kFrames) / p.chunks;
     const int p0 = 10 + 16 * strip;                  // first position (bin pair) of the strip: bins 2 p0 = 20 + 32 strip
     const int wb = 2 * p0 - 4;                       // first zp word of the strip's window (a multiple of 4)
     const uint32_t* zwin = p.zp + (int64_t)b * kZWin + wb;
@@ -238,7 +239,11 @@ bool contour_conv1_use_march() {
 
 void launch_contour_conv1_march(const uint32_t* zp, const void* wfrag, const float* bias, float* c1, int n_windows, int n_cu,
                                 bool weights_have_lo, hipStream_t stream) {
-  ContourMarchParams p{static_cast<const uint4*>(wfrag), bias, zp, c1, n_windows * kCmChunks * kCmStrips};
+  // small batches: more, shorter chunks until there is a task per resident wave (a task is a serial march of rows: at
+  // one window, 4 chunks leave 28 waves marching 45 rows each while 2020 wave slots idle)
+  int chunks = kCmChunks;
+  while (chunks < 32 && (int64_t)n_windows * chunks * kCmStrips < (int64_t)2 * n_cu * kCmWaves) chunks *= 2;
+  ContourMarchParams p{static_cast<const uint4*>(wfrag), bias, zp, c1, n_windows * chunks * kCmStrips, chunks};
   if (p.n_tasks <= 0) return;
   int grid = (p.n_tasks + kCmWaves - 1) / kCmWaves;
   if (grid > 2 * n_cu) grid = 2 * n_cu;  // two workgroups of four waves per CU (registers), persistent

@@ -45,7 +45,8 @@ struct NoteMarchParams {
   const float* wf32;     // bias1[32], ..., bias2 at [41]
   const float* contour;  // [n][172][264]
   float* out;            // [n][172][88]
-  int n_tasks;           // n_windows * kNmChunks * kNmStrips
+  int n_tasks;           // n_windows * chunks * kNmStrips
+  int chunks;            // time chunks per window: kNmChunks at full batches, more when few windows must fill the chip
 };
 
 template <bool WLO>
@@ -57,10 +58,10 @@ __global__ __launch_bounds__(64 * kNmWaves, 3) void note_march_kernel(NoteMarchP
   const int h = lane >> 5, li = lane & 31;
   const int task = blockIdx.x * kNmWaves + wave;
   if (task >= p.n_tasks) return;  // wave-uniform; no barriers below
-  const int b = task / (kNmChunks * kNmStrips);
-  const int rem = task - b * (kNmChunks * kNmStrips);
+  const int b = task / (p.chunks * kNmStrips);
+  const int rem = task - b * (p.chunks * kNmStrips);
   const int ci = rem / kNmStrips, strip = rem - ci * kNmStrips;
-  const int T0 = (ci * kFrames) / kNmChunks, T1 = ((ci + 1) * kFrames) / kNmChunks;
+  const int T0 = (ci * kFrames) / p.chunks, T1 = ((ci + 1) * kFrames) / p.chunks;
 
   uint4* img_hi = lds[wave][0];
   uint4* img_lo = lds[wave][1];
@@ -249,7 +250,9 @@ __global__ __launch_bounds__(64 * kNmWaves, 3) void note_march_kernel(NoteMarchP
 
 void launch_note_march(const float* contour, const void* wfrag, const float* wf32, float* note, int n_windows,
                        bool weights_have_lo, hipStream_t stream) {
-  NoteMarchParams p{static_cast<const uint4*>(wfrag), wf32, contour, note, n_windows * kNmChunks * kNmStrips};
+  int chunks = kNmChunks;  // small batches: shorter chunks (a task's 6 rows of halo weigh more, its serial march less)
+  while (chunks < 16 && (int64_t)n_windows * chunks * kNmStrips < 3072) chunks *= 2;
+  NoteMarchParams p{static_cast<const uint4*>(wfrag), wf32, contour, note, n_windows * chunks * kNmStrips, chunks};
   if (p.n_tasks <= 0) return;
   const int grid = (p.n_tasks + kNmWaves - 1) / kNmWaves;
   static const bool prof = getenv("BP_BRANCH_PROF") != nullptr;

@@ -61,7 +61,8 @@ struct Onset16Params {
   const uint32_t* zp;   // [n][kZRowsP][kZRow] packed (hi | lo << 16) words, zero padded (bp_common.h)
   const float* note;    // [n][172][88]
   float* out;           // [n][172][88]
-  int n_tasks;          // n_windows * kO16Chunks * kO16Strips
+  int n_tasks;          // n_windows * chunks * kO16Strips
+  int chunks;           // time chunks per window: kO16Chunks at full batches, more when few windows must fill the chip
 };
 
 template <bool WLO>
@@ -123,10 +124,10 @@ __global__ __launch_bounds__(64 * kO16Waves, 2) void onset_march16_kernel(Onset1
   const int total_waves = gridDim.x * kO16Waves;
 #pragma unroll 1
   for (int task = blockIdx.x * kO16Waves + wave; task < p.n_tasks; task += total_waves) {  // wave-uniform; no barriers
-    const int b = task / (kO16Chunks * kO16Strips);
-    const int rem = task - b * (kO16Chunks * kO16Strips);
+    const int b = task / (p.chunks * kO16Strips);
+    const int rem = task - b * (p.chunks * kO16Strips);
     const int ci = rem / kO16Strips, strip = rem - ci * kO16Strips;
-    const int T0 = (ci * kFrames) / kO16Chunks, T1 = ((ci + 1) * kFrames) / kO16Chunks;
+    const int T0 = (ci * kFrames) / p.chunks, T1 = ((ci + 1) * kFrames) / p.chunks;
 
     // this lane's two pixels of the strip (tile nt: strip pixel 16 nt + n), and the stack bin of image slot 0
     int w[2], wc[2];
@@ -350,7 +351,9 @@ __global__ __launch_bounds__(64 * kO16Waves, 2) void onset_march16_kernel(Onset1
 
 void launch_onset_march16(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, float* onset,
                           int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream) {
-  Onset16Params p{static_cast<const uint4*>(wfrag), wf32, zp, note, onset, n_windows * kO16Chunks * kO16Strips};
+  int chunks = kO16Chunks;  // small batches: shorter chunks until every resident wave has a task
+  while (chunks < 32 && (int64_t)n_windows * chunks * kO16Strips < (int64_t)2 * n_cu * kO16Waves) chunks *= 2;
+  Onset16Params p{static_cast<const uint4*>(wfrag), wf32, zp, note, onset, n_windows * chunks * kO16Strips, chunks};
   if (p.n_tasks <= 0) return;
   int grid = (p.n_tasks + kO16Waves - 1) / kO16Waves;
   if (grid > 2 * n_cu) grid = 2 * n_cu;  // two resident workgroups per CU (LDS), persistent: the waves walk the tasks

@@ -1,4 +1,11 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-tools/profile_gpu.sh r04_b 300 5 > gpurun_out/prof_r04_b.log 2>&1
-python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+python -m pytest tests/test_gpu_parity.py -x -q -k "fused_branch or batch_invariance or end_to_end or edge_cases or track_path or multi_track or ort_shim" 2>&1 | tail -3
+python - <<'PY'
+import json, sys, time
+sys.path.insert(0, '.')
+import torch, numpy as np
+import bench
+print(json.dumps({k: round(v['windows_per_s']) for k, v in bench.config_extras(torch, 0).items()}))
+print(bench.seam_b1_host())
+PY
