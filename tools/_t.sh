@@ -1,11 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_parity.py -x -q -k "fused_branch or batch_invariance or end_to_end or edge_cases or track_path or multi_track or ort_shim" 2>&1 | tail -3
-python - <<'PY'
-import json, sys, time
-sys.path.insert(0, '.')
-import torch, numpy as np
-import bench
-print(json.dumps({k: round(v['windows_per_s']) for k, v in bench.config_extras(torch, 0).items()}))
-print(bench.seam_b1_host())
-PY
+for b in 1 4 16 64; do echo "== batch $b"; python bench.py --batch $b --steps 50 --no-cpu-baseline --sustained-s 0 --no-config-extras --no-exact-f32 --no-fp8-extra 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('value %.0f ms %.4f' % (d['value'], d['ms_per_step'])); print({k: round(v,4) for k,v in d['stage_ms'].items() if v})"; done
