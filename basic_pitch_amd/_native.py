@@ -151,6 +151,7 @@ EXPORTED_SYMBOLS = [
     "bp_run_stage",
     "bp_pyramid_layout",
     "bp_version",
+    "bp_device_count",
     "bp_note_params_default",
     "bp_notes_decode",
     "bp_notes_last_error",
@@ -180,6 +181,16 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
             f"{p} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc, gfx950). basic_pitch_amd has no CPU fallback."
         )
+    # ONE HIP runtime per process.  PyTorch's libraries ask for "libamdhip64.so" (and find the copy bundled in torch/lib),
+    # this library for "libamdhip64.so.7" (the system's /opt/rocm copy); both files carry the SONAME libamdhip64.so.7.  When
+    # torch loads first, this library's request matches the SONAME of the copy already in the process.  The other way
+    # round torch's request matched nothing and a SECOND runtime was loaded — whichever initialised second then saw no
+    # device (measured: build() followed by smoke() in one process).  Loading the runtime by torch's name first puts that
+    # name on the link map, so a later `import torch` reuses it.
+    try:
+        C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
     try:
         lib = C.CDLL(p)
     except OSError as e:  # missing libamdhip64 etc.
@@ -231,6 +242,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bp_run_stage.restype = C.c_int
     lib.bp_pyramid_layout.argtypes = [C.c_int, C.POINTER(i64), C.POINTER(i64)]
     lib.bp_pyramid_layout.restype = C.c_int
+    lib.bp_device_count.argtypes = []
+    lib.bp_device_count.restype = C.c_int
     lib.bp_version.argtypes = []
     lib.bp_version.restype = C.c_char_p
     lib.bp_note_params_default.argtypes = [C.POINTER(bp_note_params)]

@@ -900,6 +900,16 @@ extern "C" {
 
 const char* bp_version(void) { return "basic_pitch_amd 0.1.0 (gfx950)"; }
 
+// Number of HIP devices this process sees (0 without a GPU or a HIP runtime).
+int bp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
 const char* bp_last_error(bp_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned flags,

@@ -282,6 +282,8 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* buf, int64_t n_
 int bp_pyramid_layout(int level /*1..8*/, int64_t* offset, int64_t* length);
 
 const char* bp_version(void);
+/* HIP devices visible to this process (0 without a GPU). */
+int bp_device_count(void);
 
 /* ---- note decoding: posteriorgrams -> note events (host C++, no GPU needed) -------------------------
  * Replaces the Python loops of basic_pitch/note_creation.py: output_to_notes_polyphonic (360-511, with

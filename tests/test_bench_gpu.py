@@ -63,3 +63,20 @@ def test_bench_single_rank_line_has_the_contract_keys():
     assert line["seam_b1_host"]["windows_per_s"] > 0 and line["seam_b1_host"]["ms_per_call"] > 0
     st = r["step_traffic"]
     assert st is None or (st["ratio"] > 1.0 and st["bytes_per_step"] > st["algorithmic_bytes_per_step"])
+
+
+def test_library_then_torch_share_one_hip_runtime():
+    """Load order must not matter: PyTorch bundles its own copy of libamdhip64 and asks for it by another name than this
+    library does.  Loaded in the order [this library, torch], a process used to end up with TWO HIP runtimes and the one
+    that initialised second saw no device (build() followed by smoke() in one process).  _native.load_library() now
+    brings the runtime in under torch's name first: one copy in the process, every order works."""
+    code = (
+        "from basic_pitch_amd import _native; _native.load_library()\n"
+        "import torch; assert torch.cuda.is_available(); x = torch.ones(3).cuda()\n"
+        "from basic_pitch_amd import Model; m = Model(max_windows=1); assert m.info()['arch'].startswith('gfx950')\n"
+        "libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l))\n"
+        "assert len(libs) == 1, libs\n"
+        "print('ok', float(x.sum()))\n"
+    )
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert res.returncode == 0 and "ok 3.0" in res.stdout, res.stderr[-3000:]
