@@ -1,4 +1,6 @@
-// Contour branch, default path: two kernels with the 8-channel intermediate in HBM.
+// Contour branch: two kernels with the 8-channel intermediate in HBM.  Since round 4 the interior of conv1 is
+// conv_contour_march.hip (default); this file keeps conv2 (default), the exact 8-channel conv1 (rim of the extended mode,
+// BP_RIM=exact, BP_CONV1=full) and the round-2 folded conv1 (BP_CONV1=rounds).
 //
 //   contour_conv1_kernel   Conv2D 8->8, (3 frames x 39 bins), "same", folded BN, ReLU on the harmonic stack
 //                          (basic_pitch/models.py:241-250, nn.py:69-88)                          zp -> c1
