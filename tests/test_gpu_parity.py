@@ -825,3 +825,27 @@ def test_onset_march_equals_workgroup_kernel(tmp_path):
     assert np.array_equal(outs["march32"], outs["ring"])
     d = np.abs(outs["march16"] - outs["march32"]).max()
     assert d <= 2e-6, d
+
+
+def test_contour_march_equals_round_kernel(tmp_path):
+    """The contour conv1 interior as a vertical march on 16x16x32 (conv_contour_march.hip, the default since round 4) and
+    as 256-position rounds on 32x32x16 (BP_CONV1=rounds) are the same folded operator: they sum the same 528 products
+    per output in another order (32 taps per matrix instruction instead of 16, frame taps interleaved row by row), so
+    the contour maps agree to fp32 accumulation-order noise: 2e-6 on a sigmoid output.  Random z through the C ABI stage
+    hook, one process per kernel (the choice is read once per process)."""
+    import subprocess
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "experiments", "contour_ab.py")
+    outs = {}
+    for name, env in (("march", {}), ("rounds", {"BP_CONV1": "rounds"})):
+        out = str(tmp_path / f"{name}.npy")
+        e = dict(os.environ, **env)
+        e.pop("BASIC_PITCH_AMD_LIB", None)
+        if not env:
+            e.pop("BP_CONV1", None)
+        subprocess.run([sys.executable, tool, out], check=True, env=e, timeout=300)
+        outs[name] = np.load(out)
+    assert np.isfinite(outs["march"]).all()
+    d = np.abs(outs["march"] - outs["rounds"]).max()
+    assert d <= 2e-6, d
