@@ -92,8 +92,15 @@ __global__ __launch_bounds__(64 * kCmWaves, 2) void contour_conv1_march_kernel(C
   for (int i = lane; i < 2 * kCmRowU; i += 64) img[i] = uint4{0u, 0u, 0u, 0u};
 
   const int total_waves = gridDim.x * kCmWaves;
+  // XCD-aware task order: workgroups go to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own L2; consecutive
+  // tasks — the strips and chunks of ONE window, which read overlapping parts of the same zp rows — are given to
+  // workgroups of the same XCD, so a row is fetched from HBM by one L2 instead of by up to eight
+  // (inside each half of the grid: a CU hosts workgroups p and p + gridDim.x / 2, and when the tasks per wave are not a whole
+  // number the first half of the LOGICAL blocks carries the extra task — the pair of a CU must stay (first, second half))
+  const int half_n = (int)gridDim.x / 2, pq = (int)blockIdx.x % (half_n > 0 ? half_n : 1);
+  const int lblock = (gridDim.x % 16 == 0) ? ((int)blockIdx.x / half_n) * half_n + (pq % 8) * (half_n / 8) + pq / 8 : (int)blockIdx.x;
 #pragma unroll 1
-  for (int task = blockIdx.x * kCmWaves + wave; task < p.n_tasks; task += total_waves) {  // wave-uniform; no barriers
+  for (int task = lblock * kCmWaves + wave; task < p.n_tasks; task += total_waves) {  // wave-uniform; no barriers
     const int b = task / (p.chunks * kCmStrips);
     const int rem = task - b * (p.chunks * kCmStrips);
     const int ci = rem / kCmStrips, strip = rem - ci * kCmStrips;
