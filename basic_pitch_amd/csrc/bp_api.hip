@@ -74,7 +74,7 @@ bool contour_conv1_use_march();
 void launch_contour_conv1_march(const uint32_t* zp, const void* wfrag, const float* bias, float* c1, int n_windows, int n_cu,
                                 bool weights_have_lo, hipStream_t stream);
 void launch_contour_conv1_rim(const uint32_t* zp, const void* afrag, const float* bias, float* c1, int n_windows, int n_cu,
-                              bool weights_have_lo, hipStream_t stream);
+                              bool weights_have_lo, bool ext, hipStream_t stream);
 void launch_onset_march(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, float* onset,
                         int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
 void launch_onset_march16(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, float* onset,
@@ -450,12 +450,14 @@ void pack_contour_march(const Tensor* w1, std::vector<uint16_t>& out) {
 //   convolution zero-pads THAT) and z bin f + df - 19 + shift_c == j0 + j of W1[o][c][dt][df].
 // A fragments [side][M block 5][k-step 27 = dt * 9 + e][hi|lo][64 lanes][8]: lane (i = lane & 31 = 8 (f % 4) + o,
 // kh = lane >> 5), element el: j = 16 e + 8 kh + el.
-void pack_contour_rim(const Tensor* w1, std::vector<uint16_t>& out) {
+// `n_bins`: bins of the CQT (309; 345 for the extended 44.1 kHz mode, whose bins 309..344 reach the high rim); `kJ`: z bins a
+// side's window holds (144; 160 for the extended mode: the kernel's RimGeo<160>).
+void pack_contour_rim(const Tensor* w1, std::vector<uint16_t>& out, int n_bins = 309, int kJ = 144) {
   static const int shifts[8] = {-36, 0, 36, 57, 72, 84, 93, 101};
-  constexpr int kJ = 144, kStepsDt = kJ / 16;
+  const int kStepsDt = kJ / 16;
   out.assign((size_t)2 * 5 * 3 * kStepsDt * 2 * 64 * 8, 0);
   for (int side = 0; side < 2; ++side) {
-    const int f0 = side ? 244 : 0, j0 = side ? 184 : 0;
+    const int f0 = side ? 244 : 0, j0 = side ? (kJ == 144 ? 184 : 188) : 0;  // conv_contour_rim.hip RimGeo::j0
     std::vector<double> k((size_t)20 * 8 * 3 * kJ, 0.0);  // [f_local][o][dt][j]
     for (int fl = 0; fl < 20; ++fl)
       for (int o = 0; o < 8; ++o)
@@ -466,9 +468,10 @@ void pack_contour_rim(const Tensor* w1, std::vector<uint16_t>& out) {
               if (sb < 0 || sb >= 264) continue;
               const int j = sb + shifts[c] - j0;  // z bin (zero outside [0, 309): nothing to add there)
               const int zb = sb + shifts[c];
-              if (zb < 0 || zb >= 309) continue;
-              if (j < 0 || j >= kJ) {  // cannot happen with the windows above; guard the table
-                continue;
+              if (zb < 0 || zb >= n_bins) continue;
+              if (j < 0 || j >= kJ) {  // cannot happen with the windows above
+                std::fprintf(stderr, "pack_contour_rim: z bin %d outside the side's window\n", zb);
+                std::abort();
               }
               k[(((size_t)fl * 8 + o) * 3 + dt) * kJ + j] += (double)w1->data[((o * 8 + c) * 3 + dt) * 39 + df];
             }
@@ -858,7 +861,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
       if (contour_conv1_full() || h->rim_exact)
         launch_contour_conv1_exact(zpp, h->d_d1_wlds, h->d_d1_bias, c1p, nw, h->n_cu, wlo, s);
       else
-        launch_contour_conv1_rim(zpp, h->d_d1_wrim, h->d_d1_bias, c1p, nw, h->n_cu, wlo, s);
+        launch_contour_conv1_rim(zpp, h->d_d1_wrim, h->d_d1_bias, c1p, nw, h->n_cu, wlo, h->ext, s);
       if (!contour_conv1_full()) {
         BP_MARK(BP_STAGE_CONTOUR_CONV1_EDGE);
         BP_DOM_BEGIN();
@@ -1064,7 +1067,10 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wfold))) return fail(rc);
     pack_contour_march(c1w, frag);
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wmarch))) return fail(rc);
-    pack_contour_rim(c1w, frag);
+    if (flags & BP_FLAG_EXT_CQT_44K)
+      pack_contour_rim(c1w, frag, kBinsExt, 160);  // the 345-bin CQT: 160 z bins per rim side (conv_contour_rim.hip RimGeo<160>)
+    else
+      pack_contour_rim(c1w, frag);
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wrim))) return fail(rc);
     // folded conv1: all three split-precision products on f16 by default (fp32-class); BP_FLAG_FP8_CORRECTIONS opts into
     // the block-scaled fp8 corrections (conv_contour_fold_mx.hip; ~1e-5 on the contour map), BP_CONV1=f16 then keeps this
@@ -1088,9 +1094,8 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     if (const char* ep = std::getenv("BP_CONTOUR_PARTS")) h->contour_parts = std::atoi(ep) > 8 ? 8 : std::atoi(ep);
     {
       const char* er = std::getenv("BP_RIM");  // "exact": the round-1 rim kernel on the 8-channel form (A/B runs)
-      // the extended 345-bin CQT (BP_FLAG_EXT_CQT_44K) feeds bins 309..344 into the high rim: its GEMM table is built for
-      // the model's 309 bins, so that mode stays on the exact kernel
-      h->rim_exact = (er && std::strcmp(er, "exact") == 0) || (flags & BP_FLAG_EXT_CQT_44K);
+      // (the extended 345-bin CQT has its own GEMM table since round 4: 160 z bins per side)
+      h->rim_exact = er && std::strcmp(er, "exact") == 0;
     }
     for (int br = 0; br < 2; ++br) {
       pack_branch(br ? 13 : 4, br ? o1w : n1w, br ? o2w : n2w, br == 1, frag);
@@ -1720,7 +1725,7 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
           if (contour_conv1_full() || h->rim_exact)
             launch_contour_conv1_exact(bf->zp, h->d_d1_wlds, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
           else
-            launch_contour_conv1_rim(bf->zp, h->d_d1_wrim, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
+            launch_contour_conv1_rim(bf->zp, h->d_d1_wrim, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, h->ext, s);
           if (h->fold_mx && wlo) {
             const char* base = reinterpret_cast<const char*>(h->d_d1_wfold_mx);
             launch_contour_conv1_fold_mx(bf->zp, base, base + 36 * 64 * 16, base + 36 * 64 * 16 + 18 * 64 * 32, h->d_d1_bias,

@@ -35,26 +35,37 @@ namespace bp {
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
 constexpr int kRimBlocks = 5;             // M blocks of 32 rows: 20 bins x 8 channels per side
-constexpr int kRimWaves = 4;              // wave w: block w, and k-steps [rim_ks(w), rim_ks(w + 1)) of block 4
-constexpr int kRimBins = 144;             // z bins per frame a side reads (multiple of 16)
-constexpr int kRimStepsDt = kRimBins / 16;  // 9 k-steps per frame tap
-constexpr int kRimSteps = 3 * kRimStepsDt;  // 27
+constexpr int kRimWaves = 4;              // wave w: block w, and k-steps [ks(w), ks(w + 1)) of block 4
 #ifndef BP_RIM_FRAMES
 #define BP_RIM_FRAMES 64
 #endif
 constexpr int kRimFrames = BP_RIM_FRAMES;  // frames per work item: kRimNT 32-column tiles
 constexpr int kRimNT = kRimFrames / 32;
 constexpr int kRimTiles = (kFrames + kRimFrames - 1) / kRimFrames;  // 3
-constexpr int kRimRowU = 37;              // LDS row: 18 units hi | 18 units lo | 1 pad (odd: conflict-free)
 constexpr int kRimRows = kRimFrames + 2;
 constexpr int kRimPf = 3;                 // k-steps of A prefetch (L2 latency under load ~ 4 k-steps of 6 MFMAs)
-__host__ __device__ constexpr int rim_ks(int w) { return w >= 4 ? 27 : 7 * w; }  // 7 + 7 + 7 + 6 k-steps
-__host__ __device__ constexpr int rim_j0(int side) { return side ? 184 : 0; }
 __host__ __device__ constexpr int rim_f0(int side) { return side ? 244 : 0; }
+// z bins per frame a side reads (a multiple of 16).  144 for the model's 309-bin CQT: low rim bins [0, 144) (141 used), high
+// rim [184, 328) (125 used; bins >= 309 are zp's zero padding).  160 for the extended 345-bin CQT of the 44.1 kHz mode
+// (round 4): there bins 309 .. 344 carry data and the high rim (stack bins up to 263 + shift 101) reads z bins up to 343.
+template <int BINS>
+struct RimGeo {
+  static_assert(BINS == 144 || BINS == 160, "rim window");
+  static constexpr int kBins = BINS;
+  static constexpr int kUnitsRow = BINS / 8;        // 16-byte units per plane and row
+  static constexpr int kStepsDt = BINS / 16;        // k-steps per frame tap: 9 / 10
+  static constexpr int kSteps = 3 * kStepsDt;       // 27 / 30
+  static constexpr int kRowU = 2 * kUnitsRow + 1;   // LDS row: hi units | lo units | 1 pad (odd: conflict-free): 37 / 41
+  // block 4's k-steps dealt to the four waves: 7 + 7 + 7 + 6 / 8 + 8 + 7 + 7
+  // first z bin of a side's window: the high rim reads z bins 189 .. min(364, n_bins - 1): [184, 328) holds them for 309 bins,
+  // [188, 348) for 345
+  static __host__ __device__ constexpr int j0(int side) { return side ? (BINS == 144 ? 184 : 188) : 0; }
+  static __host__ __device__ constexpr int ks(int w) { return w >= 4 ? kSteps : (BINS == 144 ? 7 * w : (w <= 2 ? 8 * w : 23)); }
+};
 
 struct RimParams {
   const uint32_t* zp;   // [n][kZRowsP][kZRow]
-  const uint4* afrag;   // [side 2][mb 5][step 27][hi|lo][64 lanes] x (8 x f16)   (bp_api.hip pack_contour_rim)
+  const uint4* afrag;   // [side 2][mb 5][step 27 | 30][hi|lo][64 lanes] x (8 x f16)   (bp_api.hip pack_contour_rim)
   const float* bias;    // [8]
   float* c1;            // [n][172][kC1Row][8]
   int n_items;          // n_windows * 2 * kRimTiles
@@ -74,20 +85,21 @@ __device__ __forceinline__ void rim_a_prefetch(const uint4* afr, uint4 (&ah)[kRi
   }
 }
 
-template <bool WLO, int S0, int S1>
+template <class Geo, bool WLO, int S0, int S1>
 __device__ __forceinline__ void rim_ksteps(const uint4* afr, const uint4* img, int lane_u, uint4 (&ah)[kRimPf],
                                            uint4 (&al)[kRimPf], f32x16 (&acc)[kRimNT], f32x16 (&accc)[kRimNT]) {
   static_assert(S1 - S0 >= kRimPf, "the ring is full at entry");
   f16x8 bh[kRimNT], bl[kRimNT];
   auto read_bh = [&](int s) {
-    const int dt = s / kRimStepsDt, e = s - dt * kRimStepsDt;
+    const int dt = s / Geo::kStepsDt, e = s - dt * Geo::kStepsDt;
 #pragma unroll
-    for (int j = 0; j < kRimNT; ++j) bh[j] = __builtin_bit_cast(f16x8, img[lane_u + (32 * j + dt) * kRimRowU + 2 * e]);
+    for (int j = 0; j < kRimNT; ++j) bh[j] = __builtin_bit_cast(f16x8, img[lane_u + (32 * j + dt) * Geo::kRowU + 2 * e]);
   };
   auto read_bl = [&](int s) {
-    const int dt = s / kRimStepsDt, e = s - dt * kRimStepsDt;
+    const int dt = s / Geo::kStepsDt, e = s - dt * Geo::kStepsDt;
 #pragma unroll
-    for (int j = 0; j < kRimNT; ++j) bl[j] = __builtin_bit_cast(f16x8, img[lane_u + (32 * j + dt) * kRimRowU + 2 * e + 18]);
+    for (int j = 0; j < kRimNT; ++j)
+      bl[j] = __builtin_bit_cast(f16x8, img[lane_u + (32 * j + dt) * Geo::kRowU + 2 * e + Geo::kUnitsRow]);
   };
   read_bh(S0);
   read_bl(S0);
@@ -119,8 +131,9 @@ __device__ __forceinline__ void rim_ksteps(const uint4* afr, const uint4* img, i
   }
 }
 
-template <bool WLO>
+template <class Geo, bool WLO>
 __global__ __launch_bounds__(64 * kRimWaves, kRimNT <= 2 ? 4 : 2) void contour_conv1_rim_kernel(RimParams p) {
+  constexpr int kRimBins = Geo::kBins, kRimRowU = Geo::kRowU, kRimSteps = Geo::kSteps;
   __shared__ __attribute__((aligned(16))) uint4 img[kRimRows * kRimRowU];
   static_assert(sizeof(uint4) * kRimRows * kRimRowU >= sizeof(float) * kRimWaves * 16 * kRimNT * 64, "the partial sums fit the image");
 
@@ -150,7 +163,7 @@ __global__ __launch_bounds__(64 * kRimWaves, kRimNT <= 2 ? 4 : 2) void contour_c
   // ---- stage frames t0 - 1 .. t0 + 64 of the side's 144 z bins as f16 planes: unit (row, u) = bins j0 + 8u .. + 7.
   // All loads of a thread are in flight before the first is used (one global round trip per item, not five).
   {
-    const uint32_t* zwin = p.zp + (int64_t)b * kZWin + kZPadL + rim_j0(side);
+    const uint32_t* zwin = p.zp + (int64_t)b * kZWin + kZPadL + Geo::j0(side);
     constexpr int kUnits = kRimRows * (kRimBins / 8), kPerThread = (kUnits + 64 * kRimWaves - 1) / (64 * kRimWaves);
     uint4 w0[kPerThread], w1[kPerThread];
 #pragma unroll
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(64 * kRimWaves, kRimNT <= 2 ? 4 : 2) void contour_c
       vl.z = (w1[i].x >> 16) | (w1[i].y & 0xffff0000u);
       vl.w = (w1[i].z >> 16) | (w1[i].w & 0xffff0000u);
       img[row * kRimRowU + u] = vh;
-      img[row * kRimRowU + 18 + u] = vl;
+      img[row * kRimRowU + Geo::kUnitsRow + u] = vl;
     }
   }
   // ---- A fragments of this wave's own M block: on their way (L2) across the barrier
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(64 * kRimWaves, kRimNT <= 2 ? 4 : 2) void contour_c
 
   // ---- phase 1: the wave's own M block, all 27 k-steps
   clear();
-  rim_ksteps<WLO, 0, kRimSteps>(afr, img, lane_u, ah, al, acc, accc);
+  rim_ksteps<Geo, WLO, 0, kRimSteps>(afr, img, lane_u, ah, al, acc, accc);
 
 #if defined(RIM_PROF)
   asm volatile("" : "+v"(acc[0][0]), "+v"(accc[kRimNT - 1][15]));
@@ -233,8 +246,8 @@ __global__ __launch_bounds__(64 * kRimWaves, kRimNT <= 2 ? 4 : 2) void contour_c
   clear();
 #define RIM_QUARTER(w)                                                                              \
   case w:                                                                                           \
-    rim_a_prefetch<rim_ks(w)>(afr4, ah, al);                                                        \
-    rim_ksteps<WLO, rim_ks(w), rim_ks(w + 1)>(afr4, img, lane_u, ah, al, acc, accc);                \
+    rim_a_prefetch<Geo::ks(w)>(afr4, ah, al);                                                       \
+    rim_ksteps<Geo, WLO, Geo::ks(w), Geo::ks(w + 1)>(afr4, img, lane_u, ah, al, acc, accc);         \
     break;
   switch (wave) {
     RIM_QUARTER(0)
@@ -283,14 +296,22 @@ __global__ __launch_bounds__(64 * kRimWaves, kRimNT <= 2 ? 4 : 2) void contour_c
 }
 
 void launch_contour_conv1_rim(const uint32_t* zp, const void* afrag, const float* bias, float* c1, int n_windows, int n_cu,
-                              bool weights_have_lo, hipStream_t stream) {
+                              bool weights_have_lo, bool ext, hipStream_t stream) {
   (void)n_cu;
   RimParams p{zp, static_cast<const uint4*>(afrag), bias, c1, n_windows * 2 * kRimTiles};
   if (p.n_items <= 0) return;
-  if (weights_have_lo)
-    hipLaunchKernelGGL(contour_conv1_rim_kernel<true>, dim3(p.n_items), dim3(64 * kRimWaves), 0, stream, p);
-  else
-    hipLaunchKernelGGL(contour_conv1_rim_kernel<false>, dim3(p.n_items), dim3(64 * kRimWaves), 0, stream, p);
+  const dim3 grid(p.n_items), block(64 * kRimWaves);
+  if (ext) {  // the 345-bin CQT of the 44.1 kHz mode: 160 z bins per side (afrag packed for them)
+    if (weights_have_lo)
+      hipLaunchKernelGGL((contour_conv1_rim_kernel<RimGeo<160>, true>), grid, block, 0, stream, p);
+    else
+      hipLaunchKernelGGL((contour_conv1_rim_kernel<RimGeo<160>, false>), grid, block, 0, stream, p);
+  } else {
+    if (weights_have_lo)
+      hipLaunchKernelGGL((contour_conv1_rim_kernel<RimGeo<144>, true>), grid, block, 0, stream, p);
+    else
+      hipLaunchKernelGGL((contour_conv1_rim_kernel<RimGeo<144>, false>), grid, block, 0, stream, p);
+  }
 }
 
 }  // namespace bp
