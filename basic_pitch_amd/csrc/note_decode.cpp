@@ -12,7 +12,11 @@
 // The reference is single-threaded numpy/Python: 9.5 ms for the 9-second test clip, 2.07 s for a 3-minute
 // track and super-linear, because every melodia iteration rescans the whole matrix for its maximum
 // (np.max + np.argmax, note_creation.py:452-453).  Here the maximum comes from a tournament tree with the
-// same tie-break (lowest flat index), so an iteration costs O(log n) per cell it zeroes.
+// same tie-break (lowest flat index), so an iteration costs O(log n) per cell it zeroes.  Round 4: the float64 onset
+// map, the frame-difference map and the float64 copy of the note map (33 MB per 3-minute track) are not built — an
+// inferred onset is three loads from the float32 maps, evaluated exactly only in frames whose row maxima can reach the
+// threshold: 26 -> 7 ms per 3-minute track and core, same events.  NaN cells and thresholds <= 0 follow numpy's
+// propagation rules (tests/test_note_decode.py::test_decoder_fuzz_against_restatement).
 //
 // Bit-exactness contract (tests/test_note_decode.py): same events, in the same order, as the numpy
 // restatement oracle/note_oracle.py — which reproduces the reference's golden note events — including the
@@ -80,12 +84,30 @@ inline double np_maximum(double a, double b) {
 // is found by binary search in the sorted candidate list.
 class MaxTree {
  public:
-  MaxTree(std::vector<double>& v, double thresh, std::vector<int32_t>& cand, std::vector<int32_t>& node)
+  MaxTree(std::vector<float>& v, double thresh, std::vector<int32_t>& cand, std::vector<int32_t>& node)
       : val_(v), cand_(cand), node_(node) {
     cand_.clear();
     const int64_t n = (int64_t)v.size();
-    for (int64_t i = 0; i < n; ++i)
-      if (v[i] > thresh) cand_.push_back((int32_t)i);
+    // (double)x > thresh  <=>  x > the largest float that is <= thresh; whole frames without such a cell are skipped
+    float tf = (float)thresh;
+    if ((double)tf > thresh) tf = std::nextafterf(tf, -INFINITY);
+    const float* p = v.data();
+    int64_t i = 0;
+    for (; i + 88 <= n; i += 88) {
+      int any = 0, nan = 0;
+      for (int j = 0; j < 88; ++j) {
+        any |= p[i + j] > tf;
+        nan |= p[i + j] != p[i + j];
+      }
+      has_nan_ |= nan != 0;
+      if (!any) continue;
+      for (int j = 0; j < 88; ++j)
+        if (p[i + j] > tf) cand_.push_back((int32_t)(i + j));
+    }
+    for (; i < n; ++i) {
+      if (p[i] > tf) cand_.push_back((int32_t)i);
+      has_nan_ |= p[i] != p[i];
+    }
     nc_ = (int64_t)cand_.size();
     size_ = 1;
     while (size_ < nc_) size_ <<= 1;
@@ -95,9 +117,11 @@ class MaxTree {
   }
   // the maximum cell, or -1 when no cell above the threshold is left
   int32_t argmax() const { return nc_ ? node_[1] : -1; }
+  // np.max of a map that holds a NaN is NaN
+  bool has_nan() const { return has_nan_; }
   void set_zero(int64_t idx) {
-    if (val_[idx] == 0.0) return;
-    val_[idx] = 0.0;
+    if (val_[idx] == 0.0f) return;
+    val_[idx] = 0.0f;
     const auto it = std::lower_bound(cand_.begin(), cand_.end(), (int32_t)idx);
     if (it == cand_.end() || *it != (int32_t)idx) return;  // never a candidate: not in the tree
     for (int64_t i = (size_ + (it - cand_.begin())) >> 1; i >= 1; i >>= 1) node_[i] = better(node_[2 * i], node_[2 * i + 1]);
@@ -109,16 +133,18 @@ class MaxTree {
     if (b < 0) return a;
     return (val_[b] > val_[a]) ? b : a;  // a < b always (left child first): ties keep the lower index
   }
-  std::vector<double>& val_;
+  std::vector<float>& val_;
   std::vector<int32_t>& cand_;
   std::vector<int32_t>& node_;
   int64_t nc_ = 0, size_ = 1;
+  bool has_nan_ = false;
 };
 
 // per-thread scratch: a 3-minute track needs 11 MB per T x 88 double map; a worker thread of the file pipeline decodes
 // hundreds of tracks and would otherwise fault those pages in again for every one of them
 struct Scratch {
-  std::vector<double> on, fd, energy;
+  std::vector<float> energy, row_on;
+  std::vector<double> row_fd;
   std::vector<int32_t> cand, node;
 };
 thread_local Scratch g_scratch;
@@ -176,31 +202,68 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
     }
   }
 
-  // ---- onsets (float64 from here on when inferred, note_creation.py:289-311)
-  std::vector<double>& on = g_scratch.on;
-  on.resize((size_t)T * kF);
-  if (prm->infer_onsets) {
-    float max_on = onset[0];
-    for (int64_t i = 1; i < T * kF; ++i) max_on = (onset[i] > max_on || std::isnan(onset[i])) ? onset[i] : max_on;
-    std::vector<double>& fd = g_scratch.fd;
-    fd.assign((size_t)T * kF, 0.0);
-    double max_fd = 0.0;  // rows 0, 1 are zero, every entry is >= 0
-    for (int64_t t = 2; t < T; ++t)
-      for (int f = 0; f < kF; ++f) {
-        const double d1 = (double)note[t * kF + f] - (double)note[(t - 1) * kF + f];
-        const double d2 = (double)note[t * kF + f] - (double)note[(t - 2) * kF + f];
-        double d = d1 < d2 ? d1 : d2;
-        if (d < 0) d = 0;
-        fd[t * kF + f] = d;
-        if (d > max_fd) max_fd = d;
+  // ---- onsets (float64 when inferred, note_creation.py:289-311).  The float64 onset map is never stored: a cell of it is
+  // max(onset, max_on * fd / max_fd) with fd = max(0, min(note[t] - note[t-1], note[t] - note[t-2])), three loads away
+  // from the float32 maps, and the peak picking below needs it exactly only where it can reach the onset threshold.
+  const bool infer = prm->infer_onsets != 0;
+  double max_on_d = 0.0, max_fd = 0.0;
+  // per frame: the largest onset and the largest rise (the peak picking skips the frames that cannot reach the threshold)
+  std::vector<float>& row_on = g_scratch.row_on;
+  std::vector<double>& row_fd = g_scratch.row_fd;
+  row_on.resize((size_t)T), row_fd.assign((size_t)T, 0.0);
+  bool on_nan = false;
+  for (int64_t t = 0; t < T; ++t) {
+    const float* o = onset + t * kF;
+    float m[8];
+    int nan = 0;
+    for (int j = 0; j < 8; ++j) m[j] = o[j];
+    for (int j = 0; j < 8; ++j) nan |= o[j] != o[j];
+    for (int f = 8; f < kF; f += 8)
+      for (int j = 0; j < 8; ++j) {
+        m[j] = o[f + j] > m[j] ? o[f + j] : m[j];
+        nan |= o[f + j] != o[f + j];
       }
-    for (int64_t i = 0; i < T * kF; ++i) {
-      const double scaled = ((double)max_on * fd[i]) / max_fd;  // 0/0 -> NaN when nothing rises, like numpy
-      on[i] = np_maximum((double)onset[i], scaled);
-    }
-  } else {
-    for (int64_t i = 0; i < T * kF; ++i) on[i] = (double)onset[i];
+    float r = m[0];
+    for (int j = 1; j < 8; ++j) r = m[j] > r ? m[j] : r;
+    row_on[(size_t)t] = r;
+    on_nan |= nan != 0;
   }
+  if (infer) {
+    // np.max of the onset map: NaN if it holds one
+    float max_on = row_on[0];
+    for (int64_t t = 1; t < T; ++t) max_on = row_on[(size_t)t] > max_on ? row_on[(size_t)t] : max_on;
+    max_on_d = on_nan ? std::nan("") : (double)max_on;
+    int note_nan = 0;
+    for (int64_t t = 2; t < T; ++t) {  // rows 0, 1 are zero, every entry is >= 0
+      const float *n0 = note + t * kF, *n1 = n0 - kF, *n2 = n1 - kF;
+      double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int f = 0; f < kF; f += 8)
+        for (int j = 0; j < 8; ++j) {
+          const double d1 = (double)n0[f + j] - (double)n1[f + j], d2 = (double)n0[f + j] - (double)n2[f + j];
+          const double d = d1 < d2 ? d1 : d2;
+          m[j] = d > m[j] ? d : m[j];
+          note_nan |= (d1 != d1) | (d2 != d2);
+        }
+      double r = m[0];
+      for (int j = 1; j < 8; ++j) r = m[j] > r ? m[j] : r;
+      row_fd[(size_t)t] = r;
+      if (r > max_fd) max_fd = r;
+    }
+    // np.min / np.max propagate NaN: one NaN difference makes the scale, and with it every inferred onset, NaN
+    if (note_nan) max_fd = std::nan("");
+  }
+  auto fd_at = [&](int64_t t, int f) -> double {
+    if (t < 2) return 0.0;
+    const double d1 = (double)note[t * kF + f] - (double)note[(t - 1) * kF + f];
+    const double d2 = (double)note[t * kF + f] - (double)note[(t - 2) * kF + f];
+    const double d = d1 < d2 ? d1 : d2;  // a NaN difference only matters through max_fd, which is NaN then
+    return d < 0 ? 0.0 : d;
+  };
+  auto on_at = [&](int64_t t, int f) -> double {
+    if (!infer) return (double)onset[t * kF + f];
+    const double scaled = (max_on_d * fd_at(t, f)) / max_fd;  // 0/0 -> NaN when nothing rises, like numpy
+    return np_maximum((double)onset[t * kF + f], scaled);
+  };
 
   struct Raw {
     int32_t start, end, pitch;
@@ -209,22 +272,56 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
   std::vector<Raw> notes;
 
   // ---- peak picking (scipy.signal.argrelmax, axis 0) + threshold, visited backwards in time
-  std::vector<double>& energy = g_scratch.energy;
+  // `energy` = the note map with the cells of found notes zeroed: float32 like its source (every comparison below is
+  // between values that convert to float64 exactly)
+  std::vector<float>& energy = g_scratch.energy;
   energy.resize((size_t)T * kF);
-  for (int64_t i = 0; i < T * kF; ++i) energy[i] = (double)note[i];
+  std::memcpy(energy.data(), note, (size_t)T * kF * sizeof(float));
   const int energy_tol = prm->energy_tol;
   const double frame_thresh = prm->frame_threshold, onset_thresh = prm->onset_threshold;
-  for (int64_t t = T - 2; t >= 1; --t) {
+  // The reference keeps the onset value at the peaks and 0 elsewhere, then takes every cell >= onset_thresh
+  // (note_creation.py:398-402): with a positive threshold those are peaks that reach it — onset >= thresh, or
+  // max_on * fd / max_fd >= thresh, i.e. max_on * fd >= thresh * max_fd up to the rounding of the division (the margin
+  // below is 10^7 ulps) — and frames whose maxima cannot are skipped; with a threshold <= 0 every cell that is not a peak
+  // qualifies with its 0, first frame included.  Either way the exact value decides.
+  const bool filter = onset_thresh > 0.0 && !on_nan && (!infer || max_fd > 0.0);
+  const double lim = onset_thresh * max_fd * (1.0 - 1e-9);
+  for (int64_t t = T - 2; t >= 0; --t) {
+    if (t == 0 && onset_thresh > 0.0) break;  // never a peak: its 0 is below the threshold
+    const float *o0 = onset + t * kF, *n0 = note + t * kF, *n1 = t >= 1 ? n0 - kF : n0, *n2 = t >= 2 ? n1 - kF : n1;
+    uint8_t flag[kF];
+    int any = 0;
+    if (filter && !((double)row_on[(size_t)t] >= onset_thresh) && !(infer && max_on_d * row_fd[(size_t)t] >= lim)) continue;
+    if (filter && infer && t >= 2) {
+      for (int f = 0; f < kF; ++f) {
+        const double d1 = (double)n0[f] - (double)n1[f], d2 = (double)n0[f] - (double)n2[f];
+        const double d = d1 < d2 ? d1 : d2;
+        const int c = ((double)o0[f] >= onset_thresh) | (max_on_d * d >= lim);
+        flag[f] = (uint8_t)c;
+        any |= c;
+      }
+    } else if (filter) {
+      for (int f = 0; f < kF; ++f) {
+        const int c = (double)o0[f] >= onset_thresh;
+        flag[f] = (uint8_t)c;
+        any |= c;
+      }
+    } else {
+      std::memset(flag, 1, sizeof flag);
+      any = 1;
+    }
+    if (!any) continue;
     for (int f = kF - 1; f >= 0; --f) {
-      const double v = on[t * kF + f];
-      if (!(v > on[(t - 1) * kF + f] && v > on[(t + 1) * kF + f])) continue;
+      if (!flag[f]) continue;
+      double v = on_at(t, f);
+      if (!(t >= 1 && v > on_at(t - 1, f) && v > on_at(t + 1, f))) v = 0.0;  // scipy.signal.argrelmax along time
       if (!(v >= onset_thresh)) continue;
       const int64_t start = t;
       if (start >= T - 1) continue;
       int64_t i = start + 1;
       int k = 0;
       while (i < T - 1 && k < energy_tol) {
-        if (energy[i * kF + f] < frame_thresh)
+        if ((double)energy[i * kF + f] < frame_thresh)
           ++k;
         else
           k = 0;
@@ -244,9 +341,9 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
   // ---- melodia trick (note_creation.py:449-509)
   if (prm->melodia_trick) {
     MaxTree tree(energy, frame_thresh, g_scratch.cand, g_scratch.node);
-    while (true) {
+    while (!tree.has_nan()) {  // `while np.max(remaining_energy) > frame_thresh`: never true with a NaN in the map
       const int32_t am = tree.argmax();
-      if (am < 0 || !(energy[am] > frame_thresh)) break;
+      if (am < 0 || !((double)energy[am] > frame_thresh)) break;
       const int64_t i_mid = am / kF;
       const int f = am % kF;
       tree.set_zero(am);
@@ -258,7 +355,7 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
       int64_t i = i_mid + 1;
       int k = 0;
       while (i < T - 1 && k < energy_tol) {
-        if (energy[i * kF + f] < frame_thresh)
+        if ((double)energy[i * kF + f] < frame_thresh)
           ++k;
         else
           k = 0;
@@ -269,7 +366,7 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
       i = i_mid - 1;
       k = 0;
       while (i > 0 && k < energy_tol) {
-        if (energy[i * kF + f] < frame_thresh)
+        if ((double)energy[i * kF + f] < frame_thresh)
           ++k;
         else
           k = 0;

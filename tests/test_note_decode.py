@@ -302,3 +302,58 @@ def test_sonification_renders_the_notes(tmp_path):
     NC.sonify_midi(midi, tmp_path / "s.wav", sr=22050)
     sr, back = wavfile.read(tmp_path / "s.wav")
     assert sr == 22050 and np.array_equal(back, y)
+
+
+def _fuzz_maps(rng, T, kind):
+    """Posteriorgram-like maps: smooth ridges in time so notes exist, plus the degenerate shapes the decoder's shortcuts
+    (frames skipped by their row maxima, the onset map evaluated only near the threshold) must not change."""
+    note = rng.random((T, 88), dtype=np.float32) ** 3
+    onset = rng.random((T, 88), dtype=np.float32) ** 6
+    for _ in range(12):
+        f, a, n = int(rng.integers(0, 88)), int(rng.integers(0, max(1, T - 5))), int(rng.integers(5, 60))
+        note[a : a + n, f] = np.maximum(note[a : a + n, f], np.float32(0.35 + 0.6 * rng.random()))
+        onset[a, f] = np.float32(0.4 + 0.6 * rng.random())
+    if kind == "flat":  # nothing rises: max of the frame differences is 0 -> the inferred onsets are 0/0 = NaN
+        note[:] = np.float32(0.4)
+    elif kind == "nan_onset":
+        onset[int(rng.integers(0, T)), int(rng.integers(0, 88))] = np.nan
+    elif kind == "nan_note":
+        note[int(rng.integers(2, T)), int(rng.integers(0, 88))] = np.nan
+    elif kind == "zero_onsets":
+        onset[:] = 0
+    contour = rng.random((T, 264), dtype=np.float32)
+    return {"note": note, "onset": onset, "contour": contour}
+
+
+@pytest.mark.parametrize("kind", ["plain", "flat", "nan_onset", "nan_note", "zero_onsets"])
+def test_decoder_fuzz_against_restatement(kind):
+    """Seeded random maps, thresholds from below zero to above one, every switch: the C++ decoder and the numpy
+    restatement of note_creation.py:360-511 give the same events bit for bit."""
+    import warnings
+
+    from basic_pitch_amd import note_creation as NC
+
+    rng = np.random.default_rng({"plain": 1, "flat": 2, "nan_onset": 3, "nan_note": 4, "zero_onsets": 5}[kind])
+    for trial in range(10):
+        T = int(rng.integers(3, 400))
+        out = _fuzz_maps(rng, T, kind)
+        args = dict(onset_thresh=float(rng.choice([-0.1, 0.0, 0.2, 0.5, 0.9, 1.5])),
+                    frame_thresh=float(rng.choice([0.0, 0.1, 0.3, 0.6])),
+                    infer_onsets=bool(rng.integers(0, 2)), melodia_trick=bool(rng.integers(0, 2)),
+                    min_note_len=int(rng.choice([0, 3, 11])), include_pitch_bends=bool(rng.integers(0, 2)))
+        a = {k: v.copy() for k, v in out.items()}
+        b = {k: v.copy() for k, v in out.items()}
+        # the decoder alone (a NaN amplitude cannot become a MIDI velocity, in the reference either)
+        raw, bends, n = NC._decode(a["note"], a["onset"], a["contour"], args["onset_thresh"], args["frame_thresh"],
+                                   args["min_note_len"], args["infer_onsets"], None, None, args["melodia_trick"],
+                                   NC.ENERGY_TOLERANCE, args["include_pitch_bends"])
+        ev = [(float(raw[i].start_s), float(raw[i].end_s), int(raw[i].pitch_midi), np.float32(raw[i].amplitude),
+               bends[raw[i].bend_offset : raw[i].bend_offset + raw[i].n_bends].tolist() if args["include_pitch_bends"] else None)
+              for i in range(n)]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # numpy's 0/0 and NaN comparisons
+            ref, _ = NO.model_output_to_notes(b, **args)
+        nan_a = [i for i, e in enumerate(ev) if np.isnan(e[3])]
+        assert nan_a == [i for i, e in enumerate(ref) if np.isnan(e[3])]
+        fix = lambda evs: [(e[0], e[1], e[2], np.float32(0) if np.isnan(e[3]) else e[3], e[4]) for e in evs]
+        _same_events(fix(ev), fix(ref))
