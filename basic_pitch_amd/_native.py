@@ -23,6 +23,8 @@ BP_FLAG_BF16_WEIGHTS = 4
 BP_FLAG_EXT_CQT_44K = 8
 BP_FLAG_F16_CORRECTIONS = 32
 BP_FLAG_FP8_CORRECTIONS = 64
+BP_FLAG_BLOCKING_WAIT = 128
+BP_PCM_F32, BP_PCM_S16, BP_PCM_S24, BP_PCM_S32, BP_PCM_U8, BP_PCM_F64 = range(6)
 BP_N_STAGES = 15
 BP_Z_ROW = 448
 BP_Z_ROWS = 174
@@ -108,6 +110,11 @@ class bp_file_report(C.Structure):
         ("n_note_events", C.c_int32),
         ("n_frames", C.c_int64),
         ("message", C.c_char * 240),
+        ("ms_read", C.c_float),
+        ("ms_lane_wait", C.c_float),
+        ("ms_device", C.c_float),
+        ("ms_notes", C.c_float),
+        ("ms_write", C.c_float),
     ]
 
 
@@ -137,6 +144,9 @@ EXPORTED_SYMBOLS = [
     "bp_resampled_length",
     "bp_resample",
     "bp_infer_pcm",
+    "bp_infer_pcm_raw",
+    "bp_host_alloc",
+    "bp_host_free",
     "bp_track_n_windows",
     "bp_handle_track_n_windows",
     "bp_handle_track_n_frames",
@@ -216,6 +226,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bp_resample.restype = C.c_int
     lib.bp_infer_pcm.argtypes = [vp, fp, i64, C.c_int, C.c_int, fp, fp, fp, C.c_int]
     lib.bp_infer_pcm.restype = C.c_int
+    lib.bp_infer_pcm_raw.argtypes = [vp, vp, C.c_int, i64, C.c_int, C.c_int, fp, fp, fp, C.c_int]
+    lib.bp_infer_pcm_raw.restype = C.c_int
+    lib.bp_host_alloc.argtypes = [C.c_size_t]
+    lib.bp_host_alloc.restype = C.c_void_p
+    lib.bp_host_free.argtypes = [C.c_void_p]
+    lib.bp_host_free.restype = None
     lib.bp_handle_track_n_windows.argtypes = [vp, i64]
     lib.bp_handle_track_n_windows.restype = i64
     lib.bp_handle_track_n_frames.argtypes = [vp, i64]

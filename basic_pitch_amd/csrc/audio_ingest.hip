@@ -20,6 +20,7 @@
 #include <cmath>
 #include <vector>
 
+#include "../../include/basic_pitch_amd.h"
 #include "bp_common.h"
 
 namespace bp {
@@ -113,6 +114,38 @@ __global__ __launch_bounds__(256) void downmix_kernel(const float* __restrict__ 
   mono[i] = s / (float)channels;
 }
 
+// The same downmix straight from the file's sample format (bp_pcm_format): 16-bit stereo is half the bytes of its float
+// form over PCIe and the host never converts it.  Scales as in basic_pitch_amd/audio.py read_wav / the WAV reader of
+// file_pipeline.cpp (powers of two: exact), so the mono signal is bit-identical to the float path's.
+template <int FMT>
+__device__ __forceinline__ float pcm_sample(const uint8_t* __restrict__ raw, int64_t i) {
+  if (FMT == BP_PCM_S16) return (float)reinterpret_cast<const int16_t*>(raw)[i] * (1.0f / 32768.0f);
+  if (FMT == BP_PCM_U8) return ((float)raw[i] - 128.0f) * (1.0f / 128.0f);
+  if (FMT == BP_PCM_S24) {
+    const uint8_t* p = raw + 3 * i;
+    int32_t v = (int32_t)p[0] | ((int32_t)p[1] << 8) | ((int32_t)p[2] << 16);
+    if (v >= 1 << 23) v -= 1 << 24;
+    return (float)v * (1.0f / 8388608.0f);
+  }
+  if (FMT == BP_PCM_S32) return (float)((double)reinterpret_cast<const int32_t*>(raw)[i] * (1.0 / 2147483648.0));
+  if (FMT == BP_PCM_F64) return (float)reinterpret_cast<const double*>(raw)[i];
+  return reinterpret_cast<const float*>(raw)[i];
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256) void downmix_raw_kernel(const uint8_t* __restrict__ raw, int64_t n_frames, int channels,
+                                                          float* __restrict__ mono) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_frames) return;
+  if (channels == 1) {
+    mono[i] = pcm_sample<FMT>(raw, i);
+    return;
+  }
+  float s = 0.0f;
+  for (int c = 0; c < channels; ++c) s += pcm_sample<FMT>(raw, i * channels + c);
+  mono[i] = s / (float)channels;
+}
+
 // y[k] = sum_j x[j] h[k * down + centre - j * up], the signal zero outside [0, n_in)
 __global__ __launch_bounds__(256) void resample_poly_kernel(const float* __restrict__ x, int64_t n_in,
                                                             const double* __restrict__ taps, ResamplePlan pl,
@@ -127,6 +160,91 @@ __global__ __launch_bounds__(256) void resample_poly_kernel(const float* __restr
   double acc = 0.0;
   for (int64_t j = j_lo; j <= j_hi; ++j) acc += (double)x[j] * taps[base - j * pl.up];
   y[k] = (float)acc;
+}
+
+// The same sum, term for term in the same order, for a block of 256 outputs whose input span fits LDS: the block's slice of
+// x is staged once (each input sample is used by n_taps / down outputs — 195 at 2 : 1, where the kernel above fetched every
+// one of them from memory again: 1.55 ms for a 3-minute track, more than the CQT + CNN of its 110 windows) and, when the
+// table is small (pure decimation: 389 taps at 2 : 1), the taps too.
+constexpr int kResTileX = 4096;     // floats of x per block
+constexpr int kResTileTaps = 1024;  // float64 taps held in LDS
+template <bool TAPS_LDS>
+__global__ __launch_bounds__(256) void resample_tiled_kernel(const float* __restrict__ x, int64_t n_in,
+                                                             const double* __restrict__ taps, ResamplePlan pl,
+                                                             float* __restrict__ y, int64_t n_out) {
+  __shared__ float xs[kResTileX];
+  __shared__ double hs[TAPS_LDS ? kResTileTaps : 1];
+  auto j_lo_of = [&](int64_t base) {
+    const int64_t lo_num = base - (pl.n_taps - 1);
+    return lo_num <= 0 ? (int64_t)0 : (lo_num + pl.up - 1) / pl.up;
+  };
+  auto j_hi_of = [&](int64_t base) {
+    const int64_t j = base / pl.up;
+    return j > n_in - 1 ? n_in - 1 : j;
+  };
+  const int64_t k0 = (int64_t)blockIdx.x * 256;
+  const int64_t k_last = k0 + 255 < n_out - 1 ? k0 + 255 : n_out - 1;
+  const int64_t j0 = j_lo_of(k0 * (int64_t)pl.down + pl.centre);
+  const int64_t j1 = j_hi_of(k_last * (int64_t)pl.down + pl.centre);
+  for (int64_t j = j0 + threadIdx.x; j <= j1; j += 256) xs[j - j0] = x[j];
+  if (TAPS_LDS)
+    for (int i = threadIdx.x; i < (int)pl.n_taps; i += 256) hs[i] = taps[i];
+  __syncthreads();
+  const int64_t k = k0 + threadIdx.x;
+  if (k >= n_out) return;
+  const int64_t base = k * (int64_t)pl.down + pl.centre;
+  const int64_t j_lo = j_lo_of(base), j_hi = j_hi_of(base);
+  double acc = 0.0;
+  for (int64_t j = j_lo; j <= j_hi; ++j) {
+    const int64_t t = base - j * pl.up;
+    acc += (double)xs[j - j0] * (TAPS_LDS ? hs[t] : taps[t]);
+  }
+  y[k] = (float)acc;
+}
+
+// 2 : 1 (44.1 kHz files, the common case): the same sum once more, each thread four consecutive outputs.  Output k at
+// step s (tap n_taps - 1 - s, i.e. j ascending as above) reads x[X0 + 8 t + s + 2 i] for k = K0 + 4 t + i, so the block's
+// slice of x is stored de-interleaved by 8 (sub[e & 7][e >> 3]): a thread holds one value of each of the eight
+// sub-sequences in registers, step s multiplies four of them with ONE tap and replaces one — per four multiply-adds one
+// conflict-free ds_read_b32, one conversion and one broadcast tap read, where the tiled kernel paid two reads and a
+// conversion for each.  Samples outside the signal and the steps that pad the tap count to a multiple of 8 contribute
+// x * 0 or 0 * tap = 0, which leaves a float64 accumulator as it is: the result is the kernels' above, bit for bit.
+// 303 -> ~40 us for a 3-minute track.
+constexpr int kHalfSub = 388;  // 256 threads + 1024 / 8 tap blocks + 1, = 4 (mod 32): the de-interleaved fill is conflict-free
+__global__ __launch_bounds__(256) void resample_half_kernel(const float* __restrict__ x, int64_t n_in,
+                                                            const double* __restrict__ taps, ResamplePlan pl,
+                                                            float* __restrict__ y, int64_t n_out) {
+  __shared__ float sub[8][kHalfSub];
+  __shared__ double hs[kResTileTaps + 8];
+  const int M = (int)pl.n_taps, nb = (M + 7) / 8, t = threadIdx.x;
+  const int64_t K0 = (int64_t)blockIdx.x * 1024;
+  const int64_t X0 = 2 * K0 + pl.centre - (M - 1);  // x index behind sub[0][0]
+  const int n_tile = 8 * (256 + nb + 1);
+  for (int e = t; e < n_tile; e += 256) {
+    const int64_t X = X0 + e;
+    sub[e & 7][e >> 3] = (X >= 0 && X < n_in) ? x[X] : 0.0f;
+  }
+  for (int s = t; s < 8 * nb; s += 256) hs[s] = s < M ? taps[M - 1 - s] : 0.0;
+  __syncthreads();
+  double r[8], acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) r[q] = (double)sub[q][t];
+  for (int b = 0; b < nb; ++b) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double h = hs[8 * b + q];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_fma(r[(q + 2 * i) & 7], h, acc[i]);
+      r[q] = (double)sub[q][t + b + 1];
+    }
+  }
+  const int64_t k = K0 + 4 * t;
+  if (k + 3 < n_out) {
+    *reinterpret_cast<float4*>(y + k) = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
+  } else {
+    for (int i = 0; i < 4; ++i)
+      if (k + i < n_out) y[k + i] = (float)acc[i];
+  }
 }
 
 // the same sum with the taps evaluated in place: sinc in closed form, the Kaiser window by cubic (4-point Lagrange)
@@ -163,15 +281,38 @@ void launch_downmix(const float* pcm, int64_t n_frames, int channels, float* mon
                      channels, mono);
 }
 
+void launch_downmix_raw(const void* raw, int format, int64_t n_frames, int channels, float* mono, hipStream_t stream) {
+  if (n_frames <= 0) return;
+  const dim3 grid((unsigned)((n_frames + 255) / 256));
+  const uint8_t* p = static_cast<const uint8_t*>(raw);
+  switch (format) {
+    case BP_PCM_S16: hipLaunchKernelGGL(downmix_raw_kernel<BP_PCM_S16>, grid, dim3(256), 0, stream, p, n_frames, channels, mono); break;
+    case BP_PCM_S24: hipLaunchKernelGGL(downmix_raw_kernel<BP_PCM_S24>, grid, dim3(256), 0, stream, p, n_frames, channels, mono); break;
+    case BP_PCM_S32: hipLaunchKernelGGL(downmix_raw_kernel<BP_PCM_S32>, grid, dim3(256), 0, stream, p, n_frames, channels, mono); break;
+    case BP_PCM_U8: hipLaunchKernelGGL(downmix_raw_kernel<BP_PCM_U8>, grid, dim3(256), 0, stream, p, n_frames, channels, mono); break;
+    case BP_PCM_F64: hipLaunchKernelGGL(downmix_raw_kernel<BP_PCM_F64>, grid, dim3(256), 0, stream, p, n_frames, channels, mono); break;
+    default: hipLaunchKernelGGL(downmix_raw_kernel<BP_PCM_F32>, grid, dim3(256), 0, stream, p, n_frames, channels, mono); break;
+  }
+}
+
+// mode 0: the fastest kernel that fits; 1: the one-thread-per-output kernel; 2: at most the tiled one (A/B runs, BP_RESAMPLE)
 void launch_resample(const float* x, int64_t n_in, const double* taps, const ResamplePlan& pl, float* y,
-                     int64_t n_out, hipStream_t stream) {
+                     int64_t n_out, int mode, hipStream_t stream) {
   if (n_out <= 0) return;
+  // inputs a block of 256 outputs reaches (upper bound)
+  const int64_t span = (255 * (int64_t)pl.down + pl.n_taps - 1) / pl.up + 2;
+  const dim3 per_output((unsigned)((n_out + 255) / 256));
   if (pl.direct)
-    hipLaunchKernelGGL(resample_direct_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, x, n_in,
-                       taps, pl, y, n_out);
+    hipLaunchKernelGGL(resample_direct_kernel, per_output, dim3(256), 0, stream, x, n_in, taps, pl, y, n_out);
+  else if (mode == 0 && pl.up == 1 && pl.down == 2 && pl.n_taps <= kResTileTaps && (reinterpret_cast<uintptr_t>(y) & 15) == 0)
+    hipLaunchKernelGGL(resample_half_kernel, dim3((unsigned)((n_out + 1023) / 1024)), dim3(256), 0, stream, x, n_in, taps,
+                       pl, y, n_out);
+  else if (mode != 1 && span <= kResTileX && pl.n_taps <= kResTileTaps)
+    hipLaunchKernelGGL(resample_tiled_kernel<true>, per_output, dim3(256), 0, stream, x, n_in, taps, pl, y, n_out);
+  else if (mode != 1 && span <= kResTileX)
+    hipLaunchKernelGGL(resample_tiled_kernel<false>, per_output, dim3(256), 0, stream, x, n_in, taps, pl, y, n_out);
   else
-    hipLaunchKernelGGL(resample_poly_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, x, n_in,
-                       taps, pl, y, n_out);
+    hipLaunchKernelGGL(resample_poly_kernel, per_output, dim3(256), 0, stream, x, n_in, taps, pl, y, n_out);
 }
 
 }  // namespace bp

@@ -63,8 +63,9 @@ void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, L
                   hipStream_t s);
 ResamplePlan make_resample_plan(int source_rate, int target_rate, std::vector<double>& taps);
 void launch_downmix(const float* pcm, int64_t n_frames, int channels, float* mono, hipStream_t stream);
+void launch_downmix_raw(const void* raw, int format, int64_t n_frames, int channels, float* mono, hipStream_t stream);
 void launch_resample(const float* x, int64_t n_in, const double* taps, const ResamplePlan& pl, float* y,
-                     int64_t n_out, hipStream_t stream);
+                     int64_t n_out, int mode, hipStream_t stream);
 void launch_contour_conv1_exact(const uint32_t* zp, const void* wlds, const float* bias, float* c1, int n_windows,
                                 int n_cu, bool weights_have_lo, hipStream_t stream);
 void launch_contour_conv1_folded(const uint32_t* zp, const void* wfold, const float* bias, float* c1, int n_windows,
@@ -190,6 +191,7 @@ struct bp_context {
   int n_cu = 256;
   char arch[32] = {0};
   hipStream_t own_stream = nullptr, stream = nullptr;
+  hipEvent_t done = nullptr;  // BP_FLAG_BLOCKING_WAIT: the event a waiting host thread sleeps on
   int64_t cap = 0;
   int64_t workspace_bytes = 0;
   std::string err;
@@ -211,6 +213,7 @@ struct bp_context {
   float *d_d1_wlds = nullptr, *d_d1_wfold = nullptr, *d_d1_wmarch = nullptr, *d_d1_wrim = nullptr, *d_d1_bias = nullptr,
         *d_d2_w = nullptr;
   bool rim_exact = false, fold_mx = false;
+  int resample_mode = 0;  // BP_RESAMPLE=plain|tiled: 1 | 2 (A/B runs of the resampling kernels)
   int contour_parts = 0;  // BP_CONTOUR_PARTS (0: automatic)
   float* d_d1_wfold_mx = nullptr;
   float* c1s = nullptr;  // [cap][172][kC1Row][8] relu(conv1); pad bins zeroed once at allocation
@@ -759,6 +762,7 @@ int free_all(bp_handle h) {
   if (h->ev_valid)
     for (auto& row : h->ev)
       for (auto& e : row) (void)hipEventDestroy(e);
+  if (h->done) (void)hipEventDestroy(h->done);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   return BP_OK;
 }
@@ -1097,6 +1101,8 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       // (the extended 345-bin CQT has its own GEMM table since round 4: 160 z bins per side)
       h->rim_exact = er && std::strcmp(er, "exact") == 0;
     }
+    if (const char* es = std::getenv("BP_RESAMPLE"))  // A/B runs: the resampler's simpler kernels (bit-identical results)
+      h->resample_mode = std::strcmp(es, "plain") == 0 ? 1 : std::strcmp(es, "tiled") == 0 ? 2 : 0;
     for (int br = 0; br < 2; ++br) {
       pack_branch(br ? 13 : 4, br ? o1w : n1w, br ? o2w : n2w, br == 1, frag);
       std::vector<float> f32(42, 0.f);
@@ -1194,6 +1200,11 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
           return fail(BP_ERR_HIP);
         }
     h->ev_valid = true;
+  }
+  if ((flags & BP_FLAG_BLOCKING_WAIT) &&
+      hipEventCreateWithFlags(&h->done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
+    h->err = "hipEventCreateWithFlags failed";
+    return fail(BP_ERR_HIP);
   }
   *out = h;
   return BP_OK;
@@ -1328,6 +1339,18 @@ int64_t bp_track_n_frames(int64_t n_samples) {
 }
 
 // windows of a device-resident 22.05 kHz signal -> un-overlapped posteriorgrams (host or device outputs)
+// end of a host-blocking call: spin on the stream (lowest latency) or, with BP_FLAG_BLOCKING_WAIT, sleep until the device
+// raises the event's interrupt (the core goes to another worker thread)
+static int wait_stream(bp_handle h) {
+  if (h->done) {
+    BP_HIP(hipEventRecord(h->done, h->stream));
+    BP_HIP(hipEventSynchronize(h->done));
+  } else {
+    BP_HIP(hipStreamSynchronize(h->stream));
+  }
+  return BP_OK;
+}
+
 static int track_core(bp_handle h, const float* d_samples, int64_t n_samples, float* note, float* onset,
                       float* contour, int out_kind) {
   hipStream_t s = h->stream;
@@ -1364,8 +1387,7 @@ static int track_core(bp_handle h, const float* d_samples, int64_t n_samples, fl
     BP_HIP(hipMemcpyAsync(onset, d_onset, (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
     BP_HIP(hipMemcpyAsync(contour, d_contour, (size_t)T * 264 * 4, hipMemcpyDeviceToHost, s));
   }
-  BP_HIP(hipStreamSynchronize(s));
-  return BP_OK;
+  return wait_stream(h);
 }
 
 static int grow(bp_handle h, float** buf, int64_t* cap, int64_t need) {
@@ -1515,8 +1537,7 @@ int bp_infer_tracks(bp_handle h, int64_t n_tracks, const float* const* samples, 
       BP_HIP(hipMemcpyAsync(contour[t], d_contour[t], (size_t)T * 264 * 4, hipMemcpyDeviceToHost, s));
     }
   }
-  BP_HIP(hipStreamSynchronize(s));
-  return BP_OK;
+  return wait_stream(h);
 }
 
 int64_t bp_resampled_length(int64_t n_frames, int sample_rate) {
@@ -1526,11 +1547,24 @@ int64_t bp_resampled_length(int64_t n_frames, int sample_rate) {
 
 // downmix + resample into h->res_dev (or straight through when already mono 22.05 kHz on the device);
 // *out = device pointer of the 22.05 kHz signal, *n_out = its length
-static int ingest(bp_handle h, const float* pcm, int64_t n_frames, int channels, int sample_rate, int mem_kind,
+static int pcm_width(int format) {
+  switch (format) {
+    case BP_PCM_F32: return 4;
+    case BP_PCM_S16: return 2;
+    case BP_PCM_S24: return 3;
+    case BP_PCM_S32: return 4;
+    case BP_PCM_U8: return 1;
+    case BP_PCM_F64: return 8;
+    default: return 0;
+  }
+}
+
+static int ingest(bp_handle h, const void* pcm, int format, int64_t n_frames, int channels, int sample_rate, int mem_kind,
                   const float** out, int64_t* n_out) {
-  if (n_frames < 0 || channels < 1 || channels > 64 || sample_rate < 1000 || sample_rate > 768000 ||
+  const int width = pcm_width(format);
+  if (n_frames < 0 || channels < 1 || channels > 64 || sample_rate < 1000 || sample_rate > 768000 || width == 0 ||
       (mem_kind != BP_MEM_HOST && mem_kind != BP_MEM_DEVICE) || (n_frames > 0 && !pcm)) {
-    h->err = "audio ingest: bad argument (n_frames, channels, sample_rate, mem_kind or null pcm)";
+    h->err = "audio ingest: bad argument (n_frames, channels, sample_rate, format, mem_kind or null pcm)";
     return BP_ERR_INVALID_ARG;
   }
   BP_HIP(hipSetDevice(h->device));
@@ -1538,18 +1572,22 @@ static int ingest(bp_handle h, const float* pcm, int64_t n_frames, int channels,
   *n_out = bp_handle_resampled_length(h, n_frames, sample_rate);
   *out = nullptr;
   if (n_frames == 0) return BP_OK;
-  const float* d_pcm = pcm;
+  const void* d_pcm = pcm;
   if (mem_kind == BP_MEM_HOST) {
-    int rc = grow(h, &h->pcm_dev, &h->pcm_cap, n_frames * channels);
+    const int64_t bytes = n_frames * channels * width;
+    int rc = grow(h, &h->pcm_dev, &h->pcm_cap, (bytes + 3) / 4);
     if (rc) return rc;
-    BP_HIP(hipMemcpyAsync(h->pcm_dev, pcm, (size_t)n_frames * channels * 4, hipMemcpyHostToDevice, s));
+    BP_HIP(hipMemcpyAsync(h->pcm_dev, pcm, (size_t)bytes, hipMemcpyHostToDevice, s));
     d_pcm = h->pcm_dev;
   }
-  const float* d_mono = d_pcm;
-  if (channels > 1) {
+  const float* d_mono = static_cast<const float*>(d_pcm);
+  if (channels > 1 || format != BP_PCM_F32) {
     int rc = grow(h, &h->mono_dev, &h->mono_cap, n_frames);
     if (rc) return rc;
-    launch_downmix(d_pcm, n_frames, channels, h->mono_dev, s);
+    if (format == BP_PCM_F32)
+      launch_downmix(static_cast<const float*>(d_pcm), n_frames, channels, h->mono_dev, s);
+    else
+      launch_downmix_raw(d_pcm, format, n_frames, channels, h->mono_dev, s);
     d_mono = h->mono_dev;
   }
   if (sample_rate == h->rate) {
@@ -1569,7 +1607,7 @@ static int ingest(bp_handle h, const float* pcm, int64_t n_frames, int channels,
   }
   int rc = grow(h, &h->res_dev, &h->res_cap, *n_out);
   if (rc) return rc;
-  launch_resample(d_mono, n_frames, h->taps_dev, h->plan, h->res_dev, *n_out, s);
+  launch_resample(d_mono, n_frames, h->taps_dev, h->plan, h->res_dev, *n_out, h->resample_mode, s);
   BP_HIP(hipGetLastError());
   *out = h->res_dev;
   return BP_OK;
@@ -1580,7 +1618,7 @@ int bp_resample(bp_handle h, const float* pcm, int64_t n_frames, int channels, i
   if (!h) return BP_ERR_INVALID_ARG;
   const float* d = nullptr;
   int64_t n_out = 0;
-  int rc = ingest(h, pcm, n_frames, channels, sample_rate, mem_kind, &d, &n_out);
+  int rc = ingest(h, pcm, BP_PCM_F32, n_frames, channels, sample_rate, mem_kind, &d, &n_out);
   if (rc) return rc;
   if (n_out == 0) return BP_OK;
   if (!out22k) {
@@ -1593,12 +1631,12 @@ int bp_resample(bp_handle h, const float* pcm, int64_t n_frames, int channels, i
   return BP_OK;
 }
 
-int bp_infer_pcm(bp_handle h, const float* pcm, int64_t n_frames, int channels, int sample_rate, float* note,
-                 float* onset, float* contour, int mem_kind) {
+int bp_infer_pcm_raw(bp_handle h, const void* pcm, int format, int64_t n_frames, int channels, int sample_rate, float* note,
+                     float* onset, float* contour, int mem_kind) {
   if (!h) return BP_ERR_INVALID_ARG;
   const float* d = nullptr;
   int64_t n = 0;
-  int rc = ingest(h, pcm, n_frames, channels, sample_rate, mem_kind, &d, &n);
+  int rc = ingest(h, pcm, format, n_frames, channels, sample_rate, mem_kind, &d, &n);
   if (rc) return rc;
   if (h_track_n_windows(h, n) == 0) return BP_OK;
   if (h_track_n_frames(h, n) > 0 && (!note || !onset || !contour)) {
@@ -1606,6 +1644,24 @@ int bp_infer_pcm(bp_handle h, const float* pcm, int64_t n_frames, int channels, 
     return BP_ERR_INVALID_ARG;
   }
   return track_core(h, d, n, note, onset, contour, mem_kind);
+}
+
+int bp_infer_pcm(bp_handle h, const float* pcm, int64_t n_frames, int channels, int sample_rate, float* note,
+                 float* onset, float* contour, int mem_kind) {
+  return bp_infer_pcm_raw(h, pcm, BP_PCM_F32, n_frames, channels, sample_rate, note, onset, contour, mem_kind);
+}
+
+void* bp_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+void bp_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int bp_get_stage_ms(bp_handle h, float* ms, int n) {

@@ -12,20 +12,23 @@
 #include <algorithm>
 #include <atomic>
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <fstream>
 #include <map>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
+#include <cerrno>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../include/basic_pitch_amd.h"
 
@@ -344,20 +347,100 @@ bool notes_midi(const bp_note_event* ev, int64_t n, const int32_t* bends, bool m
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-bool read_file(const std::string& path, std::vector<uint8_t>& data) {
-  std::ifstream f(path, std::ios::binary | std::ios::ate);
-  if (!f) {
+// page-locked, grow-only: what a worker hands to / receives from the device goes by DMA without the runtime's staging copy.
+// Page-locking tens of megabytes costs milliseconds, so a worker's buffers go back to a process-wide pool when it ends and
+// the next bp_transcribe_files call starts from them (at most kPoolMax buffers are kept; the rest are released).
+struct PinnedPool {
+  static constexpr size_t kPoolMax = 192;
+  std::mutex mu;
+  std::vector<std::pair<void*, size_t>> free_list;
+  // the smallest pooled buffer of at least n bytes, else a new one
+  std::pair<void*, size_t> take(size_t n) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      size_t best = free_list.size();
+      for (size_t i = 0; i < free_list.size(); ++i)
+        if (free_list[i].second >= n && (best == free_list.size() || free_list[i].second < free_list[best].second)) best = i;
+      if (best != free_list.size()) {
+        const auto b = free_list[best];
+        free_list.erase(free_list.begin() + (long)best);
+        return b;
+      }
+    }
+    const size_t want = n + n / 8 + 4096;
+    return {bp_host_alloc(want), want};
+  }
+  void give(void* p, size_t cap) {
+    if (!p) return;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (free_list.size() < kPoolMax) {
+        free_list.emplace_back(p, cap);
+        return;
+      }
+    }
+    bp_host_free(p);
+  }
+};
+PinnedPool g_pinned;
+
+struct Pinned {
+  void* p = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t n) {
+    if (n <= cap) return true;
+    g_pinned.give(p, cap);
+    p = nullptr, cap = 0;
+    const auto b = g_pinned.take(n);
+    if (!b.first) {
+      g_file_error = "page-locked host allocation of " + std::to_string(b.second) + " bytes failed";
+      return false;
+    }
+    p = b.first, cap = b.second;
+    return true;
+  }
+  ~Pinned() { g_pinned.give(p, cap); }
+  Pinned() = default;
+  Pinned(const Pinned&) = delete;
+  Pinned& operator=(const Pinned&) = delete;
+};
+
+bool read_file_pinned(const std::string& path, Pinned& buf, size_t& n) {
+  n = 0;
+  const int fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+  if (fd < 0) {
     g_file_error = path + " is not a file path.";
     return false;
   }
-  const std::streamsize n = f.tellg();
-  f.seekg(0);
-  data.resize((size_t)n);
-  if (n && !f.read(reinterpret_cast<char*>(data.data()), n)) {
-    g_file_error = "cannot read " + path;
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+    g_file_error = path + " is not a file path.";
+    close(fd);
     return false;
   }
+  const size_t size = (size_t)st.st_size;
+  if (!buf.ensure(size ? size : 1)) {
+    close(fd);
+    return false;
+  }
+  while (n < size) {
+    const ssize_t got = read(fd, static_cast<uint8_t*>(buf.p) + n, size - n);
+    if (got < 0 && errno == EINTR) continue;
+    if (got < 0) {
+      g_file_error = path + ": " + std::strerror(errno);
+      close(fd);
+      return false;
+    }
+    if (got == 0) break;  // shorter than fstat said: what is there
+    n += (size_t)got;
+  }
+  close(fd);
   return true;
+}
+
+int wav_pcm_format(const WavInfo& w) {
+  if (w.tag == 1) return w.bits == 8 ? BP_PCM_U8 : w.bits == 16 ? BP_PCM_S16 : w.bits == 24 ? BP_PCM_S24 : BP_PCM_S32;
+  return w.bits == 32 ? BP_PCM_F32 : BP_PCM_F64;
 }
 
 bool write_new_file(const std::string& path, const void* data, size_t n) {
@@ -385,7 +468,8 @@ std::string stem_of(const std::string& path) {
 }
 
 // one worker per core this process may really use: a cgroup CPU quota (containers: 16 of a host's 256 hardware threads)
-// counts, not the host's thread count — oversubscribed workers measured 25 % slower
+// counts, not the host's thread count — oversubscribed workers measured 25 % slower (the quota throttles every thread of
+// the group, the ones feeding the GPU included)
 int default_threads() {
   int n = (int)std::thread::hardware_concurrency();
   if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
@@ -500,6 +584,7 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
         set_report(&reports[i], BP_ERR_INVALID_ARG,
                    std::string("the outputs of ") + paths[i] + " would overwrite those of " + paths[seen[stem]] + " (same file stem)");
         reports[i].n_note_events = 0, reports[i].n_frames = 0;
+        reports[i].ms_read = reports[i].ms_lane_wait = reports[i].ms_device = reports[i].ms_notes = reports[i].ms_write = 0.0f;
       } else {
         seen[stem] = i;
       }
@@ -527,8 +612,7 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
 
   std::atomic<int64_t> next{0};
   auto worker = [&]() {
-    std::vector<uint8_t> file;
-    std::vector<float> pcm, note, onset, contour;
+    Pinned file, decoded, maps;  // the file's bytes; float PCM of a FLAC file; the three posteriorgrams
     std::vector<bp_note_event> events;
     std::vector<int32_t> bends;
     std::vector<uint8_t> midi;
@@ -539,6 +623,14 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
       if (dup[(size_t)i]) continue;
       bp_file_report* rep = &reports[i];
       rep->n_note_events = 0, rep->n_frames = 0;
+      rep->ms_read = rep->ms_lane_wait = rep->ms_device = rep->ms_notes = rep->ms_write = 0.0f;
+      auto clock = std::chrono::steady_clock::now();
+      auto lap = [&clock]() {  // milliseconds since the previous lap
+        const auto t = std::chrono::steady_clock::now();
+        const float ms = std::chrono::duration<float, std::milli>(t - clock).count();
+        clock = t;
+        return ms;
+      };
       const std::string path = paths[i];
       const std::string base = std::string(out_dir) + "/" + stem_of(path) + "_basic_pitch.";
       // refuse before doing the work, like build_output_path
@@ -546,50 +638,64 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
         set_report(rep, BP_ERR_INVALID_ARG, base + "* already exists and would be overwritten. Skipping output files for " + path + ".");
         continue;
       }
-      if (!read_file(path, file)) {
+      size_t n_bytes = 0;
+      if (!read_file_pinned(path, file, n_bytes)) {
         set_report(rep, BP_ERR_BAD_AUDIO, g_file_error);
         continue;
       }
-      int channels = 0, sr = 0;
+      const uint8_t* fb = static_cast<const uint8_t*>(file.p);
+      int channels = 0, sr = 0, format = BP_PCM_F32;
       int64_t n_frames = 0;
-      if (file.size() >= 12 && std::memcmp(file.data(), "RIFF", 4) == 0 && std::memcmp(file.data() + 8, "WAVE", 4) == 0) {
+      const void* pcm = nullptr;
+      if (n_bytes >= 12 && std::memcmp(fb, "RIFF", 4) == 0 && std::memcmp(fb + 8, "WAVE", 4) == 0) {
         WavInfo w;
-        if (!wav_parse(file.data(), file.size(), w)) {
+        if (!wav_parse(fb, n_bytes, w)) {
           set_report(rep, BP_ERR_BAD_AUDIO, path + ": " + g_file_error);
           continue;
         }
-        channels = w.channels, sr = w.sample_rate, n_frames = w.n_frames;
-        pcm.resize((size_t)(n_frames * channels));
-        wav_to_float(w, pcm.data());
-      } else if (file.size() >= 4 && (std::memcmp(file.data(), "fLaC", 4) == 0 || std::memcmp(file.data(), "ID3", 3) == 0)) {
+        // the samples go to the device as the file stores them (bp_infer_pcm_raw converts there)
+        channels = w.channels, sr = w.sample_rate, n_frames = w.n_frames, pcm = w.pcm, format = wav_pcm_format(w);
+      } else if (n_bytes >= 4 && (std::memcmp(fb, "fLaC", 4) == 0 || std::memcmp(fb, "ID3", 3) == 0)) {
         int bits = 0;
-        if (bp_flac_info(file.data(), file.size(), &channels, &sr, &bits, &n_frames) != BP_OK) {
+        if (bp_flac_info(fb, n_bytes, &channels, &sr, &bits, &n_frames) != BP_OK) {
           set_report(rep, BP_ERR_BAD_AUDIO, path + ": " + bp_audio_last_error());
           continue;
         }
-        pcm.resize((size_t)(n_frames * channels));
+        if (!decoded.ensure((size_t)(n_frames * channels) * sizeof(float) + 4)) {
+          set_report(rep, BP_ERR_OUT_OF_MEMORY, path + ": " + g_file_error);
+          continue;
+        }
         int64_t got = 0;
-        if (bp_flac_decode(file.data(), file.size(), pcm.data(), n_frames, &got) != BP_OK || got != n_frames) {
+        if (bp_flac_decode(fb, n_bytes, static_cast<float*>(decoded.p), n_frames, &got) != BP_OK || got != n_frames) {
           set_report(rep, BP_ERR_BAD_AUDIO, path + ": " + bp_audio_last_error());
           continue;
         }
+        pcm = decoded.p;
       } else {
         set_report(rep, BP_ERR_BAD_AUDIO, path + ": not a WAV or FLAC file (the native pipeline reads RIFF/WAVE and FLAC)");
         continue;
       }
-      std::vector<uint8_t>().swap(file);  // 30 MB per worker back before the posteriorgrams are allocated
 
+      const int64_t T = bp_handle_track_n_frames(handles[0], bp_handle_resampled_length(handles[0], n_frames, sr));
+      if (T > 0 && !maps.ensure((size_t)T * (88 + 88 + 264) * sizeof(float))) {
+        set_report(rep, BP_ERR_OUT_OF_MEMORY, path + ": " + g_file_error);
+        continue;
+      }
+      float* note = static_cast<float*>(maps.p);
+      float* onset = note + T * 88;
+      float* contour = onset + T * 88;
+      rep->ms_read = lap();
       const int lane = acquire();
+      rep->ms_lane_wait = lap();
       bp_handle h = handles[lane];
-      const int64_t T = bp_handle_track_n_frames(h, bp_handle_resampled_length(h, n_frames, sr));
       int rc = BP_OK;
       std::string err;
       if (T > 0) {
-        note.resize((size_t)T * 88), onset.resize((size_t)T * 88), contour.resize((size_t)T * 264);
-        rc = bp_infer_pcm(h, pcm.data(), n_frames, channels, sr, note.data(), onset.data(), contour.data(), BP_MEM_HOST);
+        rc = bp_infer_pcm_raw(h, pcm, format, n_frames, channels, sr, note, onset, contour, BP_MEM_HOST);
         if (rc != BP_OK) err = bp_last_error(h);
       }
       release(lane);
+      rep->ms_device = lap();
       if (rc != BP_OK) {
         set_report(rep, rc, path + ": " + err);
         continue;
@@ -600,8 +706,8 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
       size_t cap_ev = (size_t)std::max<int64_t>(256, T / 4), cap_b = (size_t)std::max<int64_t>(4096, 4 * T);
       for (int attempt = 0; attempt < 2; ++attempt) {
         events.resize(cap_ev), bends.resize(cap_b);
-        rc = T > 0 ? bp_notes_decode(note.data(), onset.data(), contour.data(), T, &prm.notes, events.data(), (int64_t)cap_ev,
-                                     bends.data(), (int64_t)cap_b, &n_ev, &n_b)
+        rc = T > 0 ? bp_notes_decode(note, onset, contour, T, &prm.notes, events.data(), (int64_t)cap_ev, bends.data(),
+                                     (int64_t)cap_b, &n_ev, &n_b)
                    : BP_OK;
         if (rc == BP_OK || !((size_t)n_ev > cap_ev || (size_t)n_b > cap_b)) break;
         cap_ev = std::max(cap_ev, (size_t)n_ev), cap_b = std::max(cap_b, (size_t)n_b);
@@ -611,6 +717,7 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
         continue;
       }
       rep->n_note_events = (int32_t)n_ev;
+      rep->ms_notes = lap();
       const int32_t* bp = prm.notes.include_pitch_bends ? bends.data() : nullptr;
       bool ok = true;
       if (prm.save_midi) {
@@ -626,6 +733,7 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
         set_report(rep, BP_ERR_INVALID_ARG, g_file_error);
         continue;
       }
+      rep->ms_write = lap();
       set_report(rep, BP_OK, "");
     }
   };

@@ -79,6 +79,7 @@ class Model:
         ext_cqt_44k: bool = False,
         f16_corrections: bool = False,
         fp8_corrections: bool = False,
+        blocking_wait: bool = False,
     ):
         self.model_type = Model.MODEL_TYPES.MI355X_HIP
         self._lib = _native.load_library()
@@ -97,6 +98,8 @@ class Model:
             flags |= _native.BP_FLAG_F16_CORRECTIONS
         if fp8_corrections:  # opt-in reduced precision: contour / onset conv1 corrections on block-scaled fp8 MFMA
             flags |= _native.BP_FLAG_FP8_CORRECTIONS
+        if blocking_wait:  # whole-track calls sleep on an interrupt instead of spinning (file jobs: workers share cores)
+            flags |= _native.BP_FLAG_BLOCKING_WAIT
         rc = self._lib.bp_create(blob, len(blob), int(device), flags, int(max_windows), C.byref(self._handle))
         if rc != _native.BP_OK:
             self._handle = C.c_void_p()
@@ -739,14 +742,15 @@ def transcribe_files(
     natively: ONE call into the library (`bp_transcribe_files`, csrc/file_pipeline.cpp), C++ worker threads from the
     file's bytes to its outputs, no Python in the loop.  Same bytes as `predict_and_save(..., save_midi, False, False,
     save_notes)`.  `models` (or `lanes` models built from `model_or_model_path`) are the GPU lanes the workers queue
-    for.  Returns per file `{"status": 0 | bp_status, "n_note_events": k, "n_frames": T, "message": str}`; per-file
+    for.  Returns per file `{"status": 0 | bp_status, "n_note_events": k, "n_frames": T, "message": str, "ms": {stage: wall
+    milliseconds of the worker}}`; per-file
     failures are reported, not raised (the reference's per-file try / except)."""
     own: List[Model] = []
     if models is None:
         if isinstance(model_or_model_path, Model):
             models = [model_or_model_path]
         else:
-            own = [Model(model_or_model_path, max_windows=128) for _ in range(max(1, int(lanes)))]
+            own = [Model(model_or_model_path, max_windows=128, blocking_wait=True) for _ in range(max(1, int(lanes)))]
             models = own
     try:
         lib = models[0]._lib
@@ -770,7 +774,8 @@ def transcribe_files(
         if rc != _native.BP_OK:
             raise ValueError(f"bp_transcribe_files: {lib.bp_files_last_error().decode(errors='replace')}")
         return [{"status": int(reports[i].status), "n_note_events": int(reports[i].n_note_events),
-                 "n_frames": int(reports[i].n_frames), "message": reports[i].message.decode(errors="replace")}
+                 "n_frames": int(reports[i].n_frames), "message": reports[i].message.decode(errors="replace"),
+                 "ms": {k: float(getattr(reports[i], "ms_" + k)) for k in ("read", "lane_wait", "device", "notes", "write")}}
                 for i in range(n)]
     finally:
         for m in own:

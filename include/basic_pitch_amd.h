@@ -98,6 +98,10 @@ typedef enum bp_mem_kind {
                                     * 1.05e-4 (profiles/r02_parity_many.md).  (Environment, for A/B runs of one layer on a
                                     * handle created with this flag: BP_CONV1=f16, BP_ONSET=f16.)  Ignored with
                                     * BP_FLAG_BF16_WEIGHTS / BP_FLAG_F32_MFMA. */
+#define BP_FLAG_BLOCKING_WAIT 128u /* the whole-track calls (bp_infer_track / _tracks / _pcm / _pcm_raw) wait for the device
+                                    * asleep on an interrupt instead of spinning on the stream: for file jobs with more worker
+                                    * threads than cores (bp_transcribe_files).  Costs tens of microseconds of wake-up
+                                    * latency per call; results are the same. */
 
 /*
  * Weights blob ("BPAMDW01", little endian) — produced from the reference's nmp.onnx
@@ -178,6 +182,27 @@ int bp_resample(bp_handle h, const float* pcm, int64_t n_frames, int channels, i
                 int mem_kind);
 int bp_infer_pcm(bp_handle h, const float* pcm, int64_t n_frames, int channels, int sample_rate, float* note,
                  float* onset, float* contour, int mem_kind);
+
+/*
+ * bp_infer_pcm on the samples as the file stores them: interleaved little-endian PCM in one of the formats below goes over
+ * PCIe as it is (16-bit stereo: half the bytes of its float form) and becomes float on the device, with the scaling of
+ * libsndfile's float read that librosa.load uses (inference.py:239): integers / 2^(bits-1), 8-bit unsigned (v - 128) / 128,
+ * float64 rounded to float32.  Same result, bit for bit, as converting on the host and calling bp_infer_pcm.
+ * bp_host_alloc / bp_host_free: page-locked host memory (any thread, any device); copies to and from it are DMA without
+ * the runtime's staging copy — for `pcm` and the three outputs of the BP_MEM_HOST calls.  NULL when the allocation fails.
+ */
+typedef enum bp_pcm_format {
+  BP_PCM_F32 = 0, /* IEEE float32 */
+  BP_PCM_S16 = 1,
+  BP_PCM_S24 = 2, /* packed, 3 bytes per sample */
+  BP_PCM_S32 = 3,
+  BP_PCM_U8 = 4,
+  BP_PCM_F64 = 5
+} bp_pcm_format;
+int bp_infer_pcm_raw(bp_handle h, const void* pcm, int format, int64_t n_frames, int channels, int sample_rate, float* note,
+                     float* onset, float* contour, int mem_kind);
+void* bp_host_alloc(size_t bytes);
+void bp_host_free(void* p);
 
 /*
  * Replaces: the decode step of librosa.load for FLAC input (inference.py:239; README.md:182-189 lists .flac) — host
@@ -350,6 +375,9 @@ typedef struct bp_file_report {
   int32_t n_note_events;
   int64_t n_frames;             /* rows of the file's posteriorgrams */
   char message[240];            /* empty on success */
+  /* where the worker's wall time for this file went, in milliseconds: reading the file (and FLAC decode), waiting for a
+   * GPU lane, the device call (copy in, resample, CQT + CNN, copy out), note decoding, MIDI / CSV encoding + writes */
+  float ms_read, ms_lane_wait, ms_device, ms_notes, ms_write;
 } bp_file_report;
 
 void bp_transcribe_params_default(bp_transcribe_params* p);

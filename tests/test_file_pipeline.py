@@ -209,3 +209,64 @@ def test_sharded_batch_job_through_the_native_pipeline(tmp_path):
     for i in range(4):
         for ext in ("mid", "csv"):
             assert (out_dir / f"c{i}_basic_pitch.{ext}").read_bytes() == (ref_dir / f"c0_basic_pitch.{ext}").read_bytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["u8", "i16", "i24", "i32", "f32", "f64"])
+def test_raw_pcm_formats_equal_the_float_path(kind):
+    """bp_infer_pcm_raw converts the file's sample format on the device: bit-identical posteriorgrams to converting on the
+    host (bp_wav_decode's scaling = read_wav's) and calling bp_infer_pcm — stereo 44.1 kHz and mono 22.05 kHz, input and
+    outputs in page-locked memory from bp_host_alloc, on a handle that waits asleep (BP_FLAG_BLOCKING_WAIT)."""
+    from basic_pitch_amd import Model
+
+    lib = _native.load_library()
+    fmt, dt, tag, bits = {"u8": (_native.BP_PCM_U8, np.uint8, 1, 8), "i16": (_native.BP_PCM_S16, "<i2", 1, 16),
+                          "i24": (_native.BP_PCM_S24, None, 1, 24), "i32": (_native.BP_PCM_S32, "<i4", 1, 32),
+                          "f32": (_native.BP_PCM_F32, "<f4", 3, 32), "f64": (_native.BP_PCM_F64, "<f8", 3, 64)}[kind]
+    rng = np.random.default_rng(11)
+    model = Model(max_windows=8, blocking_wait=True)
+    fp = C.POINTER(C.c_float)
+    for ch, rate, n in ((2, 44100, 3 * 44100 + 17), (1, 22050, 2 * 22050 + 5)):
+        t = np.arange(n) / rate
+        x = 0.5 * np.sin(2 * np.pi * 330.0 * t)[:, None] * np.array([1.0, 0.6])[None, :ch] + 0.02 * rng.standard_normal((n, ch))
+        x = np.clip(x, -0.99, 0.99)
+        if kind == "u8":
+            raw = np.round(x * 127 + 128).astype(np.uint8).tobytes()
+        elif kind == "i24":
+            v = np.round(x * (2**23 - 1)).astype(np.int64).ravel()
+            raw = b"".join(int(s & 0xFFFFFF).to_bytes(3, "little") for s in v)
+        elif tag == 1:
+            raw = np.round(x * (2 ** (bits - 1) - 1)).astype(dt).tobytes()
+        else:
+            raw = x.astype(dt).tobytes()
+        wav = _wav_bytes(tag, bits, ch, rate, raw)
+        pcm = np.empty((n, ch), np.float32)
+        k = C.c_int64()
+        assert lib.bp_wav_decode(wav, len(wav), pcm.ctypes.data_as(fp), n, C.byref(k)) == 0 and k.value == n
+        T = lib.bp_handle_track_n_frames(model._handle, lib.bp_handle_resampled_length(model._handle, n, rate))
+        assert T > 0
+        ref = [np.empty((T, w), np.float32) for w in (88, 88, 264)]
+        rc = lib.bp_infer_pcm(model._handle, pcm.ctypes.data_as(fp), n, ch, rate, *[a.ctypes.data_as(fp) for a in ref], 0)
+        assert rc == 0, model.last_error() if hasattr(model, "last_error") else rc
+        # the raw samples at an odd offset inside a page-locked buffer, as the file pipeline hands them over
+        n_out = T * 440 * 4
+        host = lib.bp_host_alloc(len(raw) + 3 + n_out)
+        assert host
+        try:
+            C.memmove(host + 3, raw, len(raw))
+            out = host + 3 + len(raw)
+            out += (-out) % 4
+            host_out = lib.bp_host_alloc(n_out)
+            assert host_out
+            try:
+                ptrs = [C.cast(host_out + o * 4, fp) for o in (0, T * 88, T * 176)]
+                rc = lib.bp_infer_pcm_raw(model._handle, host + 3, fmt, n, ch, rate, *ptrs, 0)
+                assert rc == 0
+                got = np.ctypeslib.as_array(C.cast(host_out, fp), shape=(T * 440,)).copy()
+            finally:
+                lib.bp_host_free(host_out)
+        finally:
+            lib.bp_host_free(host)
+        for a, o, w in zip(ref, (0, T * 88, T * 176), (88, 88, 264)):
+            assert np.array_equal(a.view(np.uint32).ravel(), got[o : o + T * w].view(np.uint32)), (kind, ch, w)
+    assert lib.bp_infer_pcm_raw(model._handle, None, 99, 10, 1, 22050, None, None, None, 0) == _native.BP_ERR_INVALID_ARG

@@ -642,6 +642,26 @@ def test_device_audio_ingest(weights):
     m.close()
 
 
+def test_resample_kernels_agree_bit_for_bit(monkeypatch):
+    """The resampler's three kernels — one thread per output, the LDS-tiled one, the 2 : 1 register-window one — add the
+    same products in the same order: identical float32 signals, at the signal's edges too (a 2 : 1 length that is not a
+    multiple of the block's 1024 outputs, a signal shorter than the filter)."""
+    from basic_pitch_amd import Model
+
+    rng = np.random.default_rng(8)
+    cases = [(44100, 2, 150001), (44100, 1, 2 * 1024 * 7), (44100, 1, 300), (88200, 1, 40000), (48000, 2, 9600), (16000, 1, 4000)]
+    sig = [rng.uniform(-1, 1, (n, ch)).astype(np.float32) for _, ch, n in cases]
+    got = {}
+    for mode in ("plain", "tiled", "auto"):
+        monkeypatch.setenv("BP_RESAMPLE", mode)
+        m = Model(max_windows=8)
+        got[mode] = [m.resample(x, sr) for x, (sr, _, _) in zip(sig, cases)]
+        m.close()
+    for i, c in enumerate(cases):
+        for mode in ("tiled", "auto"):
+            assert np.array_equal(got["plain"][i].view(np.uint32), got[mode][i].view(np.uint32)), (c, mode)
+
+
 def test_predict_note_events_match_reference_golden(tmp_path):
     """BASELINE.json north star: MIDI note events identical to the reference's on its test clip.
     `predict()` end to end (WAV decode on the host; downmix, resampling, CQT + CNN on the MI355X; note decoding in C++)

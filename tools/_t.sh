@@ -1,11 +1,9 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_parity.py -x -q -k "extended or fused_branch or batch_invariance or bf16" 2>&1 | tail -40
-for i in 1 2; do
-echo "== ext rim GEMM"; python bench.py --ext-cqt-44k --batch 512 --steps 10 --no-cpu-baseline --sustained-s 0 --no-config-extras 2>/dev/null | python -c "
+python -m pytest tests/test_file_pipeline.py tests/test_gpu_parity.py -x -q -k "ingest or pipeline or raw_pcm or transcribe or golden or track or resample" 2>&1 | tail -4
+for cfg in "2 0" "3 0" "4 0" "4 14"; do
+set -- $cfg
+echo "== lanes $1 threads $2"; python bench.py --workload files --native --files 1024 --lanes $1 --native-threads $2 2>&1 | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('value %.0f ms %.4f' % (d['value'], d['ms_per_step'])); print({k: round(v,4) for k,v in d['stage_ms'].items() if v})"
-echo "== ext rim exact"; BP_RIM=exact python bench.py --ext-cqt-44k --batch 512 --steps 10 --no-cpu-baseline --sustained-s 0 --no-config-extras 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('value %.0f ms %.4f' % (d['value'], d['ms_per_step'])); print({k: round(v,4) for k,v in d['stage_ms'].items() if v})"
+d=json.loads(sys.stdin.read()); print('files/s %.1f' % d['value'], {k: round(v,2) for k,v in d.get('worker_ms_per_file').items()})"
 done
