@@ -147,6 +147,7 @@ EXPORTED_SYMBOLS = [
     "bp_infer_pcm_raw",
     "bp_host_alloc",
     "bp_host_free",
+    "bp_files_release_buffers",
     "bp_track_n_windows",
     "bp_handle_track_n_windows",
     "bp_handle_track_n_frames",
@@ -232,6 +233,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bp_host_alloc.restype = C.c_void_p
     lib.bp_host_free.argtypes = [C.c_void_p]
     lib.bp_host_free.restype = None
+    lib.bp_files_release_buffers.argtypes = []
+    lib.bp_files_release_buffers.restype = None
     lib.bp_handle_track_n_windows.argtypes = [vp, i64]
     lib.bp_handle_track_n_windows.restype = i64
     lib.bp_handle_track_n_frames.argtypes = [vp, i64]

@@ -495,6 +495,15 @@ extern "C" {
 
 const char* bp_files_last_error(void) { return g_file_error.c_str(); }
 
+void bp_files_release_buffers(void) {
+  std::vector<std::pair<void*, size_t>> all;
+  {
+    std::lock_guard<std::mutex> lk(g_pinned.mu);
+    all.swap(g_pinned.free_list);
+  }
+  for (auto& b : all) bp_host_free(b.first);
+}
+
 int bp_wav_info(const void* file, size_t nbytes, int* channels, int* sample_rate, int* bits_per_sample, int64_t* n_frames) {
   WavInfo w;
   if (!file || !wav_parse(static_cast<const uint8_t*>(file), nbytes, w)) {

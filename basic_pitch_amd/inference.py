@@ -735,7 +735,7 @@ def transcribe_files(
     melodia_trick: bool = True,
     midi_tempo: float = DEFAULT_MINIMUM_MIDI_TEMPO,
     models: Optional[Sequence[Model]] = None,
-    lanes: int = 2,
+    lanes: int = 3,
     threads: int = 0,
 ) -> List[Dict[str, Any]]:
     """The batch job of `predict_and_save` (inference.py:509-604) for WAV / FLAC input and MIDI / note-event output, run

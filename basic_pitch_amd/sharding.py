@@ -287,15 +287,15 @@ def _save_shard(paths: Sequence[Any], indices: Sequence[int], device: int, model
 
     if not indices:
         return {}
+    kwargs = dict(kwargs)
+    native = kwargs.pop("native", False)
+    native_lanes, native_threads = int(kwargs.pop("native_lanes", 3)), int(kwargs.pop("native_threads", 0))
     if model_factory is not None:
         model = model_factory(device)
     elif isinstance(model_or_model_path, inference.Model):
         model = model_or_model_path
-    else:
-        model = inference.Model(model_or_model_path, device=device)
-    kwargs = dict(kwargs)
-    native = kwargs.pop("native", False)
-    native_lanes, native_threads = int(kwargs.pop("native_lanes", 2)), int(kwargs.pop("native_threads", 0))
+    else:  # the native pipeline's lanes wait asleep: its workers share the cores with the lanes' waiting threads
+        model = inference.Model(model_or_model_path, device=device, blocking_wait=bool(native))
     if native:
         # the native pipeline (bp_transcribe_files: C++ worker threads, no Python in the loop) for this worker's share
         if save_flags.get("sonify_midi") or save_flags.get("save_model_outputs"):
@@ -304,7 +304,7 @@ def _save_shard(paths: Sequence[Any], indices: Sequence[int], device: int, model
             kwargs.pop(k, None)
         lanes = [model]
         if model_factory is None and not isinstance(model_or_model_path, inference.Model):
-            lanes += [inference.Model(model_or_model_path, device=device) for _ in range(max(0, native_lanes - 1))]
+            lanes += [inference.Model(model_or_model_path, device=device, blocking_wait=True) for _ in range(max(0, native_lanes - 1))]
         sel = [paths[i] for i in indices]
         raw = inference.transcribe_files(sel, output_directory, save_flags.get("save_midi", True), save_flags.get("save_notes", True),
                                          models=lanes, threads=native_threads, **kwargs)

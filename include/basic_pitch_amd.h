@@ -394,6 +394,9 @@ int64_t bp_notes_to_csv(const bp_note_event* events, int64_t n_events, const int
 int bp_wav_info(const void* file, size_t nbytes, int* channels, int* sample_rate, int* bits_per_sample, int64_t* n_frames);
 int bp_wav_decode(const void* file, size_t nbytes, float* pcm, int64_t max_frames, int64_t* n_frames);
 const char* bp_files_last_error(void); /* thread-local */
+/* bp_transcribe_files keeps its workers' page-locked buffers (a file's bytes, its posteriorgrams) in a process-wide pool
+ * between calls; this releases the pooled ones (a long-lived service calls it when a burst of jobs is over). */
+void bp_files_release_buffers(void);
 
 #ifdef __cplusplus
 }

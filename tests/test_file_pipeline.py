@@ -181,6 +181,16 @@ def test_transcribe_files_equals_predict_and_save(tmp_path):
     assert rep[0]["n_note_events"] == 28  # the reference's golden clip
     again = transcribe_files(good[:1], out_dir, models=[model])
     assert again[0]["status"] != 0 and "already exists" in again[0]["message"]
+    # the workers' page-locked buffers are pooled between calls; releasing the pool changes nothing but memory
+    assert all(set(r["ms"]) == {"read", "lane_wait", "device", "notes", "write"} for r in rep)
+    _native.load_library().bp_files_release_buffers()
+    out2 = tmp_path / "out2"
+    out2.mkdir()
+    rep2 = transcribe_files(good, out2, models=[model], threads=2)
+    assert [r["status"] for r in rep2] == [0] * len(good)
+    for p in good:
+        stem = os.path.splitext(os.path.basename(str(p)))[0]
+        assert (out_dir / f"{stem}_basic_pitch.mid").read_bytes() == (out2 / f"{stem}_basic_pitch.mid").read_bytes()
 
 
 @pytest.mark.gpu
