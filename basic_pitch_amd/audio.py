@@ -21,8 +21,9 @@ import numpy as np
 AUDIO_SAMPLE_RATE = 22050
 
 
-def read_wav(path: Union[str, pathlib.Path]) -> Tuple[np.ndarray, int]:
-    """Return (float32 samples [n, channels] in [-1, 1), sample_rate) for PCM8/16/24/32 or float WAV."""
+def wav_raw(path: Union[str, pathlib.Path]):
+    """The samples of a RIFF/WAVE file as the file stores them: (uint8 view of the data chunk, format tag, bits, channels,
+    sample_rate).  Tag 1 = integer PCM (8 / 16 / 24 / 32 bits), 3 = IEEE float (32 / 64)."""
     with open(path, "rb") as f:
         data = memoryview(f.read())  # chunks below are views, not copies (a 3-minute stereo file is 31 MB)
     if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
@@ -45,6 +46,16 @@ def read_wav(path: Union[str, pathlib.Path]) -> Tuple[np.ndarray, int]:
     if fmt is None or pcm is None:
         raise ValueError(f"{path}: missing fmt or data chunk")
     tag, ch, sr, bits = fmt
+    if not ((tag == 1 and bits in (8, 16, 24, 32)) or (tag == 3 and bits in (32, 64))):
+        raise ValueError(f"{path}: unsupported PCM bit depth {bits}" if tag == 1 else f"{path}: unsupported WAV format tag {tag}")
+    if ch < 1:
+        raise ValueError(f"{path}: zero channels")
+    return pcm, tag, bits, ch, sr
+
+
+def read_wav(path: Union[str, pathlib.Path]) -> Tuple[np.ndarray, int]:
+    """Return (float32 samples [n, channels] in [-1, 1), sample_rate) for PCM8/16/24/32 or float WAV."""
+    pcm, tag, bits, ch, sr = wav_raw(path)
     if tag == 1:  # integer PCM; scale factors are powers of two: multiplying by the reciprocal is exact
         if bits == 8:
             x = np.frombuffer(pcm, dtype=np.uint8).astype(np.float32)

@@ -19,6 +19,7 @@ import enum
 import json
 import os
 import pathlib
+import threading
 from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -318,6 +319,29 @@ class Model:
         _native.check(self._lib, self._handle, rc, "bp_infer_pcm")
         return out
 
+    def predict_pcm_raw(self, samples, fmt: int, n_frames: int, channels: int, sample_rate: int) -> Dict[str, np.ndarray]:
+        """predict_pcm on interleaved samples in the file's own format (`fmt` = a BP_PCM_* code; `samples` = any buffer
+        of n_frames * channels of them): they cross PCIe as they are — 16-bit stereo is half the bytes of its float form
+        — and become float on the device, bit-identical to converting on the host first (bp_infer_pcm_raw)."""
+        buf = np.frombuffer(samples, dtype=np.uint8)
+        width = {_native.BP_PCM_F32: 4, _native.BP_PCM_S16: 2, _native.BP_PCM_S24: 3, _native.BP_PCM_S32: 4,
+                 _native.BP_PCM_U8: 1, _native.BP_PCM_F64: 8}[int(fmt)]
+        if buf.size < int(n_frames) * int(channels) * width:
+            raise ValueError("predict_pcm_raw: the buffer is shorter than n_frames * channels samples")
+        n22 = int(self._lib.bp_handle_resampled_length(self._handle, int(n_frames), int(sample_rate)))
+        T = int(self._lib.bp_handle_track_n_frames(self._handle, n22))
+        out = {
+            "note": np.empty((T, N_FREQ_BINS_NOTES), dtype=np.float32),
+            "onset": np.empty((T, N_FREQ_BINS_NOTES), dtype=np.float32),
+            "contour": np.empty((T, N_FREQ_BINS_CONTOURS), dtype=np.float32),
+        }
+        rc = self._lib.bp_infer_pcm_raw(
+            self._handle, buf.ctypes.data if buf.size else None, int(fmt), int(n_frames), int(channels), int(sample_rate),
+            out["note"].ctypes.data, out["onset"].ctypes.data, out["contour"].ctypes.data, _native.BP_MEM_HOST,
+        )
+        _native.check(self._lib, self._handle, rc, "bp_infer_pcm_raw")
+        return out
+
     # -- introspection ----------------------------------------------------------------------------
     def info(self) -> Dict[str, Any]:
         inf = _native.bp_info()
@@ -377,6 +401,37 @@ def unwrap_output(
     return unwrapped_output[: int(n_expected_windows * n_frames_per_window), :]
 
 
+# `predict(path)` with a model PATH loads the model on every call in the reference (inference.py:291-292 -> Model(...)).
+# Loading is 60 ms here (parsing, packing the operand fragments, 0.8 GB of device buffers) against ~1 ms for the
+# reference's 10-second clip itself, so a loaded model is kept per (file identity, calling thread) and reused: the handle
+# is stateful and not for two threads at once, hence one per thread.
+_MODEL_CACHE: "Dict[Tuple[Any, ...], Model]" = {}
+_MODEL_CACHE_LOCK = threading.Lock()
+_MODEL_CACHE_MAX = 8
+
+
+def _model_from(model_or_model_path) -> Any:
+    """A Model (or anything shaped like one) as it is; a path as the cached Model loaded from that file."""
+    if not isinstance(model_or_model_path, (str, os.PathLike)):
+        return model_or_model_path
+    try:
+        real = os.path.realpath(os.fspath(model_or_model_path))
+        st = os.stat(real)
+        key = (real, st.st_mtime_ns, st.st_size, threading.get_ident())
+    except OSError:
+        return Model(model_or_model_path)  # raises what loading a missing file raises
+    with _MODEL_CACHE_LOCK:
+        model = _MODEL_CACHE.get(key)
+        if model is not None and model._handle.value:
+            return model
+    model = Model(model_or_model_path)
+    with _MODEL_CACHE_LOCK:
+        while len(_MODEL_CACHE) >= _MODEL_CACHE_MAX:
+            _MODEL_CACHE.pop(next(iter(_MODEL_CACHE)))  # oldest first; the handle is freed when nobody holds the Model
+        _MODEL_CACHE[key] = model
+    return model
+
+
 def run_inference(
     audio_path: Union[pathlib.Path, str],
     model_or_model_path: Union[Model, pathlib.Path, str] = ICASSP_2022_MODEL_PATH,
@@ -386,16 +441,28 @@ def run_inference(
 
     Returns {"note": (T,88), "onset": (T,88), "contour": (T,264)} float32, T = int(L/36164*142).
     """
-    model = model_or_model_path if isinstance(model_or_model_path, Model) else Model(model_or_model_path)
+    model = _model_from(model_or_model_path)
     n_overlapping_frames = DEFAULT_OVERLAPPING_FRAMES
     overlap_len = n_overlapping_frames * FFT_HOP
     hop_size = AUDIO_N_SAMPLES - overlap_len
 
     # decode on the host (container parsing), everything after it on the device: channel-mean downmix, resampling
     # to 22.05 kHz, the 3840-sample lead-in + windowing, CQT + CNN, un-overlapping (inference.py:239-244, 302-315)
-    pcm, file_sr = _audio.read_audio(str(audio_path))
-    audio_original_length = int(-(-pcm.shape[0] * AUDIO_SAMPLE_RATE // file_sr))  # librosa.resample: ceil(n * sr / file_sr)
-    unwrapped_output = model.predict_pcm(pcm, file_sr)
+    with open(audio_path, "rb") as f:
+        head = f.read(12)
+    if head[:4] == b"RIFF" and head[8:12] == b"WAVE" and hasattr(model, "predict_pcm_raw"):
+        # a WAV file's samples go to the device in the file's own format (no float copy on the host, half the PCIe bytes
+        # for 16-bit audio); same posteriorgrams, bit for bit, as decoding them here
+        raw, tag, bits, channels, file_sr = _audio.wav_raw(str(audio_path))
+        fmt = {(1, 8): _native.BP_PCM_U8, (1, 16): _native.BP_PCM_S16, (1, 24): _native.BP_PCM_S24,
+               (1, 32): _native.BP_PCM_S32, (3, 32): _native.BP_PCM_F32, (3, 64): _native.BP_PCM_F64}[(tag, bits)]
+        n_file_frames = len(raw) // (bits // 8) // channels
+        unwrapped_output = model.predict_pcm_raw(raw, fmt, n_file_frames, channels, file_sr)
+    else:
+        pcm, file_sr = _audio.read_audio(str(audio_path))
+        n_file_frames = pcm.shape[0]
+        unwrapped_output = model.predict_pcm(pcm, file_sr)
+    audio_original_length = int(-(-n_file_frames * AUDIO_SAMPLE_RATE // file_sr))  # librosa.resample: ceil(n * sr / file_sr)
 
     if debug_file:
         with open(debug_file, "w") as f:
@@ -559,8 +626,9 @@ def predict_many(
     import concurrent.futures as cf
     import os
 
-    # a path loads the model like the reference does; a Model — or anything with its resample / predict_tracks — is used
-    model = Model(model_or_model_path) if isinstance(model_or_model_path, (str, os.PathLike)) else model_or_model_path
+    # a path loads the model like the reference does (once per thread: _model_from); a Model — or anything with its
+    # resample / predict_tracks — is used
+    model = _model_from(model_or_model_path)
     if group < 1:
         raise ValueError("group must be >= 1")
     paths = [pathlib.Path(p) for p in audio_paths]
@@ -675,7 +743,7 @@ def predict_and_save_many(
     reference's `raise e`).  Two inputs that map to the same output name (same stem) cannot both be written: as in the
     reference's sequential loop (inference.py:401-404) the first one wins and every later one gets the "already exists"
     IOError — decided up front, so concurrent writers never race on the exists-check."""
-    model = Model(model_or_model_path) if isinstance(model_or_model_path, (str, os.PathLike)) else model_or_model_path
+    model = _model_from(model_or_model_path)
     paths = [pathlib.Path(p) for p in audio_path_list]
     saving = save_midi or sonify_midi or save_model_outputs or save_notes
     # two inputs with the same stem would write the same files.  The map is made up front only so that concurrent writers
@@ -817,7 +885,7 @@ def predict_and_save(
     midi_tempo: float = DEFAULT_MINIMUM_MIDI_TEMPO,
 ) -> None:
     """inference.py:509-618: model output (.npz), MIDI (.mid), sonified MIDI (.wav), note events (.csv) per file."""
-    model = model_or_model_path if isinstance(model_or_model_path, Model) else Model(model_or_model_path)
+    model = _model_from(model_or_model_path)
     for audio_path in audio_path_list:
         result = predict(
             pathlib.Path(audio_path), model, onset_threshold, frame_threshold, minimum_note_length,

@@ -642,6 +642,37 @@ def test_device_audio_ingest(weights):
     m.close()
 
 
+def test_model_path_is_loaded_once_per_thread():
+    """predict(path) with a model PATH (the reference's default call): the loaded model is kept and reused by later calls
+    of the same thread, another thread gets its own (a handle is not for two threads at once), same results either way."""
+    import threading
+
+    from basic_pitch_amd import inference as inf
+
+    wav = os.path.join(GOLDEN, "vocadito_10.wav")
+    inf._MODEL_CACHE.clear()
+    a, _, ev_a = inf.predict(wav)
+    assert len(inf._MODEL_CACHE) == 1
+    first = next(iter(inf._MODEL_CACHE.values()))
+    b, _, ev_b = inf.predict(wav, inf.ICASSP_2022_MODEL_PATH)
+    assert len(inf._MODEL_CACHE) == 1 and next(iter(inf._MODEL_CACHE.values())) is first
+    got = {}
+
+    def other():
+        got["out"] = inf.predict(wav)
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert len(inf._MODEL_CACHE) == 2
+    for k in a:
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], got["out"][0][k]), k
+    assert len(ev_a) == len(ev_b) == len(got["out"][2]) == 28
+    with pytest.raises(ValueError):
+        inf.predict(wav, os.path.join(GOLDEN, "no_such_model.onnx"))
+    inf._MODEL_CACHE.clear()
+
+
 def test_resample_kernels_agree_bit_for_bit(monkeypatch):
     """The resampler's three kernels — one thread per output, the LDS-tiled one, the 2 : 1 register-window one — add the
     same products in the same order: identical float32 signals, at the signal's edges too (a 2 : 1 length that is not a
