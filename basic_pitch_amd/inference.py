@@ -805,12 +805,15 @@ def transcribe_files(
     models: Optional[Sequence[Model]] = None,
     lanes: int = 3,
     threads: int = 0,
+    devices: Optional[Sequence[int]] = None,
 ) -> List[Dict[str, Any]]:
     """The batch job of `predict_and_save` (inference.py:509-604) for WAV / FLAC input and MIDI / note-event output, run
     natively: ONE call into the library (`bp_transcribe_files`, csrc/file_pipeline.cpp), C++ worker threads from the
     file's bytes to its outputs, no Python in the loop.  Same bytes as `predict_and_save(..., save_midi, False, False,
-    save_notes)`.  `models` (or `lanes` models built from `model_or_model_path`) are the GPU lanes the workers queue
-    for.  Returns per file `{"status": 0 | bp_status, "n_note_events": k, "n_frames": T, "message": str, "ms": {stage: wall
+    save_notes)`.  `models` (or `lanes` models per device of `devices` — default: device 0 — built from
+    `model_or_model_path`) are the GPU lanes the workers queue for; lanes may live on different GPUs, a worker takes
+    whichever is free, so ONE call shards its files over all GPUs of a node by itself (file-granular, no collective).
+    Returns per file `{"status": 0 | bp_status, "n_note_events": k, "n_frames": T, "message": str, "ms": {stage: wall
     milliseconds of the worker}}`; per-file
     failures are reported, not raised (the reference's per-file try / except)."""
     own: List[Model] = []
@@ -818,7 +821,8 @@ def transcribe_files(
         if isinstance(model_or_model_path, Model):
             models = [model_or_model_path]
         else:
-            own = [Model(model_or_model_path, max_windows=128, blocking_wait=True) for _ in range(max(1, int(lanes)))]
+            own = [Model(model_or_model_path, device=int(d), max_windows=128, blocking_wait=True)
+                   for d in (devices if devices is not None else [0]) for _ in range(max(1, int(lanes)))]
             models = own
     try:
         lib = models[0]._lib

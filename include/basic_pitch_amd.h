@@ -355,7 +355,8 @@ const char* bp_notes_last_error(void);
  * librosa.load (239: decode; downmix + resampling on the device), run_inference (282-330), model_output_to_notes
  * (note_creation.py:52-116), note_events_to_midi + pretty_midi write (222-267; inference.py:586) and save_note_events
  * (inference.py:409-428).  A worker thread owns a file from its bytes to its outputs; the handles are GPU lanes the
- * workers queue for (two or three handles overlap one file's transfers with another's kernels).  Outputs are named
+ * workers queue for (three handles per GPU overlap one file's transfers with another's kernels; handles of several GPUs
+ * in one call shard the files over them: a worker takes whichever lane is free, all handles of the same mode).  Outputs are named
  * <out_dir>/<stem>_basic_pitch.mid / .csv and never overwritten (inference.py:401-404): an existing file, and every
  * later input with the stem of an earlier one, is reported instead of written.  Per-file failures do not stop the job
  * (the reference's per-file try / except, 548-604): reports[i].status / message.  Bytes are identical to what

@@ -183,6 +183,12 @@ def test_transcribe_files_equals_predict_and_save(tmp_path):
     assert again[0]["status"] != 0 and "already exists" in again[0]["message"]
     # the workers' page-locked buffers are pooled between calls; releasing the pool changes nothing but memory
     assert all(set(r["ms"]) == {"read", "lane_wait", "device", "notes", "write"} for r in rep)
+    # lanes built per device (here: the one GPU named twice = four lanes; on a node: one call over all its GPUs)
+    out3 = tmp_path / "out3"
+    out3.mkdir()
+    rep3 = transcribe_files(good, out3, lanes=2, devices=[0, 0])
+    assert [r["status"] for r in rep3] == [0] * len(good)
+    assert (out3 / "clip_basic_pitch.csv").read_bytes() == (out_dir / "clip_basic_pitch.csv").read_bytes()
     _native.load_library().bp_files_release_buffers()
     out2 = tmp_path / "out2"
     out2.mkdir()
