@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void resample_tiled_kernel(const float* __rest
 // conflict-free ds_read_b32, one conversion and one broadcast tap read, where the tiled kernel paid two reads and a
 // conversion for each.  Samples outside the signal and the steps that pad the tap count to a multiple of 8 contribute
 // x * 0 or 0 * tap = 0, which leaves a float64 accumulator as it is: the result is the kernels' above, bit for bit.
-// 303 -> ~40 us for a 3-minute track.
+// 303 -> 83 us for a 3-minute track.
 constexpr int kHalfSub = 388;  // 256 threads + 1024 / 8 tap blocks + 1, = 4 (mod 32): the de-interleaved fill is conflict-free
 __global__ __launch_bounds__(256) void resample_half_kernel(const float* __restrict__ x, int64_t n_in,
                                                             const double* __restrict__ taps, ResamplePlan pl,
