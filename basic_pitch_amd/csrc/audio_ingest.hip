@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void resample_poly_kernel(const float* __restr
 }
 
 // The same sum, term for term in the same order, for a block of 256 outputs whose input span fits LDS: the block's slice of
-// x is staged once (each input sample is used by n_taps / down outputs — 195 at 2 : 1, where the kernel above fetched every
+// x is staged once (each input sample is used by n_taps / down outputs — 195 at 2 : 1, each of which reads 389 —, where the kernel above fetched every
 // one of them from memory again: 1.55 ms for a 3-minute track, more than the CQT + CNN of its 110 windows) and, when the
 // table is small (pure decimation: 389 taps at 2 : 1), the taps too.
 constexpr int kResTileX = 4096;     // floats of x per block
@@ -202,47 +202,57 @@ __global__ __launch_bounds__(256) void resample_tiled_kernel(const float* __rest
   y[k] = (float)acc;
 }
 
-// 2 : 1 (44.1 kHz files, the common case): the same sum once more, each thread four consecutive outputs.  Output k at
-// step s (tap n_taps - 1 - s, i.e. j ascending as above) reads x[X0 + 8 t + s + 2 i] for k = K0 + 4 t + i, so the block's
-// slice of x is stored de-interleaved by 8 (sub[e & 7][e >> 3]): a thread holds one value of each of the eight
-// sub-sequences in registers, step s multiplies four of them with ONE tap and replaces one — per four multiply-adds one
-// conflict-free ds_read_b32, one conversion and one broadcast tap read, where the tiled kernel paid two reads and a
-// conversion for each.  Samples outside the signal and the steps that pad the tap count to a multiple of 8 contribute
+// 2 : 1 (44.1 kHz files, the common case): the same sum once more, each thread OUT consecutive outputs.  Output k at
+// step s (tap n_taps - 1 - s, i.e. j ascending as above) reads x[X0 + W t + s + 2 i] for k = K0 + OUT t + i, W = 2 OUT,
+// so the block's slice of x is stored de-interleaved by W (sub[e % W][e / W]): a thread holds one value of each of the
+// W sub-sequences in registers, step s multiplies OUT of them with ONE tap and replaces one — per OUT multiply-adds
+// one conflict-free ds_read_b32, one conversion and one broadcast tap read, where the tiled kernel paid two reads and a
+// conversion for each.  Samples outside the signal and the steps that pad the tap count to a multiple of W contribute
 // x * 0 or 0 * tap = 0, which leaves a float64 accumulator as it is: the result is the kernels' above, bit for bit.
-// 303 -> 83 us for a 3-minute track.
-constexpr int kHalfSub = 388;  // 256 threads + 1024 / 8 tap blocks + 1, = 4 (mod 32): the de-interleaved fill is conflict-free
+// 3-minute track (1.54 G multiply-adds = 39 us at the fp64 vector rate): 303 us (tiled) -> 83 us with OUT = 4 -> 70 us with OUT = 8.
+constexpr int kHalfOut = 8, kHalfW = 2 * kHalfOut;
+// row length of a sub-sequence in LDS: 256 threads + 1024 / W tap blocks + 1, and = 2 (mod 32) so that the 32 lanes of a
+// fill pass (16 rows x 2 columns) hit 32 different banks
+constexpr int kHalfSub = 322;  // >= 256 + 64 + 1, = 2 (mod 32)
+static_assert(kHalfW == 16 && kHalfSub % 32 == 2 && kHalfSub >= 256 + kResTileTaps / kHalfW + 1, "fill pattern");
 __global__ __launch_bounds__(256) void resample_half_kernel(const float* __restrict__ x, int64_t n_in,
                                                             const double* __restrict__ taps, ResamplePlan pl,
                                                             float* __restrict__ y, int64_t n_out) {
-  __shared__ float sub[8][kHalfSub];
-  __shared__ double hs[kResTileTaps + 8];
-  const int M = (int)pl.n_taps, nb = (M + 7) / 8, t = threadIdx.x;
-  const int64_t K0 = (int64_t)blockIdx.x * 1024;
+  __shared__ float sub[kHalfW][kHalfSub];
+  __shared__ double hs[kResTileTaps + kHalfW];
+  const int M = (int)pl.n_taps, nb = (M + kHalfW - 1) / kHalfW, t = threadIdx.x;
+  const int64_t K0 = (int64_t)blockIdx.x * (256 * kHalfOut);
   const int64_t X0 = 2 * K0 + pl.centre - (M - 1);  // x index behind sub[0][0]
-  const int n_tile = 8 * (256 + nb + 1);
+  const int n_tile = kHalfW * (256 + nb + 1);
   for (int e = t; e < n_tile; e += 256) {
     const int64_t X = X0 + e;
-    sub[e & 7][e >> 3] = (X >= 0 && X < n_in) ? x[X] : 0.0f;
+    sub[e % kHalfW][e / kHalfW] = (X >= 0 && X < n_in) ? x[X] : 0.0f;
   }
-  for (int s = t; s < 8 * nb; s += 256) hs[s] = s < M ? taps[M - 1 - s] : 0.0;
+  for (int s = t; s < kHalfW * nb; s += 256) hs[s] = s < M ? taps[M - 1 - s] : 0.0;
   __syncthreads();
-  double r[8], acc[4] = {0.0, 0.0, 0.0, 0.0};
+  double r[kHalfW], acc[kHalfOut];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) r[q] = (double)sub[q][t];
+  for (int i = 0; i < kHalfOut; ++i) acc[i] = 0.0;
+#pragma unroll
+  for (int q = 0; q < kHalfW; ++q) r[q] = (double)sub[q][t];
   for (int b = 0; b < nb; ++b) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const double h = hs[8 * b + q];
+    for (int q = 0; q < kHalfW; ++q) {
+      const double h = hs[kHalfW * b + q];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = __builtin_fma(r[(q + 2 * i) & 7], h, acc[i]);
+      for (int i = 0; i < kHalfOut; ++i) acc[i] = __builtin_fma(r[(q + 2 * i) % kHalfW], h, acc[i]);
       r[q] = (double)sub[q][t + b + 1];
     }
   }
-  const int64_t k = K0 + 4 * t;
-  if (k + 3 < n_out) {
-    *reinterpret_cast<float4*>(y + k) = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
+  const int64_t k = K0 + kHalfOut * t;
+  if (k + kHalfOut - 1 < n_out) {
+#pragma unroll
+    for (int i = 0; i < kHalfOut; i += 4)
+      *reinterpret_cast<float4*>(y + k + i) =
+          make_float4((float)acc[i], (float)acc[i + 1], (float)acc[i + 2], (float)acc[i + 3]);
   } else {
-    for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int i = 0; i < kHalfOut; ++i)
       if (k + i < n_out) y[k + i] = (float)acc[i];
   }
 }
@@ -305,7 +315,7 @@ void launch_resample(const float* x, int64_t n_in, const double* taps, const Res
   if (pl.direct)
     hipLaunchKernelGGL(resample_direct_kernel, per_output, dim3(256), 0, stream, x, n_in, taps, pl, y, n_out);
   else if (mode == 0 && pl.up == 1 && pl.down == 2 && pl.n_taps <= kResTileTaps && (reinterpret_cast<uintptr_t>(y) & 15) == 0)
-    hipLaunchKernelGGL(resample_half_kernel, dim3((unsigned)((n_out + 1023) / 1024)), dim3(256), 0, stream, x, n_in, taps,
+    hipLaunchKernelGGL(resample_half_kernel, dim3((unsigned)((n_out + 256 * kHalfOut - 1) / (256 * kHalfOut))), dim3(256), 0, stream, x, n_in, taps,
                        pl, y, n_out);
   else if (mode != 1 && span <= kResTileX && pl.n_taps <= kResTileTaps)
     hipLaunchKernelGGL(resample_tiled_kernel<true>, per_output, dim3(256), 0, stream, x, n_in, taps, pl, y, n_out);
