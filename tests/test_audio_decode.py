@@ -103,3 +103,22 @@ def test_second_clip_flac_decodes_and_has_the_expected_length():
     g = np.load(os.path.join(GOLDEN, "vocadito_14_expected.npz"))
     y, _ = audio.load(os.path.join(GOLDEN, "vocadito_14.flac"))
     assert y.shape == (int(g["n_samples_22k"][0]),) == (268962,)
+
+
+def test_flac_every_truncation_point_near_the_end_is_an_error(tmp_path):
+    """The decoder reads 64-bit windows while eight bytes are left and byte-wise after that: cutting the stream anywhere
+    in its last 48 bytes is reported (never read past the end, never silence), the whole stream still decodes."""
+    from basic_pitch_amd import audio
+
+    rng = np.random.default_rng(12)
+    pcm = rng.integers(-3000, 3000, size=(4096 + 37, 2)).astype(np.int64)
+    pcm[100:300, 0] = (2000 * np.sin(np.arange(200) * 0.2)).astype(np.int64)
+    data = FW.encode(pcm, 44100, 16, blocksize=1024)
+    p = tmp_path / "t.flac"
+    p.write_bytes(data)
+    y, _ = audio.read_audio(p)
+    assert np.array_equal(y, (pcm / 32768.0).astype(np.float32))
+    for cut in range(1, 49):
+        p.write_bytes(data[: len(data) - cut])
+        with pytest.raises(ValueError):
+            audio.read_audio(p)

@@ -155,10 +155,9 @@ def test_transcribe_files_equals_predict_and_save(tmp_path):
     with wave.open(str(src / "mono22k.wav"), "wb") as w:
         w.setnchannels(1), w.setsampwidth(2), w.setframerate(22050)
         w.writeframes((np.clip(x, -1, 1) * 32767).astype("<i2").tobytes())
-    flac = os.path.join(GOLDEN, "flac")
-    flacs = [f for f in (os.listdir(flac) if os.path.isdir(flac) else []) if f.endswith(".flac")]
-    if flacs:
-        shutil.copy(os.path.join(flac, flacs[0]), src / "f.flac")
+    flacs = [f for f in sorted(os.listdir(GOLDEN)) if f.endswith(".flac")]
+    assert flacs, "the FLAC fixtures live next to the golden WAV"
+    shutil.copy(os.path.join(GOLDEN, flacs[-1]), src / "f.flac")  # vocadito_14.flac: 12 s mono 44.1 kHz
     (src / "broken.wav").write_bytes(b"RIFF\x00\x00\x00\x00WAVEjunk")
     sub = src / "sub"
     sub.mkdir()
