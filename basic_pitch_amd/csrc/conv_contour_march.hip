@@ -42,7 +42,8 @@ constexpr int kCmStrips = 7;         // 32-bin strips: bins 20 .. 243
 #define BP_CM_CHUNKS 4
 #endif
 constexpr int kCmChunks = BP_CM_CHUNKS;  // frame chunks per window (4: 0.211 ms at B = 256; 8: 0.225 — twice the warm-up rows; 1: 0.227 —
-                                         // 7 of a CU's 8 wave slots busy)
+                                         // 7 of a CU's 8 wave slots busy; same-box sweep at the end of round 4: 2 / 3 / 4 / 5 / 6
+                                         // chunks = 0.225 / 0.227 / 0.201 / 0.210 / 0.215 ms)
 constexpr int kCmKS = 6;             // k-steps of 32 taps per frame tap: 192 >= 176 + 1 + 1
 constexpr int kCmCopyU = 30;         // 16-byte units per row copy: one unit of front slack (the staging lanes whose words lie
                                      // in front of a shifted copy write there instead of branching), 28 used, one behind
