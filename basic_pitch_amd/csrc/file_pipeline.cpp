@@ -351,9 +351,11 @@ bool notes_midi(const bp_note_event* ev, int64_t n, const int32_t* bends, bool m
 // Page-locking tens of megabytes costs milliseconds, so a worker's buffers go back to a process-wide pool when it ends and
 // the next bp_transcribe_files call starts from them (at most kPoolMax buffers are kept; the rest are released).
 struct PinnedPool {
-  static constexpr size_t kPoolMax = 192;
+  static constexpr size_t kPoolMax = 192;              // buffers
+  static constexpr size_t kPoolBytes = (size_t)2 << 30;  // and bytes kept between calls (16 workers of 3-minute files: ~1 GB)
   std::mutex mu;
   std::vector<std::pair<void*, size_t>> free_list;
+  size_t pooled_bytes = 0;
   // the smallest pooled buffer of at least n bytes, else a new one
   std::pair<void*, size_t> take(size_t n) {
     {
@@ -364,6 +366,7 @@ struct PinnedPool {
       if (best != free_list.size()) {
         const auto b = free_list[best];
         free_list.erase(free_list.begin() + (long)best);
+        pooled_bytes -= b.second;
         return b;
       }
     }
@@ -374,8 +377,9 @@ struct PinnedPool {
     if (!p) return;
     {
       std::lock_guard<std::mutex> lk(mu);
-      if (free_list.size() < kPoolMax) {
+      if (free_list.size() < kPoolMax && pooled_bytes + cap <= kPoolBytes) {
         free_list.emplace_back(p, cap);
+        pooled_bytes += cap;
         return;
       }
     }
@@ -500,6 +504,7 @@ void bp_files_release_buffers(void) {
   {
     std::lock_guard<std::mutex> lk(g_pinned.mu);
     all.swap(g_pinned.free_list);
+    g_pinned.pooled_bytes = 0;
   }
   for (auto& b : all) bp_host_free(b.first);
 }
