@@ -642,6 +642,51 @@ def test_device_audio_ingest(weights):
     m.close()
 
 
+def test_predict_parameter_sweeps_of_the_reference():
+    """tests/test_inference.py:105-161 of the reference: predict() over its sweeps of onset_threshold, frame_threshold,
+    minimum_note_length, minimum_frequency and maximum_frequency on its clip — its property assertions, and beyond them
+    the same events as the numpy restatement of note_creation.py decodes from the same posteriorgrams."""
+    import warnings
+
+    from basic_pitch_amd import inference as inf
+    from oracle import note_oracle as NO
+
+    wav = os.path.join(GOLDEN, "vocadito_10.wav")
+    model = inf.Model(max_windows=8)
+    base = inf.run_inference(wav, model)
+
+    def check(**kw):
+        out, _, events = inf.predict(wav, model, **kw)
+        for k in base:  # constrain_frequency zeroes columns of the returned maps in place, like the reference
+            if "minimum_frequency" not in kw and "maximum_frequency" not in kw:
+                assert np.array_equal(out[k], base[k]), k
+        okw = dict(onset_thresh=kw.get("onset_threshold", 0.5), frame_thresh=kw.get("frame_threshold", 0.3),
+                   min_note_len=int(np.round(kw.get("minimum_note_length", 127.70) / 1000 * (22050 / 256))),
+                   min_freq=kw.get("minimum_frequency"), max_freq=kw.get("maximum_frequency"))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref, _ = NO.model_output_to_notes({k: v.copy() for k, v in base.items()}, **okw)
+        assert len(events) == len(ref), (kw, len(events), len(ref))
+        for a, b in zip(events, ref):
+            assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and list(a[4]) == list(b[4]), kw
+            assert np.float32(a[3]).tobytes() == np.float32(b[3]).tobytes(), kw
+        return events
+
+    hz_to_midi = lambda f: 12.0 * (np.log2(f) - np.log2(440.0)) + 69.0
+    for v in (0, 0.3, 0.8, 1):
+        check(onset_threshold=v)
+        check(frame_threshold=v)
+    for ms in (10, 100, 1000):
+        ev = check(minimum_note_length=ms)
+        assert all(n[1] - n[0] >= ms / 1000.0 for n in ev)
+    for f in (40, 80, 200, 2000):
+        ev = check(minimum_frequency=f)
+        assert all(n[2] >= np.round(hz_to_midi(f)) for n in ev)
+        ev = check(maximum_frequency=f)
+        assert all(n[2] <= np.round(hz_to_midi(f)) for n in ev)
+    model.close()
+
+
 def test_model_path_is_loaded_once_per_thread():
     """predict(path) with a model PATH (the reference's default call): the loaded model is kept and reused by later calls
     of the same thread, another thread gets its own (a handle is not for two threads at once), same results either way."""

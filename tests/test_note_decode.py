@@ -357,3 +357,24 @@ def test_decoder_fuzz_against_restatement(kind):
         assert nan_a == [i for i, e in enumerate(ref) if np.isnan(e[3])]
         fix = lambda evs: [(e[0], e[1], e[2], np.float32(0) if np.isnan(e[3]) else e[3], e[4]) for e in evs]
         _same_events(fix(ev), fix(ref))
+
+
+def test_drop_overlapping_pitch_bends_known_answer():
+    """The reference's own known-answer vector for drop_overlapping_pitch_bends (tests/test_note_creation.py:21-51 of
+    spotify/basic-pitch v0.4.0): notes that overlap in time lose their pitch bends, the others keep them — through this
+    package's function and, for the notes that keep / lose them, through the native MIDI writer (one instrument: a pitch
+    bend survives only on a note nothing overlaps)."""
+    from basic_pitch_amd import note_creation as NC
+
+    B = [0, 1, 2]
+    events = [(0.0, 0.1, 60, 1.0, None), (2.0, 2.1, 62, 1.0, B), (2.0, 2.1, 64, 1.0, B), (1.0, 1.1, 65, 1.0, B),
+              (1.1, 1.2, 67, 1.0, B), (3.0, 3.2, 69, 1.0, B), (3.1, 3.3, 71, 1.0, B), (5.0, 5.1, 72, 1.0, B),
+              (5.0, 5.2, 74, 1.0, B), (4.0, 4.2, 76, 1.0, B), (4.1, 4.2, 77, 1.0, B)]
+    keep = {65, 67}  # the only notes nothing overlaps
+    want = [(s, e, p, a, (B if p in keep else None)) for s, e, p, a, _ in events]
+    got = NC.drop_overlapping_pitch_bends([tuple(e) for e in events])
+    assert sorted(got, key=lambda n: (n[0], n[1], n[2])) == sorted(want, key=lambda n: (n[0], n[1], n[2]))
+    # the MIDI object: pitch-bend messages only inside the two kept notes
+    midi = NC.note_events_to_midi([tuple(e) for e in events], multiple_pitch_bends=False)
+    bends = [pb.time for inst in midi.instruments for pb in inst.pitch_bends]
+    assert bends and all(1.0 <= t <= 1.2 for t in bends), bends
