@@ -756,6 +756,14 @@ def test_predict_note_events_match_reference_golden(tmp_path):
         assert list(e[4]) == list(g["bend_values"][g["bend_offsets"][i] : g["bend_offsets"][i + 1]]), i
     assert set(model_output) == {"note", "onset", "contour"}
     assert len(midi.instruments) == 1 and len(midi.instruments[0].notes) == 28
+    # the remaining assertions of the reference's test_predict (tests/test_inference.py:50-65): shapes, the supported
+    # pitch range, and the model output's length against the audio's duration through model_frames_to_time
+    from basic_pitch_amd import audio as A, note_creation as NC
+
+    assert model_output["note"].shape == model_output["onset"].shape and isinstance(events, list)
+    assert all(21 <= e[2] <= 21 + 88 for e in events)
+    last_frame_s = NC.model_frames_to_time(model_output["note"].shape[0])[-1]
+    assert abs(last_frame_s - A.get_duration(wav)) <= 2 * (256 / 22050)
     # predict_and_save writes the reference's four artefacts (inference.py:565-602)
     inf.predict_and_save([wav], tmp_path, True, True, True, True)
     stem = tmp_path / "vocadito_10_basic_pitch"
