@@ -346,11 +346,13 @@ template <int ORDER>
 void lpc_restore_n(int64_t* s, const int64_t* coef, int shift, int blocksize) {
   int64_t c[ORDER];
   for (int j = 0; j < ORDER; ++j) c[j] = coef[j];
+  // unsigned arithmetic: a corrupted stream (caught by the frame CRC afterwards) may drive the sums past 63 bits, and
+  // wrapping is defined only there
   for (int i = ORDER; i < blocksize; ++i) {
-    int64_t acc = 0;
+    uint64_t acc = 0;
 #pragma GCC unroll 32
-    for (int j = 0; j < ORDER; ++j) acc += c[j] * s[i - 1 - j];
-    s[i] += acc >> shift;
+    for (int j = 0; j < ORDER; ++j) acc += (uint64_t)c[j] * (uint64_t)s[i - 1 - j];
+    s[i] = (int64_t)((uint64_t)s[i] + (uint64_t)((int64_t)acc >> shift));
   }
 }
 
@@ -394,11 +396,12 @@ bool read_subframe(BitReader& br, int bps, int blocksize, std::vector<int64_t>& 
     for (int i = 0; i < order; ++i) s[i] = br.sbits(bps);
     if (!read_residual(br, order, blocksize, s)) return false;
     for (int i = order; i < blocksize; ++i) {
+      const auto u = [&](int k) { return (uint64_t)s[i - k]; };  // wrapping sums (see lpc_restore_n)
       switch (order) {
-        case 1: s[i] += s[i - 1]; break;
-        case 2: s[i] += 2 * s[i - 1] - s[i - 2]; break;
-        case 3: s[i] += 3 * s[i - 1] - 3 * s[i - 2] + s[i - 3]; break;
-        case 4: s[i] += 4 * s[i - 1] - 6 * s[i - 2] + 4 * s[i - 3] - s[i - 4]; break;
+        case 1: s[i] = (int64_t)((uint64_t)s[i] + u(1)); break;
+        case 2: s[i] = (int64_t)((uint64_t)s[i] + 2 * u(1) - u(2)); break;
+        case 3: s[i] = (int64_t)((uint64_t)s[i] + 3 * u(1) - 3 * u(2) + u(3)); break;
+        case 4: s[i] = (int64_t)((uint64_t)s[i] + 4 * u(1) - 6 * u(2) + 4 * u(3) - u(4)); break;
         default: break;
       }
     }
@@ -428,7 +431,7 @@ bool read_subframe(BitReader& br, int bps, int blocksize, std::vector<int64_t>& 
     return false;
   }
   if (wasted)
-    for (int i = 0; i < blocksize; ++i) s[i] *= (int64_t)1 << wasted;
+    for (int i = 0; i < blocksize; ++i) s[i] = (int64_t)((uint64_t)s[i] << wasted);
   return !br.fail;
 }
 
@@ -508,14 +511,14 @@ int decode(const uint8_t* d, size_t n, float* pcm, int64_t capacity, StreamInfo&
     }
     pos += body + 2;
     if (ch_code == 8) {
-      for (int i = 0; i < blocksize; ++i) ch[1][i] = ch[0][i] - ch[1][i];
+      for (int i = 0; i < blocksize; ++i) ch[1][i] = (int64_t)((uint64_t)ch[0][i] - (uint64_t)ch[1][i]);
     } else if (ch_code == 9) {
-      for (int i = 0; i < blocksize; ++i) ch[0][i] += ch[1][i];
+      for (int i = 0; i < blocksize; ++i) ch[0][i] = (int64_t)((uint64_t)ch[0][i] + (uint64_t)ch[1][i]);
     } else if (ch_code == 10) {
       for (int i = 0; i < blocksize; ++i) {
-        const int64_t side = ch[1][i], mid = ch[0][i] * 2 + (side & 1);
-        ch[0][i] = (mid + side) >> 1;
-        ch[1][i] = (mid - side) >> 1;
+        const uint64_t side = (uint64_t)ch[1][i], mid = ((uint64_t)ch[0][i] << 1) + (side & 1);
+        ch[0][i] = (int64_t)(mid + side) >> 1;
+        ch[1][i] = (int64_t)(mid - side) >> 1;
       }
     }
     int64_t keep = blocksize;

@@ -181,6 +181,12 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
     g_notes_error = "bp_notes_decode: more than 2^24 frames";
     return BP_ERR_INVALID_ARG;
   }
+  if (prm->melodia_trick && prm->frame_threshold < 0.0) {
+    // `while np.max(remaining_energy) > frame_thresh` (note_creation.py:452) never ends below zero: the cells it zeroes
+    // stay above the threshold.  The reference hangs; this reports.
+    g_notes_error = "bp_notes_decode: a negative frame threshold with the melodia trick never terminates (note_creation.py:452)";
+    return BP_ERR_INVALID_ARG;
+  }
   *n_events_out = 0;
   *n_bends_out = 0;
   const int64_t T = n_frames;

@@ -146,6 +146,14 @@ def test_decoder_edge_cases():
     with pytest.raises(ValueError):
         NC.model_output_to_notes({"note": np.zeros((5, 87)), "onset": np.zeros((5, 88), np.float32),
                                   "contour": np.zeros((5, 264), np.float32)}, 0.5, 0.3)
+    # a negative frame threshold with the melodia trick: the reference's `while np.max(...) > frame_thresh` never ends
+    # (zeroed cells stay above it); the decoder reports instead of hanging, and without the trick it decodes
+    neg = {"note": np.full((40, 88), 0.2, np.float32), "onset": np.zeros((40, 88), np.float32),
+           "contour": np.zeros((40, 264), np.float32)}
+    with pytest.raises(ValueError, match="never terminates"):
+        NC.model_output_to_notes({k: v.copy() for k, v in neg.items()}, 0.5, -0.1)
+    _, ev = NC.model_output_to_notes({k: v.copy() for k, v in neg.items()}, 0.5, -0.1, melodia_trick=False)
+    assert ev == []
 
 
 def test_decoder_accepts_what_the_reference_accepts(fixtures):
