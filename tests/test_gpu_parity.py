@@ -661,7 +661,7 @@ def test_predict_parameter_sweeps_of_the_reference():
             if "minimum_frequency" not in kw and "maximum_frequency" not in kw:
                 assert np.array_equal(out[k], base[k]), k
         okw = dict(onset_thresh=kw.get("onset_threshold", 0.5), frame_thresh=kw.get("frame_threshold", 0.3),
-                   min_note_len=int(np.round(kw.get("minimum_note_length", 127.70) / 1000 * (22050 / 256))),
+                   min_note_len=int(np.round(kw.get("minimum_note_length", inf.DEFAULT_MINIMUM_NOTE_LENGTH_MS) / 1000 * (22050 / 256))),
                    min_freq=kw.get("minimum_frequency"), max_freq=kw.get("maximum_frequency"))
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
