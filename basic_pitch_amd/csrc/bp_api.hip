@@ -57,8 +57,9 @@ void launch_pyramid_planes(const float* audio, int64_t audio_stride, uint16_t* p
 int filterbank_planes_partials(bool ext);
 void launch_mm_reduce(const float* scratch, int* mm, int n_windows, int n_partials, hipStream_t stream);
 bool launch_filterbank_planes(const uint16_t* pl, const float* audio, int64_t audio_stride, const void* bfrag,
-                              const float* sqrt_len, float* lp, float* scratch,
+                              const float* bin_consts, float* lp, float* scratch,
                               uint32_t* zp, int n_windows, LogConsts kc, int n_cu, bool ext, hipStream_t stream);
+void filterbank_planes_bin_consts(const float* sqrt_len, int n_bins, LogConsts kc, float* out);
 void launch_zpack(const float* lp, const int* mm, uint32_t* zp, int n_windows, LogConsts kc, int n_bins,
                   hipStream_t s);
 ResamplePlan make_resample_plan(int source_rate, int target_rate, std::vector<double>& taps);
@@ -66,18 +67,24 @@ void launch_downmix(const float* pcm, int64_t n_frames, int channels, float* mon
 void launch_downmix_raw(const void* raw, int format, int64_t n_frames, int channels, float* mono, hipStream_t stream);
 void launch_resample(const float* x, int64_t n_in, const double* taps, const ResamplePlan& pl, float* y,
                      int64_t n_out, int mode, hipStream_t stream);
+#ifdef BP_AB_KERNELS  // conv_contour_direct.hip: the exact 8-channel and the round-2 folded conv1 (A/B builds only)
 void launch_contour_conv1_exact(const uint32_t* zp, const void* wlds, const float* bias, float* c1, int n_windows,
                                 int n_cu, bool weights_have_lo, hipStream_t stream);
 void launch_contour_conv1_folded(const uint32_t* zp, const void* wfold, const float* bias, float* c1, int n_windows,
                                  int n_cu, bool weights_have_lo, hipStream_t stream);
 bool contour_conv1_full();
+#else
+static inline bool contour_conv1_full() { return false; }
+#endif
 bool contour_conv1_use_march();
 void launch_contour_conv1_march(const uint32_t* zp, const void* wfrag, const float* bias, float* c1, int n_windows, int n_cu,
                                 bool weights_have_lo, hipStream_t stream);
 void launch_contour_conv1_rim(const uint32_t* zp, const void* afrag, const float* bias, float* c1, int n_windows, int n_cu,
                               bool weights_have_lo, bool ext, hipStream_t stream);
+#ifdef BP_AB_KERNELS  // onset_march.hip: the 32x32x16 form of the onset march (A/B builds only)
 void launch_onset_march(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, float* onset,
                         int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
+#endif
 void launch_onset_march16(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, float* onset,
                           int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
 void launch_contour_conv1_fold_mx(const uint32_t* zp, const void* a16, const void* amx, const void* ascale,
@@ -88,18 +95,25 @@ void launch_note_march(const float* contour, const void* wfrag, const float* wf3
                        bool weights_have_lo, hipStream_t stream);
 void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, const void* wmx,
                          float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
-// the onset branch: the wave-private march on 16x16x32 by default (round 4); its 32x32x16 form behind BP_ONSET=march32,
-// the workgroup kernel for the fp8-correction mode (it carries the block-scaled products) and behind BP_ONSET=ring (A/B runs)
+// the onset branch: the wave-private march on 16x16x32; the workgroup kernel for the fp8-correction mode (it carries the
+// block-scaled products).  A/B builds only: BP_ONSET=march32 selects the 32x32x16 form of the march, BP_ONSET=ring the
+// workgroup kernel without fp8.
 static void launch_onset(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, const void* wmx,
                          const void* w16, float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream) {
-  static const int kind = [] {
-    const char* e = std::getenv("BP_ONSET");
+  int kind = 0;
+#ifdef BP_AB_KERNELS
+  static const int env_kind = [] {
+    const char* e = ab_env("BP_ONSET");
     return e && std::strcmp(e, "ring") == 0 ? 2 : (e && std::strcmp(e, "march32") == 0 ? 1 : 0);
   }();
+  kind = env_kind;
+  if (kind == 1 && !wmx) {
+    launch_onset_march(zp, note, wfrag, wf32, onset, n_windows, n_cu, weights_have_lo, stream);
+    return;
+  }
+#endif
   if (wmx || kind == 2)
     launch_onset_branch(zp, note, wfrag, wf32, wmx, onset, n_windows, n_cu, weights_have_lo, stream);
-  else if (kind == 1 || !w16)
-    launch_onset_march(zp, note, wfrag, wf32, onset, n_windows, n_cu, weights_have_lo, stream);
   else
     launch_onset_march16(zp, note, w16, wf32, onset, n_windows, n_cu, weights_have_lo, stream);
 }
@@ -205,6 +219,7 @@ struct bp_context {
   float b_contour2 = 0, b_note2 = 0, b_onset2 = 0;
   // device constants
   float *d_lowpass = nullptr, *d_sqrt_len = nullptr, *d_fb_bfrag = nullptr;
+  float* d_pl_bin_k = nullptr;  // cqt_planes.hip filterbank: per-bin eps / s^2, s = sqrt(len) 2^-12
   // fused branches (conv_branch.hip): f16 hi/lo A fragments (raw bytes) + {bias1[32], extra[9], bias2}
   float *d_note_wfrag = nullptr, *d_note_wf32 = nullptr, *d_onset_wfrag = nullptr, *d_onset_wf32 = nullptr,
         *d_onset_wmx = nullptr, *d_onset_w16 = nullptr;
@@ -752,7 +767,7 @@ void pack_filterbank_planes(const Tensor* re, const Tensor* im, std::vector<uint
 }
 
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->planes, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->d_onset_w16, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wmarch, h->d_d1_wrim, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->d_pl_bin_k, h->planes, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->d_onset_w16, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wmarch, h->d_d1_wrim, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->fb_scratch, h->pcm_dev, h->mono_dev, h->res_dev, reinterpret_cast<float*>(h->taps_dev)};
@@ -827,7 +842,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
     launch_pyramid_planes(audio_dev, h->win_len, pl, h->d_pl_tfrag, n, h->n_cu, h->ext, s);
     BP_MARK(BP_STAGE_PYRAMID);
     // with at least half a window per CU the kernel also normalises / BatchNorms / splits its windows (`zp` complete)
-    zp_done = launch_filterbank_planes(pl, audio_dev, h->win_len, h->d_pl_bfrag, h->d_sqrt_len, h->lp, h->fb_scratch,
+    zp_done = launch_filterbank_planes(pl, audio_dev, h->win_len, h->d_pl_bfrag, h->d_pl_bin_k, h->lp, h->fb_scratch,
                                        reinterpret_cast<uint32_t*>(h->zp), n, h->kc, h->n_cu, h->ext, s);
     BP_MARK(BP_STAGE_FILTERBANK);
   }
@@ -862,9 +877,11 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
       const uint32_t* zpp = reinterpret_cast<const uint32_t*>(h->zp) + (int64_t)w0 * kZWin;
       float* c1p = h->c1s + (int64_t)w0 * kC1Win;
       if (contour_conv1_full()) BP_DOM_BEGIN();
+#ifdef BP_AB_KERNELS
       if (contour_conv1_full() || h->rim_exact)
         launch_contour_conv1_exact(zpp, h->d_d1_wlds, h->d_d1_bias, c1p, nw, h->n_cu, wlo, s);
       else
+#endif
         launch_contour_conv1_rim(zpp, h->d_d1_wrim, h->d_d1_bias, c1p, nw, h->n_cu, wlo, h->ext, s);
       if (!contour_conv1_full()) {
         BP_MARK(BP_STAGE_CONTOUR_CONV1_EDGE);
@@ -873,10 +890,12 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
           const char* base = reinterpret_cast<const char*>(h->d_d1_wfold_mx);
           launch_contour_conv1_fold_mx(zpp, base, base + 36 * 64 * 16, base + 36 * 64 * 16 + 18 * 64 * 32, h->d_d1_bias, c1p,
                                        nw, h->n_cu, s);
-        } else if (contour_conv1_use_march()) {
-          launch_contour_conv1_march(zpp, h->d_d1_wmarch, h->d_d1_bias, c1p, nw, h->n_cu, wlo, s);
-        } else {
+#ifdef BP_AB_KERNELS
+        } else if (!contour_conv1_use_march()) {
           launch_contour_conv1_folded(zpp, h->d_d1_wfold, h->d_d1_bias, c1p, nw, h->n_cu, wlo, s);
+#endif
+        } else {
+          launch_contour_conv1_march(zpp, h->d_d1_wmarch, h->d_d1_bias, c1p, nw, h->n_cu, wlo, s);
         }
       }
       BP_DOM_END(BP_STAGE_CONTOUR_CONV1);
@@ -1059,16 +1078,17 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     if ((rc = upload(h, raw_of(frag), &h->d_pl_tfrag))) return fail(rc);
     pack_filterbank_planes(re, im, frag);
     if ((rc = upload(h, raw_of(frag), &h->d_pl_bfrag))) return fail(rc);
-    pack_contour_direct(c1w, frag);
     std::vector<float> w2t(200);
     for (int dt = 0; dt < 5; ++dt)
       for (int dw = 0; dw < 5; ++dw)
         for (int c = 0; c < 8; ++c) w2t[(dt * 5 + dw) * 8 + c] = c2w->data[(c * 5 + dt) * 5 + dw];
-    if ((rc = upload(h, raw_of(frag), &h->d_d1_wlds)) || (rc = upload(h, vec(c1b), &h->d_d1_bias)) ||
-        (rc = upload(h, w2t, &h->d_d2_w)))
-      return fail(rc);
+    if ((rc = upload(h, vec(c1b), &h->d_d1_bias)) || (rc = upload(h, w2t, &h->d_d2_w))) return fail(rc);
+#ifdef BP_AB_KERNELS  // operand tables of the A/B conv1 kernels (conv_contour_direct.hip)
+    pack_contour_direct(c1w, frag);
+    if ((rc = upload(h, raw_of(frag), &h->d_d1_wlds))) return fail(rc);
     pack_contour_folded(c1w, frag);
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wfold))) return fail(rc);
+#endif
     pack_contour_march(c1w, frag);
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wmarch))) return fail(rc);
     if (flags & BP_FLAG_EXT_CQT_44K)
@@ -1082,7 +1102,7 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     // the fp8 planes hold z 2^6 with z = bn_a x + bn_b, x in [0, 1] (NormalizedLog): they must stay below e4m3's 448
     const bool fp8_ok = std::fmax(std::fabs(h->kc.bn_b), std::fabs(h->kc.bn_a + h->kc.bn_b)) * 64.0f <= 440.0f &&
                         (flags & BP_FLAG_FP8_CORRECTIONS) && !(flags & BP_FLAG_F16_CORRECTIONS);
-    if (const char* ec = std::getenv("BP_CONV1");
+    if (const char* ec = ab_env("BP_CONV1");
         !(ec && std::strcmp(ec, "f16") == 0) && fp8_ok && !(flags & BP_FLAG_BF16_WEIGHTS)) {
       std::vector<uint16_t> a16;
       std::vector<uint8_t> mxf;
@@ -1095,13 +1115,13 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       if ((rc = upload(h, raw, &h->d_d1_wfold_mx))) return fail(rc);
       h->fold_mx = true;
     }
-    if (const char* ep = std::getenv("BP_CONTOUR_PARTS")) h->contour_parts = std::atoi(ep) > 8 ? 8 : std::atoi(ep);
+    if (const char* ep = ab_env("BP_CONTOUR_PARTS")) h->contour_parts = std::atoi(ep) > 8 ? 8 : std::atoi(ep);
     {
-      const char* er = std::getenv("BP_RIM");  // "exact": the round-1 rim kernel on the 8-channel form (A/B runs)
+      const char* er = ab_env("BP_RIM");  // "exact": the round-1 rim kernel on the 8-channel form (A/B runs)
       // (the extended 345-bin CQT has its own GEMM table since round 4: 160 z bins per side)
       h->rim_exact = er && std::strcmp(er, "exact") == 0;
     }
-    if (const char* es = std::getenv("BP_RESAMPLE"))  // A/B runs: the resampler's simpler kernels (bit-identical results)
+    if (const char* es = ab_env("BP_RESAMPLE"))  // A/B runs: the resampler's simpler kernels (bit-identical results)
       h->resample_mode = std::strcmp(es, "plain") == 0 ? 1 : std::strcmp(es, "tiled") == 0 ? 2 : 0;
     for (int br = 0; br < 2; ++br) {
       pack_branch(br ? 13 : 4, br ? o1w : n1w, br ? o2w : n2w, br == 1, frag);
@@ -1120,7 +1140,7 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       if ((rc = upload(h, raw_of(frag), &h->d_onset_w16))) return fail(rc);
     }
     // onset conv1: fp8 corrections under BP_FLAG_FP8_CORRECTIONS like the folded contour conv1 (BP_ONSET=f16: not this layer)
-    if (const char* eo = std::getenv("BP_ONSET"); !(eo && std::strcmp(eo, "f16") == 0) && fp8_ok && !(flags & BP_FLAG_BF16_WEIGHTS)) {
+    if (const char* eo = ab_env("BP_ONSET"); !(eo && std::strcmp(eo, "f16") == 0) && fp8_ok && !(flags & BP_FLAG_BF16_WEIGHTS)) {
       std::vector<uint8_t> mxf;
       std::vector<int32_t> mxs;
       pack_onset_mx(o1w, mxf, mxs);
@@ -1147,6 +1167,11 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
         return fail(BP_ERR_BAD_WEIGHTS);
       }
     sqrt_len = ext;
+  }
+  {
+    std::vector<float> bin_k(sqrt_len.size());
+    filterbank_planes_bin_consts(sqrt_len.data(), (int)sqrt_len.size(), h->kc, bin_k.data());
+    if ((rc = upload(h, bin_k, &h->d_pl_bin_k))) return fail(rc);
   }
   if ((rc = upload(h, vec(lowp), &h->d_lowpass)) || (rc = upload(h, sqrt_len, &h->d_sqrt_len)) ||
       (rc = upload(h, fb, &h->d_fb_bfrag)) || (rc = upload(h, c1f, &h->d_c1_bfrag)) ||
@@ -1740,7 +1765,7 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
             const int64_t off = h->ext ? ((k == 1) ? 0 : kAudioN + pyr_off(k - 1)) : pyr_off(k);
             launch_planes_split(bf->pyr + off, h->pyr_stride, k, pl, n, h->ext, s);
           }
-          (void)launch_filterbank_planes(pl, bf->audio, h->win_len, h->d_pl_bfrag, h->d_sqrt_len, bf->lp, h->fb_scratch, nullptr, n, h->kc, h->n_cu,
+          (void)launch_filterbank_planes(pl, bf->audio, h->win_len, h->d_pl_bfrag, h->d_pl_bin_k, bf->lp, h->fb_scratch, nullptr, n, h->kc, h->n_cu,
                                          h->ext, s);
           launch_mm_reduce(h->fb_scratch, bf->mm, n, filterbank_planes_partials(h->ext), s);
         }
@@ -1778,18 +1803,22 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
           h->err = "bp_run_stage: contour needs n_windows <= max_windows (internal c1 buffer)";
           return BP_ERR_INVALID_ARG;
         } else {
+#ifdef BP_AB_KERNELS
           if (contour_conv1_full() || h->rim_exact)
             launch_contour_conv1_exact(bf->zp, h->d_d1_wlds, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
           else
+#endif
             launch_contour_conv1_rim(bf->zp, h->d_d1_wrim, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, h->ext, s);
           if (h->fold_mx && wlo) {
             const char* base = reinterpret_cast<const char*>(h->d_d1_wfold_mx);
             launch_contour_conv1_fold_mx(bf->zp, base, base + 36 * 64 * 16, base + 36 * 64 * 16 + 18 * 64 * 32, h->d_d1_bias,
                                          h->c1s, n, h->n_cu, s);
-          } else if (contour_conv1_use_march()) {
-            launch_contour_conv1_march(bf->zp, h->d_d1_wmarch, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
-          } else {
+#ifdef BP_AB_KERNELS
+          } else if (!contour_conv1_use_march()) {
             launch_contour_conv1_folded(bf->zp, h->d_d1_wfold, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
+#endif
+          } else {
+            launch_contour_conv1_march(bf->zp, h->d_d1_wmarch, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
           }
           launch_contour_conv2(h->c1s, h->d_d2_w, h->b_contour2, bf->contour, n, h->n_cu, s);
         }
@@ -1812,7 +1841,7 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
     return BP_ERR_INVALID_ARG;
   }
   BP_HIP(hipGetLastError());
-  static const bool nosync = std::getenv("BP_STAGE_NOSYNC") != nullptr;  // tools only: overlap experiments
+  static const bool nosync = ab_env("BP_STAGE_NOSYNC") != nullptr;  // tools only: overlap experiments
   if (!nosync) BP_HIP(hipStreamSynchronize(s));
   return BP_OK;
 }

@@ -4,7 +4,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 namespace bp {
+
+// A/B switches.  The product library reads no behaviour switch from the environment: the env-selected variants of a
+// kernel (BP_CONV1, BP_ONSET, BP_RIM, BP_RESAMPLE, BP_CONTOUR_PARTS, BP_BRANCH_PROF, BP_STAGE_NOSYNC) and the kernels only
+// they can reach exist in builds with -DBP_AB_KERNELS (basic_pitch_amd/build.py: build_library(ab=True), the library
+// the comparison tests and tools load through BASIC_PITCH_AMD_LIB); in the default build this returns null.
+inline const char* ab_env(const char* name) {
+#ifdef BP_AB_KERNELS
+  return std::getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 constexpr int kAudioN = 43844;   // constants.py:47
 constexpr int kFrames = 172;     // constants.py:44
@@ -192,6 +207,25 @@ __device__ __forceinline__ float norm_bn(float lp, float mn, float range, const 
   float off = lp - mn;
   float nrm = (range == 0.0f) ? 0.0f : off / range;
   return __fadd_rn(__fmul_rn(nrm, k.bn_a), k.bn_b);  // Mul then Add in the frozen graph: no FMA contraction
+}
+
+// The same map as the default path evaluates it (round 5): the affine part folded into one scale per window,
+// z = (lp - min) * (bn_a / range) + bn_b — one subtraction and one FMA per element instead of sub, IEEE division, mul, add
+// (the division alone is ~10 instructions).  <= 1.5 ulp of z from the sequence above; every kernel of the default path
+// (the fused filterbank's normalise phase, zpack_kernel) uses THESE two functions, so a window's words do not depend on
+// which of them produced it.  range == 0 (a silent window): scale 0, z = bn_b, as divide_no_nan gives.
+__device__ __forceinline__ float norm_scale(float mn, float mx, const LogConsts& k) {
+  const float range = mx - mn;
+  return range == 0.0f ? 0.0f : __fdiv_rn(k.bn_a, range);
+}
+__device__ __forceinline__ float norm_bn_k(float lp, float mn, float nk, float bn_b) {
+  float z = __fmaf_rn(__fsub_rn(lp, mn), nk, bn_b);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // z is an fp32 value in a register before anything converts it: without this the compiler may fold the f16 conversion
+  // of the split into the FMA (v_fma_mixlo_f16) in one kernel and not in another
+  asm volatile("" : "+v"(z));
+#endif
+  return z;
 }
 
 // zero-phase rational polyphase resampler (audio_ingest.hip), libsoxr SOXR_HQ design at the rate source * up

@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ lp
     mn = ord2f(mm[2 * b]);
     mx = ord2f(mm[2 * b + 1]);
   }
-  const float range = mx - mn;
+  const float nk = norm_scale(mn, mx, kc);
   const float* lpb = lp + (int64_t)b * kFrames * n_bins;
   uint32_t* zb = zp + (int64_t)b * kZWin;
   // the whole padded window is written every time (pad frames and pad words are zero: the zero padding of the
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ lp
       for (int e = 0; e < 4; ++e) {
         const int g = g0 + e;
         if (g >= 0 && g < n_bins) {
-          const float z = norm_bn(lpb[t * n_bins + g], mn, range, kc);
+          const float z = norm_bn_k(lpb[t * n_bins + g], mn, nk, kc.bn_b);
           _Float16 hi, lo;
           split_f16(z, hi, lo);
           u[e] = (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
@@ -642,8 +642,9 @@ template <class Br>
 static void launch_branch(const BranchParams& p, int n_cu, bool weights_have_lo, hipStream_t stream) {
   const int items = p.n_windows * Br::CHUNKS;
   const int grid = items < Br::WGS * n_cu ? items : Br::WGS * n_cu;
-  static const bool prof = getenv("BP_BRANCH_PROF") != nullptr;
-  if (prof) {  // tools only: phase profile of block 0 to stderr
+#ifdef BP_AB_KERNELS  // tools only (A/B builds): phase profile of block 0 to stderr
+  static const bool prof = ab_env("BP_BRANCH_PROF") != nullptr;
+  if (prof) {
     BranchParams q = p;
     unsigned long long hbuf[24];
     int resident = 0;
@@ -665,16 +666,19 @@ static void launch_branch(const BranchParams& p, int n_cu, bool weights_have_lo,
     }
     return;
   }
+#endif
   if constexpr (Br::kOnset) {
     if (weights_have_lo && p.wmx) {
       hipLaunchKernelGGL((branch_kernel<Br, true, false, true>), dim3(grid), dim3(kBrThreads), 0, stream, p);
       return;
     }
   }
+#ifdef BP_AB_KERNELS  // the workgroup kernel without the fp8 products: only BP_ONSET=ring reaches it (A/B builds)
   if (weights_have_lo)
     hipLaunchKernelGGL((branch_kernel<Br, true>), dim3(grid), dim3(kBrThreads), 0, stream, p);
   else
     hipLaunchKernelGGL((branch_kernel<Br, false>), dim3(grid), dim3(kBrThreads), 0, stream, p);
+#endif
 }
 
 // wmx: the fp8 correction fragments (pack_onset_mx) or null for the three-product f16 kernel

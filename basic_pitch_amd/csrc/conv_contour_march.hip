@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * kCmWaves, 2) void contour_conv1_march_kernel(C
 // folded conv1, interior bins: the wave-private march (default) or the round-2 kernel (BP_CONV1=rounds)
 bool contour_conv1_use_march() {
   static const bool rounds = [] {
-    const char* e = getenv("BP_CONV1");
+    const char* e = ab_env("BP_CONV1");
     return e && strcmp(e, "rounds") == 0;
   }();
   return !rounds;

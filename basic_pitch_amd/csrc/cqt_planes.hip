@@ -24,6 +24,7 @@
 //
 // Arithmetic is unchanged: x = hi + lo 2^-11 (rn), products hi*hi + (lo*hi + hi*lo) 2^-11 on v_mfma_f32_16x16x32_f16,
 // fp32 accumulation, taps pre-scaled by 2^10 (decimator) / 2^12 (CQT kernels) — see cqt_mfma.hip's header.
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -76,25 +77,51 @@ int64_t planes_elements_per_window(bool ext) { return 2 * make_pl_geo(ext).strid
 
 // Level 0's "edge rows" (fp32, where the level-0 planes used to be: element 0 of the window's hi plane).  Frame f's
 // 256-sample window reads samples f hop - 128 .. f hop + 127 with reflection at both ends (nnaudio.py:229, 300-301).  The
-// filterbank takes a frame straight from the audio when its taps 16..239 lie inside the signal; row 0 holds frame 0's
-// window, rows 1.. those of the frames from pl_edge_frame() to 175 (the 11th tile's padding frames included: finite
-// values nobody's result depends on), all with the reflection applied.
+// filterbank takes the frames of its interior tiles (frames 16 .. 159) straight from the audio; the two tiles that touch
+// the ends of the signal — tile 0 (frame 0 is mirrored at the front) and tile 10 (frames 171 .. 175 run past the end; the
+// 11th tile's padding frames included: finite values nobody's result depends on) — read these 32 rows instead: rows
+// 0 .. 15 = the windows of frames 0 .. 15, rows 16 .. 31 = those of frames 160 .. 175, reflection applied, row pitch =
+// hop0 floats (so that a lane's byte offset into a row block equals its offset into the audio: round 5 — every A fragment
+// of a task is then `uniform base + one per-lane 32-bit offset`, the addressing form that costs no vector arithmetic).
 __host__ __device__ inline int pl_edge_frame(int L0, int hop0) { return (L0 - 111 + hop0 - 1) / hop0; }  // first f with f hop + 111 >= L0
-constexpr int kPlEdgeRowsMax = 1 + 8;
+constexpr int kPlEdgeRows = 32;
 
+__device__ __forceinline__ float4 pl_edge_row_load(const float* __restrict__ x, int L, int f, int hop0, int lane) {
+  const int i0 = f * hop0 - kPlPad + 4 * lane;  // this lane's four samples of frame f's window
+  if (i0 >= 0 && i0 + 3 < L) return *reinterpret_cast<const float4*>(x + i0);  // dword alignment is enough for global vector loads
+  float e[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int i = i0 + k;
+    i = i < 0 ? -i : i;                     // reflection without repeating the edge sample
+    i = i >= L ? 2 * (L - 1) - i : i;
+    const bool ok = i >= 0 && i < L;        // beyond one reflection: the padding frames' slack
+    e[k] = ok ? x[ok ? i : 0] : 0.0f;
+  }
+  return float4{e[0], e[1], e[2], e[3]};
+}
+
+// rows r and 16 + r (r = 0 .. 15) by one wave: both loads in flight, then both stores.  (A wave that wrote all 16 rows of
+// a block one after the other chained 16 memory round trips in front of its own tiles: measured + 4 us on the pyramid.)
+__device__ __forceinline__ void pl_write_edge_row_pair(const float* __restrict__ x, int L, float* __restrict__ rows, int hop0,
+                                                       int r, int lane) {
+  const float4 a = pl_edge_row_load(x, L, r, hop0, lane);
+  const float4 b = pl_edge_row_load(x, L, (kPlTilesPerLevel - 1) * 16 + r, hop0, lane);
+  *reinterpret_cast<float4*>(rows + r * hop0 + 4 * lane) = a;
+  *reinterpret_cast<float4*>(rows + (16 + r) * hop0 + 4 * lane) = b;
+}
+
+// one block of 16 rows (head: frames 0 .. 15, else frames 160 .. 175), four rows in flight at a time
 __device__ __forceinline__ void pl_write_edge_rows(const float* __restrict__ x, int L, float* __restrict__ rows, int hop0,
                                                    bool head, int lane) {
-  const int f_edge = pl_edge_frame(L, hop0);
-  const int r0 = head ? 0 : 1, r1 = head ? 1 : 1 + kPlTilesPerLevel * 16 - f_edge;
-  for (int r = r0; r < r1; ++r) {
-    const int f = r == 0 ? 0 : f_edge + r - 1;
-    for (int j = lane; j < 256; j += 64) {
-      int i = f * hop0 + j - kPlPad;
-      i = i < 0 ? -i : i;                     // reflection without repeating the edge sample
-      i = i >= L ? 2 * (L - 1) - i : i;
-      const bool ok = i >= 0 && i < L;        // beyond one reflection: the padding frames' slack
-      rows[r * 256 + j] = ok ? x[ok ? i : 0] : 0.0f;
-    }
+  const int r0 = head ? 0 : 16, f0 = head ? 0 : (kPlTilesPerLevel - 1) * 16;
+#pragma unroll 1
+  for (int r = 0; r < 16; r += 4) {
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = pl_edge_row_load(x, L, f0 + r + k, hop0, lane);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(rows + (r0 + r + k) * hop0 + 4 * lane) = v[k];
   }
 }
 
@@ -106,6 +133,25 @@ __global__ __launch_bounds__(64) void pl_edge_rows_kernel(const float* __restric
   pl_write_edge_rows(x, L, rows, hop0, true, threadIdx.x);
   pl_write_edge_rows(x, L, rows, hop0, false, threadIdx.x);
 }
+
+// tools only (tools/build_variant.sh prof cqt_planes.hip -DPL_PROF; tools/experiments/cqt_prof.py): phase stamps of two
+// workgroups of the per-window kernels, [kernel 0 = pyramid, 1 = filterbank][workgroup slot][wave][stamp]
+#ifdef PL_PROF
+__device__ unsigned long long g_pl_prof[2][2][16][16];
+#define PL_STAMP(kern, i)                                                                                   \
+  do {                                                                                                      \
+    if ((blockIdx.x == 0 || blockIdx.x == 131) && (threadIdx.x & 63) == 0)                                  \
+      g_pl_prof[kern][blockIdx.x ? 1 : 0][threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime();             \
+  } while (0)
+#define PL_STAMP_RT(kern, i)                                                                                \
+  do {                                                                                                      \
+    if ((blockIdx.x == 0 || blockIdx.x == 131) && (threadIdx.x & 63) == 0)                                  \
+      g_pl_prof[kern][blockIdx.x ? 1 : 0][threadIdx.x >> 6][i] = wall_clock64();                           \
+  } while (0)
+#else
+#define PL_STAMP(kern, i) ((void)0)
+#define PL_STAMP_RT(kern, i) ((void)0)
+#endif
 
 #define BP_PL_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0)
 
@@ -218,27 +264,19 @@ __device__ __forceinline__ PlRaw<F32IN> pl_fetch_rows(const float* __restrict__ 
   const int m = lane & 15, kg = lane >> 4;
   const int base = 2 * kPlTileOut * tile + 32 * m + 8 * kg;
   PlRaw<F32IN> r;
-#if defined(PL_ABLATE) && (PL_ABLATE & 4)  // tools only: no input loads (timing)
   if constexpr (F32IN) {
-    r.a0 = r.a1 = r.b0 = r.b1 = float4{1.f * tile, 2.f, 3.f * lane, 4.f};
-    return r;
-  }
-#endif
-  if constexpr (F32IN) {
+    // zero outside [0, L_in) (nnaudio.py:269-279).  A row's two halves start at multiples of 4 and both window lengths are
+    // multiples of 4: a half is either all signal or all padding, so the edge tiles need two predicated 16-byte loads
+    // per row, not eight predicated samples.
+    static_assert(kAudioN % 4 == 0 && kAudioNExt % 4 == 0 && kPlPad % 4 == 0, "no half straddles an end of the signal");
     auto row = [&](int g0, float4& lo4, float4& hi4) {
       if (!pl_tile_is_edge(tile, L_in)) {
         lo4 = *reinterpret_cast<const float4*>(x + g0);  // dword alignment is enough for global vector loads
         hi4 = *reinterpret_cast<const float4*>(x + g0 + 4);
       } else {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int g = g0 + e;
-          const bool ok = g >= 0 && g < L_in;
-          v[e] = ok ? x[ok ? g : 0] : 0.0f;
-        }
-        lo4 = float4{v[0], v[1], v[2], v[3]};
-        hi4 = float4{v[4], v[5], v[6], v[7]};
+        lo4 = hi4 = float4{0.f, 0.f, 0.f, 0.f};
+        if (g0 >= 0 && g0 + 3 < L_in) lo4 = *reinterpret_cast<const float4*>(x + g0);
+        if (g0 + 4 >= 0 && g0 + 7 < L_in) hi4 = *reinterpret_cast<const float4*>(x + g0 + 4);
       }
     };
     row(base - kPlPad, r.a0, r.a1);
@@ -263,100 +301,15 @@ __device__ __forceinline__ void pl_split8(const float4& a, const float4& c, uint
   split_f16x2_rn(f32x2{c.z, c.w}, h.w, l.w);
 }
 
-// F32IN = false: the input level is a plane region (`in_hi`, lo plane `stride` elements behind it).
-// F32IN = true:  the input is the fp32 signal `x` (level 0): rows are split in registers, and the tile also WRITES the
-//                level-0 planes (`in_hi` is then the level-0 region to fill): its sixteen own rows are exactly the 512
-//                elements [2 o0, 2 o0 + 512); tile 0 / the last tile add the reflect padding of level 0.
-// MIRROR: the outputs also go to a second image of the output level (`mir_hi` = its sample 0, lo plane `mir_stride`
-//         elements behind; no padding there): the per-window kernel keeps the levels it reads again in LDS.
-// PF:     k-steps of LDS fragment reads kept ahead of the matrix instructions (0 = the compiler's own order, which reads
-//         each fragment right in front of its use and waits: fine where four waves per SIMD and a prefetched next item
-//         cover it, 1.5 k cycles per tile where a tile's latency is the critical path — the per-window kernel).
-template <bool F32IN, bool MIRROR = false, int PF = 0>
-__device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, const float* __restrict__ x,
-                                            uint16_t* __restrict__ in_hi, int64_t stride, int L_in,
-                                            uint16_t* __restrict__ out_hi, int L_out, int tile, int n_tiles,
-                                            const uint4 (&th)[kPlDmSteps], const uint4* __restrict__ tlo,
-                                            uint4* __restrict__ rows, int lane, uint16_t* mir_hi = nullptr,
-                                            int mir_stride = 0, int hop0 = 0) {
-  // keep the lo fragments in LDS: without an opaque offset the compiler hoists the 9 item-invariant reads into registers
-  asm volatile("" : "+v"(lane));
+// The four consecutive outputs a lane holds after a tile's matrix work (D: column m = lane & 15, rows u = 4 kg + r):
+// tap scale off, split, one 8-byte store per plane into the output level's planes (HBM, for the filterbank), optionally a
+// second copy into an LDS image of the level (`mir_hi` = its sample 0, lo plane `mir_stride` elements behind; no padding
+// there; null = none), and — the tiles that hold samples 1..128 and L-129..L-2 — the level's reflect padding
+// (nnaudio.py:300-301).  Shared by every decimator kernel: a level's bits do not depend on which kernel made it.
+__device__ __forceinline__ void pl_tile_store(const f32x4& hh, const f32x4& xx, uint16_t* __restrict__ out_hi, int64_t stride,
+                                              int L_out, int tile, int lane, uint16_t* mir_hi, int mir_stride) {
   const int m = lane & 15, kg = lane >> 4;
   const int o0 = kPlTileOut * tile;
-  const int base = 2 * o0 + 32 * m + 8 * kg;  // region element of this lane's own row
-  uint4 ah, al, bh, bl;
-  if constexpr (F32IN) {
-    pl_split8(raw.a0, raw.a1, ah, al);
-    pl_split8(raw.b0, raw.b1, bh, bl);
-  } else {
-    ah = raw.ah, al = raw.al, bh = raw.bh, bl = raw.bl;
-    if (pl_tile_is_edge(tile, L_in)) {  // the planes carry reflect padding where the decimator wants zeros
-      ah = pl_zero_outside(ah, base, L_in);
-      al = pl_zero_outside(al, base, L_in);
-      bh = pl_zero_outside(bh, base + 256, L_in);
-      bl = pl_zero_outside(bl, base + 256, L_in);
-    }
-  }
-  uint4* rh = rows + m * kPlRowU + kg;
-  uint4* rl = rh + 24 * kPlRowU;
-  rh[0] = ah;
-  rl[0] = al;
-  if (m >= 8) {
-    rh[8 * kPlRowU] = bh;
-    rl[8 * kPlRowU] = bl;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  if constexpr (F32IN) {
-    // level 0 has no planes since round 4 (the filterbank splits its level-0 samples itself, straight from the fp32
-    // audio); what it cannot read from the audio are the windows that are mirrored at the ends of the signal: the first
-    // tile of a window leaves frame 0's reflect-padded window, the last tile those of the frames from `edge_frame` on, as
-    // fp32 rows where the level-0 planes used to be
-    if (tile == 0 || tile == n_tiles - 1) pl_write_edge_rows(x, L_in, reinterpret_cast<float*>(in_hi), hop0, tile == 0, lane);
-  }
-
-  f32x4 hh = {0.f, 0.f, 0.f, 0.f}, xx = hh;
-  const uint4* tl = tlo + lane;
-#if defined(PL_ABLATE) && (PL_ABLATE & 1)  // tools only: no matrix work (timing; garbage results)
-  hh[0] = __builtin_bit_cast(float, rh[0].x);
-#else
-  if constexpr (PF == 0) {
-#pragma unroll
-    for (int s = 0; s < kPlDmSteps; ++s) {
-      const uint4 xh = rh[s * kPlRowU], xl = rl[s * kPlRowU];
-      const uint4 tls = tl[s * 64];
-      hh = BP_PL_MFMA16(th[s], xh, hh);
-      xx = BP_PL_MFMA16(tls, xh, xx);
-      xx = BP_PL_MFMA16(th[s], xl, xx);
-    }
-  } else {
-    uint4 xh[PF + 1], xl[PF + 1], tls[PF + 1];
-    auto rd = [&](int s) {
-      xh[s % (PF + 1)] = rh[s * kPlRowU];
-      xl[s % (PF + 1)] = rl[s * kPlRowU];
-      tls[s % (PF + 1)] = tl[s * 64];
-    };
-#pragma unroll
-    for (int s = 0; s < PF; ++s) rd(s);
-#pragma unroll
-    for (int s = 0; s < kPlDmSteps; ++s) {
-      if (s + PF < kPlDmSteps) rd(s + PF);
-      __builtin_amdgcn_sched_barrier(0);
-      hh = BP_PL_MFMA16(th[s], xh[s % (PF + 1)], hh);
-      xx = BP_PL_MFMA16(tls[s % (PF + 1)], xh[s % (PF + 1)], xx);
-      xx = BP_PL_MFMA16(th[s], xl[s % (PF + 1)], xx);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-#endif
-  // the rows are read: the next tile of this wave may overwrite them
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  // D: column m = lane & 15, rows u = 4 kg + r: four consecutive outputs
   const int n0 = o0 + 16 * m + 4 * kg;
   float v[4];
 #pragma unroll
@@ -365,28 +318,20 @@ __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, const float
   split_f16x2_rn(f32x2{v[0], v[1]}, h2.x, l2.x);
   split_f16x2_rn(f32x2{v[2], v[3]}, h2.y, l2.y);
   uint16_t* oh = out_hi + kPlPad + n0;
-#if defined(PL_ABLATE) && (PL_ABLATE & 2)  // tools only: no output stores unless impossible (timing)
-  if (n0 + 3 < L_out && h2.x == 0x12345678u) {
-#else
   if (n0 + 3 < L_out) {
-#endif
     *reinterpret_cast<uint2*>(oh) = h2;
     *reinterpret_cast<uint2*>(oh + stride) = l2;
   }
-  if constexpr (MIRROR) {
-    if (mir_hi != nullptr) {  // wave-uniform
-      uint16_t* mh = mir_hi + n0;
-      if (n0 + 3 < L_out) {
-        *reinterpret_cast<uint2*>(mh) = h2;
-        *reinterpret_cast<uint2*>(mh + mir_stride) = l2;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n0 + r < L_out) {
-            mh[r] = (uint16_t)((r < 2 ? h2.x : h2.y) >> (16 * (r & 1)));
-            mh[mir_stride + r] = (uint16_t)((r < 2 ? l2.x : l2.y) >> (16 * (r & 1)));
-          }
-      }
+  if (mir_hi != nullptr) {  // wave-uniform
+    uint16_t* mh = mir_hi + n0;
+    if (n0 + 3 < L_out) {
+      *reinterpret_cast<uint2*>(mh) = h2;
+      *reinterpret_cast<uint2*>(mh + mir_stride) = l2;
+    } else if (n0 < L_out) {  // the level's last, partial group of four: zeros behind the last sample (images are sized in fours)
+      const int nv = L_out - n0;  // 1 .. 3 valid
+      const uint32_t m0 = nv > 1 ? 0xffffffffu : 0xffffu, m1 = nv > 2 ? 0xffffu : 0u;
+      *reinterpret_cast<uint2*>(mh) = uint2{h2.x & m0, h2.y & m1};
+      *reinterpret_cast<uint2*>(mh + mir_stride) = uint2{l2.x & m0, l2.y & m1};
     }
   }
   // the level's last (partial) group of four, and the reflect padding: the tiles that hold samples 1..128 and
@@ -416,6 +361,127 @@ __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, const float
   }
 }
 
+// One tile through a wave-private row image in LDS (the input comes from global memory: the fp32 signal or a level's planes).
+// F32IN = false: the input level is a plane region (`raw` holds the lane's units of its hi / lo planes).
+// F32IN = true:  the input is the fp32 signal (level 0): rows are split in registers.  (Level 0 has no planes: what the
+//                filterbank cannot read from the audio — the windows mirrored at the ends of the signal — are the edge
+//                rows, written by the kernels around this routine.)
+// MIRROR: see pl_tile_store.
+// PF:     k-steps of LDS fragment reads kept ahead of the matrix instructions (0 = the compiler's own order, which reads
+//         each fragment right in front of its use and waits: fine where four waves per SIMD and a prefetched next item
+//         cover it, 1.5 k cycles per tile where a tile's latency is the critical path — the per-window kernel).
+template <bool F32IN, bool MIRROR = false, int PF = 0>
+__device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, int64_t stride, int L_in, uint16_t* __restrict__ out_hi,
+                                            int L_out, int tile, const uint4 (&th)[kPlDmSteps], const uint4* __restrict__ tlo,
+                                            uint4* __restrict__ rows, int lane, uint16_t* mir_hi = nullptr, int mir_stride = 0) {
+  // keep the lo fragments in LDS: without an opaque offset the compiler hoists the 9 item-invariant reads into registers
+  asm volatile("" : "+v"(lane));
+  const int m = lane & 15, kg = lane >> 4;
+  const int base = 2 * kPlTileOut * tile + 32 * m + 8 * kg;  // region element of this lane's own row
+  uint4 ah, al, bh, bl;
+  if constexpr (F32IN) {
+    pl_split8(raw.a0, raw.a1, ah, al);
+    pl_split8(raw.b0, raw.b1, bh, bl);
+  } else {
+    ah = raw.ah, al = raw.al, bh = raw.bh, bl = raw.bl;
+    if (pl_tile_is_edge(tile, L_in)) {  // the planes carry reflect padding where the decimator wants zeros
+      ah = pl_zero_outside(ah, base, L_in);
+      al = pl_zero_outside(al, base, L_in);
+      bh = pl_zero_outside(bh, base + 256, L_in);
+      bl = pl_zero_outside(bl, base + 256, L_in);
+    }
+  }
+  uint4* rh = rows + m * kPlRowU + kg;
+  uint4* rl = rh + 24 * kPlRowU;
+  rh[0] = ah;
+  rl[0] = al;
+  if (m >= 8) {
+    rh[8 * kPlRowU] = bh;
+    rl[8 * kPlRowU] = bl;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // three independent accumulator chains (hi hi, lo hi, hi lo: nine dependent matrix instructions each) — round 5: with
+  // the two correction products on ONE accumulator the 18-deep dependent chain was the latency of a deep level's tile
+  f32x4 hh = {0.f, 0.f, 0.f, 0.f}, xa = hh, xb = hh;
+  const uint4* tl = tlo + lane;
+  if constexpr (PF == 0) {
+#pragma unroll
+    for (int s = 0; s < kPlDmSteps; ++s) {
+      const uint4 xh = rh[s * kPlRowU], xl = rl[s * kPlRowU];
+      const uint4 tls = tl[s * 64];
+      hh = BP_PL_MFMA16(th[s], xh, hh);
+      xa = BP_PL_MFMA16(tls, xh, xa);
+      xb = BP_PL_MFMA16(th[s], xl, xb);
+    }
+  } else {
+    uint4 xh[PF + 1], xl[PF + 1], tls[PF + 1];
+    auto rd = [&](int s) {
+      xh[s % (PF + 1)] = rh[s * kPlRowU];
+      xl[s % (PF + 1)] = rl[s * kPlRowU];
+      tls[s % (PF + 1)] = tl[s * 64];
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) rd(s);
+#pragma unroll
+    for (int s = 0; s < kPlDmSteps; ++s) {
+      if (s + PF < kPlDmSteps) rd(s + PF);
+      __builtin_amdgcn_sched_barrier(0);
+      hh = BP_PL_MFMA16(th[s], xh[s % (PF + 1)], hh);
+      xa = BP_PL_MFMA16(tls[s % (PF + 1)], xh[s % (PF + 1)], xa);
+      xb = BP_PL_MFMA16(th[s], xl[s % (PF + 1)], xb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // the rows are read: the next tile of this wave may overwrite them
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  pl_tile_store(hh, xa + xb, out_hi, stride, L_out, tile, lane, MIRROR ? mir_hi : nullptr, mir_stride);
+}
+
+// One tile whose input level is resident in LDS as contiguous hi / lo planes (round 5): the B fragment of lane (m, kg) at
+// k-step s — the 8 elements from 2 o0 + 32 (m + s) + 8 kg of the region that starts kPlPad elements in front of the level's
+// sample 0 — is ONE ds_read_b128 straight from the plane: no row image, no copy, no wavefront fence (the level was complete
+// at the last workgroup barrier).  `in_hi` = LDS address of that region's element 0, lo plane `in_stride` elements behind.
+// The region is ZERO beside the samples — kPlPad elements in front, kPwTail behind (the reference zero-pads the decimator's
+// input, nnaudio.py:269-279) — so no tile masks anything: with the masks in registers (18 fragments x ~26 operations in
+// an edge tile, and below level 4 every tile is one) a one-tile level took 2.2 us, half of it the masks.
+// At the natural 64-byte row pitch lanes m and m + 4 share banks (2-way: 8 instead of 4 LDS cycles per read, ~70 cycles a
+// tile).  The same matrix instructions in the same order on the same operands as pl_dec_tile: the same bits.
+template <int PF>
+__device__ __forceinline__ void pl_dec_tile_lds(const uint16_t* in_hi, int in_stride, uint16_t* __restrict__ out_hi,
+                                                int64_t stride, int L_out, int tile, const uint4 (&th)[kPlDmSteps],
+                                                const uint4* __restrict__ tlo, int lane, uint16_t* mir_hi, int mir_stride) {
+  asm volatile("" : "+v"(lane));  // keep the filter's lo fragments in LDS (see pl_dec_tile)
+  const int m = lane & 15, kg = lane >> 4;
+  const int base = 2 * kPlTileOut * tile + 32 * m + 8 * kg;
+  const uint4* ph = reinterpret_cast<const uint4*>(in_hi + base);
+  const uint4* pw = reinterpret_cast<const uint4*>(in_hi + in_stride + base);
+  const uint4* tl = tlo + lane;
+  f32x4 hh = {0.f, 0.f, 0.f, 0.f}, xa = hh, xb = hh;
+  uint4 xh[PF + 1], xl[PF + 1], tls[PF + 1];
+  auto rd = [&](int s) {
+    xh[s % (PF + 1)] = ph[4 * s];
+    xl[s % (PF + 1)] = pw[4 * s];
+    tls[s % (PF + 1)] = tl[s * 64];
+  };
+#pragma unroll
+  for (int s = 0; s < PF; ++s) rd(s);
+#pragma unroll
+  for (int s = 0; s < kPlDmSteps; ++s) {
+    if (s + PF < kPlDmSteps) rd(s + PF);
+    __builtin_amdgcn_sched_barrier(0);
+    hh = BP_PL_MFMA16(th[s], xh[s % (PF + 1)], hh);
+    xa = BP_PL_MFMA16(tls[s % (PF + 1)], xh[s % (PF + 1)], xa);
+    xb = BP_PL_MFMA16(th[s], xl[s % (PF + 1)], xb);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  pl_tile_store(hh, xa + xb, out_hi, stride, L_out, tile, lane, mir_hi, mir_stride);
+}
+
 // The filter's hi fragments live in registers (36 VGPRs), its lo fragments in LDS (9 KB, one ds_read_b128 per k-step):
 // with all 18 in registers the kernels would hold 3 waves per SIMD instead of 4.
 __device__ __forceinline__ void pl_load_tfrag(const uint4* __restrict__ tfrag, uint4 (&th)[kPlDmSteps], uint4* tlo) {
@@ -426,9 +492,10 @@ __device__ __forceinline__ void pl_load_tfrag(const uint4* __restrict__ tfrag, u
   __syncthreads();
 }
 
-// One level of every window.  F32IN: level 0 -> 1 from the fp32 audio (splits the signal once, writes the level-0 planes
-// with their reflect padding and the level-1 planes); else planes -> planes.  Waves walk (window, tile) items, the rows
-// of the next item are fetched before the matrix work of the current one; no workgroup barrier after the fragments are in.
+// One level of every window.  F32IN: level 0 -> 1 from the fp32 audio (the tiles at the ends of a window also leave level
+// 0's edge rows); else planes -> planes.  Waves walk (window, tile) items, the rows of the next item are fetched before the
+// matrix work of the current one; no workgroup barrier after the fragments are in.  (Launches with fewer windows than half
+// the CUs: the per-window kernels below would leave most of the chip idle.)
 template <bool F32IN>
 __global__ __launch_bounds__(256, 4) void pl_decimate_kernel(const float* __restrict__ audio, int64_t audio_stride,
                                                              uint16_t* __restrict__ pl, int64_t stride, int off_in, int L_in,
@@ -471,8 +538,11 @@ __global__ __launch_bounds__(256, 4) void pl_decimate_kernel(const float* __rest
     const PlRaw<F32IN> raw2 = fetch(item2 >= 0 ? item2 : item);
     const int b = item / tiles, tile = item - b * tiles;
     uint16_t* w = pl + (int64_t)b * 2 * stride;
-    pl_dec_tile<F32IN>(raw, audio + (int64_t)b * audio_stride, w + off_in, stride, L_in, w + off_out, L_out, tile, tiles, th,
-                       tlo, rows, lane, nullptr, 0, hop0);
+    if constexpr (F32IN) {
+      if (tile == 0 || tile == tiles - 1)  // wave-uniform
+        pl_write_edge_rows(audio + (int64_t)b * audio_stride, L_in, reinterpret_cast<float*>(w + off_in), hop0, tile == 0, lane);
+    }
+    pl_dec_tile<F32IN>(raw, stride, L_in, w + off_out, L_out, tile, th, tlo, rows, lane);
     if (item1 < 0) break;
     raw = raw1, raw1 = raw2, item = item1, item1 = item2, item2 = item3;
   }
@@ -484,6 +554,9 @@ __global__ __launch_bounds__(256, 4) void pl_decimate_kernel(const float* __rest
 // decimator zero-pads, the two edge tiles of a level mask whatever lies beside the samples), so the seven dependent
 // steps pay an LDS round trip and a barrier each, not a store-acknowledge + L2 read (28 us for 3 us of matrix work);
 // every level is also written to its planes in HBM for the filterbank.
+// (Since round 5 the 22.05 kHz pyramid of a launch with at least half a window per CU runs in pl_pyramid_window_kernel
+// below; this one serves the extended 44.1 kHz pyramid, whose level 1 does not fit the CU's LDS, and the deep levels of
+// small launches.)
 struct PlTail {
   int first, last, lds_first;
 };
@@ -503,12 +576,16 @@ __global__ __launch_bounds__(kPlTailThreads) void pl_decimate_tail_kernel(const 
   __shared__ __attribute__((aligned(16))) uint4 tlo[kPlDmSteps * 64];
   __shared__ __attribute__((aligned(16))) uint4 rows_all[(kPlTailThreads / 64) * kPlRowsU];
   __shared__ __attribute__((aligned(16))) uint16_t s_pl[2 * kPlTailLdsElems];  // hi plane, lo plane
-  uint4 th[kPlDmSteps];
-  pl_load_tfrag(tfrag, th, tlo);
   const int lane = threadIdx.x & 63;
   const int wave = wave_id();
-  uint4* rows = rows_all + wave * kPlRowsU;
   uint16_t* w = pl + (int64_t)blockIdx.x * 2 * g.stride;
+  // level 0's 32 edge rows, two per wave, before anything else is live in registers
+  if (t.first == 1)
+    pl_write_edge_row_pair(audio + (int64_t)blockIdx.x * audio_stride, g.len[0], reinterpret_cast<float*>(w + g.off[0]), g.hop0,
+                           wave, lane);
+  uint4 th[kPlDmSteps];
+  pl_load_tfrag(tfrag, th, tlo);
+  uint4* rows = rows_all + wave * kPlRowsU;
   int loff_in = 0, loff_out = kPlTailGuard;  // LDS element of sample 0 of the input / output level (when resident)
   for (int k = t.first; k <= t.last; ++k) {
     const int tiles = (g.len[k] + kPlTileOut - 1) / kPlTileOut;
@@ -516,7 +593,7 @@ __global__ __launch_bounds__(kPlTailThreads) void pl_decimate_tail_kernel(const 
     uint16_t* mir = out_lds ? s_pl + loff_out : nullptr;
     if (k == 1) {
       // level 0 -> 1 straight from the fp32 audio (round 4: the wide launch that did this spent 18 of its 35 us on per-item
-      // bookkeeping — queue draws, 64-bit addresses, edge predicates — with nothing to do: ablation in DESIGN.md §7).  Here a
+      // bookkeeping — queue draws, 64-bit addresses, edge predicates — with nothing to do: ablation in DESIGN_LOG.md).  Here a
       // wave walks tiles wave, wave + 16, ... of its workgroup's window, the next tile's rows in flight during the current
       // one's matrix work; level 1 goes to its planes in HBM (level 2 reads it back through L2 after the barrier below).
       const float* x = audio + (int64_t)blockIdx.x * audio_stride;
@@ -526,8 +603,7 @@ __global__ __launch_bounds__(kPlTailThreads) void pl_decimate_tail_kernel(const 
         for (;;) {
           const int ntile = tile + kPlTailThreads / 64;
           const PlRaw<true> nraw = pl_fetch_rows<true>(x, nullptr, 0, g.len[0], ntile < tiles ? ntile : tile, lane);
-          pl_dec_tile<true, false, 1>(raw, x, w + g.off[0], g.stride, g.len[0], w + g.off[1], g.len[1], tile, tiles, th, tlo,
-                                      rows, lane, nullptr, 0, g.hop0);
+          pl_dec_tile<true, false, 1>(raw, g.stride, g.len[0], w + g.off[1], g.len[1], tile, th, tlo, rows, lane);
           if (ntile >= tiles) break;
           raw = nraw, tile = ntile;
         }
@@ -539,8 +615,8 @@ __global__ __launch_bounds__(kPlTailThreads) void pl_decimate_tail_kernel(const 
         raw = pl_fetch_rows<false>(nullptr, s_pl + loff_in - kPlPad, kPlTailLdsElems, g.len[k - 1], tile, lane);
       else
         raw = pl_fetch_rows<false>(nullptr, w + g.off[k - 1], g.stride, g.len[k - 1], tile, lane);
-      pl_dec_tile<false, true, 3>(raw, nullptr, w + g.off[k - 1], g.stride, g.len[k - 1], w + g.off[k], g.len[k], tile, tiles,
-                               th, tlo, rows, lane, mir, kPlTailLdsElems);
+      pl_dec_tile<false, true, 3>(raw, g.stride, g.len[k - 1], w + g.off[k], g.len[k], tile, th, tlo, rows, lane, mir,
+                                  kPlTailLdsElems);
     }
     __syncthreads();  // level k is complete: in LDS for this workgroup (and in L2: same CU, same L1, workgroup scope)
     if (out_lds) {
@@ -548,6 +624,120 @@ __global__ __launch_bounds__(kPlTailThreads) void pl_decimate_tail_kernel(const 
       loff_out += (g.len[k] + 7) & ~7;
     }
   }
+}
+
+// The whole 22.05 kHz pyramid of one window, one workgroup of 16 waves, every level a wave reads again resident in LDS
+// (round 5).  What the round-4 kernel above spent per tile — ~350 instructions around 27 matrix instructions, for level
+// 1 as for the last, and a round of 16 tiles is paced by instruction issue (four waves per SIMD in lockstep behind the
+// level's barrier) — was mostly staging: every input row fetched, parked in a wave-private row image, fenced and read
+// back.  Here
+//   * level 0 -> 1 still goes through the row images (the input is the fp32 signal in HBM: fetched a tile ahead, split in
+//     registers), but level 1 ALSO stays in LDS (region A, 88 KB: hi and lo plane, samples only);
+//   * levels 2 .. 8 read their B fragments straight from the resident planes (pl_dec_tile_lds: 27 ds_read_b128 of the
+//     signal + 9 of the filter's lo fragments, 27 matrix instructions, the store): ~125 instructions a tile;
+//   * the LDS is time-shared: the 16 row images (60 KB, region B) are dead once level 1 is complete and take level 2;
+//     level 1's region is dead once level 2 is complete and takes levels 3 .. 7 back to back;
+//   * the barrier between levels waits for LDS traffic only (lds_barrier): the plane stores to HBM, which only the
+//     filterbank launch reads, stay in flight.
+// Every level is written to its planes in HBM as before; the bits are those of the kernels above (same matrix
+// instructions in the same order, same split, same masks).
+constexpr int kPwThreads = 1024;
+constexpr int kPwGuard = kPlPad;   // zeros in front of a resident level (the decimator's zero padding; tile 0 reads them)
+constexpr int kPwTail = 768;       // zeros behind it (the last tile's fragments reach at most 767 elements past the samples)
+__host__ __device__ constexpr int pw_level_elems(int k) { return kPwGuard + ((level_len(k) + 7) & ~7) + kPwTail; }
+constexpr int kPwPlaneA = pw_level_elems(1);  // 22824 elements per plane: level 1; later levels 3 .. 7 back to back
+constexpr int kPwPlaneB = pw_level_elems(2);  // 11864: level 2, in the space of the row images
+static_assert(2 * kPwPlaneB * 2 <= (kPwThreads / 64) * kPlRowsU * 16, "level 2 fits the row images' space");
+static_assert(pw_level_elems(3) + pw_level_elems(4) + pw_level_elems(5) + pw_level_elems(6) + pw_level_elems(7) <= kPwPlaneA,
+              "levels 3..7 fit level 1's space");
+static_assert(kPlDmSteps * 64 * 16 + (kPwThreads / 64) * kPlRowsU * 16 + 2 * kPwPlaneA * 2 <= 160 * 1024, "LDS budget");
+
+// zero elements [from, to) of both planes of a resident region (from, to multiples of 4), all threads of the workgroup
+__device__ __forceinline__ void pw_zero(uint16_t* hi, int stride, int from, int to) {
+  for (int i = from + 4 * (int)threadIdx.x; i < to; i += 4 * kPwThreads) {
+    *reinterpret_cast<uint2*>(hi + i) = uint2{0u, 0u};
+    *reinterpret_cast<uint2*>(hi + stride + i) = uint2{0u, 0u};
+  }
+}
+
+__global__ __launch_bounds__(kPwThreads) void pl_pyramid_window_kernel(const float* __restrict__ audio, int64_t audio_stride,
+                                                                      uint16_t* __restrict__ pl, PlGeo g,
+                                                                      const uint4* __restrict__ tfrag) {
+  __shared__ __attribute__((aligned(16))) uint4 tlo[kPlDmSteps * 64];
+  __shared__ __attribute__((aligned(16))) uint4 reg_b[(kPwThreads / 64) * kPlRowsU];
+  __shared__ __attribute__((aligned(16))) uint16_t reg_a[2 * kPwPlaneA];
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  constexpr int kWaves = kPwThreads / 64;
+  static_assert(kWaves == 16, "two of level 0's 32 edge rows per wave");
+  uint16_t* w = pl + (int64_t)blockIdx.x * 2 * g.stride;
+  uint16_t* const b16 = reinterpret_cast<uint16_t*>(reg_b);
+  const float* x = audio + (int64_t)blockIdx.x * audio_stride;
+  const int tiles1 = (g.len[1] + kPlTileOut - 1) / kPlTileOut;
+  PL_STAMP(0, 0);
+  PL_STAMP_RT(0, 14);
+  // the kernel's first memory round trips all at once: the first tile's rows, the edge rows' samples, the filter fragments
+  int tile = wave;
+  PlRaw<true> raw = pl_fetch_rows<true>(x, nullptr, 0, g.len[0], tile < tiles1 ? tile : 0, lane);
+  // level 0's 32 edge rows, two per wave
+  pl_write_edge_row_pair(x, g.len[0], reinterpret_cast<float*>(w + g.off[0]), g.hop0, wave, lane);
+  PL_STAMP(0, 1);
+  // level 1's zero surroundings in region A (its samples come from the tiles below)
+  pw_zero(reg_a, kPwPlaneA, 0, kPwGuard);
+  pw_zero(reg_a, kPwPlaneA, kPwGuard + ((g.len[1] + 3) & ~3), kPwPlaneA);
+  uint4 th[kPlDmSteps];
+  pl_load_tfrag(tfrag, th, tlo);
+  PL_STAMP(0, 2);
+  {
+    // level 0 -> 1: a wave walks tiles wave, wave + 16, ... (86 tiles: the six oldest waves have six, the others five),
+    // the next tile's rows in flight during the current one's matrix work
+    uint4* rows = reg_b + wave * kPlRowsU;
+    if (tile < tiles1) {
+      for (;;) {
+        const int ntile = tile + kWaves;
+        const PlRaw<true> nraw = pl_fetch_rows<true>(x, nullptr, 0, g.len[0], ntile < tiles1 ? ntile : tile, lane);
+        pl_dec_tile<true, true, 1>(raw, g.stride, g.len[0], w + g.off[1], g.len[1], tile, th, tlo, rows, lane,
+                                   reg_a + kPwGuard, kPwPlaneA);
+        if (ntile >= tiles1) break;
+        raw = nraw, tile = ntile;
+      }
+    }
+  }
+  PL_STAMP(0, 3);
+  lds_barrier();  // level 1 is complete in region A; the row images are dead
+  PL_STAMP(0, 4);
+  // levels 2 .. 8: input region (element 0 = kPlPad in front of the level's sample 0), output image (its sample 0)
+  const uint16_t* in_hi = reg_a;
+  int in_stride = kPwPlaneA;
+  uint16_t* mir = b16 + kPwGuard;
+  int mir_stride = kPwPlaneB;
+  for (int k = 2; k < g.n_levels; ++k) {
+    const int tiles = (g.len[k] + kPlTileOut - 1) / kPlTileOut;
+    const bool keep = k + 1 < g.n_levels;  // somebody reads this level again
+    if (k == 2) {  // level 2's zero surroundings in region B (the row images' space)
+      pw_zero(b16, kPwPlaneB, 0, kPwGuard);
+      pw_zero(b16, kPwPlaneB, kPwGuard + ((g.len[2] + 3) & ~3), kPwPlaneB);
+    } else if (k == 3) {  // those of levels 3 .. 7 in region A (level 1 is dead): in front of level 3, behind every level
+      pw_zero(reg_a, kPwPlaneA, 0, kPwGuard);
+      int off = 0;
+      for (int j = 3; j + 1 < g.n_levels; ++j) {
+        const int next = off + kPwGuard + ((g.len[j] + 7) & ~7) + kPwTail;  // the next level's region: its guard follows
+        pw_zero(reg_a, kPwPlaneA, off + kPwGuard + ((g.len[j] + 3) & ~3), j + 2 < g.n_levels ? next + kPwGuard : next);
+        off = next;
+      }
+    }
+    for (int tile_k = wave; tile_k < tiles; tile_k += kWaves)
+      pl_dec_tile_lds<3>(in_hi, in_stride, w + g.off[k], g.stride, g.len[k], tile_k, th, tlo, lane, keep ? mir : nullptr,
+                         mir_stride);
+    lds_barrier();  // level k is complete
+    PL_STAMP(0, 3 + k);
+    // level k becomes the input; level k + 1 goes to region A: at its start for k + 1 = 3, behind its predecessor after that
+    in_hi = mir - kPwGuard;
+    in_stride = mir_stride;
+    mir = k == 2 ? reg_a + kPwGuard : mir + ((g.len[k] + 7) & ~7) + kPwTail + kPwGuard;
+    mir_stride = kPwPlaneA;
+  }
+  PL_STAMP_RT(0, 15);
 }
 
 // ================================================================================================
@@ -574,43 +764,94 @@ __host__ __device__ constexpr PlFbItem pl_fb_item(int i) {
 }
 static_assert(pl_fb_item(kPlFbFrags - 1).s == 6 && pl_fb_item(kPlFbFrags).s == -1, "29 products per task");
 
-// THREADS / APF: 1024 threads = 4 waves per SIMD (128 VGPRs each) keep three k-steps of A fragments ahead (the default:
-// 54 us at B = 256); 768 / 704 threads = 3 waves per SIMD with up to 168 VGPRs hold the whole next task's fragments in
-// flight (56 registers) — measured the same 55 us: once the waves draw their tasks from a queue the kernel is paced by
-// instruction issue (matrix pipe 41 % busy, VALU most of the rest), not by memory latency.
+// Normalise + BatchNorm + split of four consecutive bins into `zp` words (signal.py:177-183, models.py:187-189):
+// z = (lp - min) * (bn_a / range) + bn_b, hi = rn_f16(z), lo = rn_f16((z - hi) 2^11), word = hi | lo << 16.
+__device__ __forceinline__ uint4 pl_zp_pack4(const float (&x)[4], float mn, float nk, float bn_b) {
+  uint32_t u[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float z = norm_bn_k(x[e], mn, nk, bn_b);
+    const _Float16 hi = (_Float16)z;
+    const _Float16 lo = (_Float16)((z - (float)hi) * kLoScale);
+    u[e] = (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
+  }
+  return uint4{u[0], u[1], u[2], u[3]};
+}
+
+// THREADS / APF: 1024 threads = 4 waves per SIMD (128 VGPRs each) keep three k-steps of A fragments ahead; 768 / 704
+// threads = 3 waves per SIMD with up to 168 VGPRs hold the whole next task's fragments in flight.
 // FUSED: a workgroup owns whole windows (its waves draw the window's 99 tasks), keeps the tiles' extrema in LDS and, when
 // the window's last task is done, normalises its log-power map itself and writes the pre-split, BatchNorm-ed `zp` words
 // (signal.py:177-183, models.py:187-189: what zpack_kernel does in a launch of its own) — the map was written by this
 // CU a few microseconds ago and comes back from L2, the extrema never leave the CU.  !FUSED: tasks strided over all
 // workgroups, extrema partials to `mmp` (launches with fewer windows than CUs, and the per-stage test hook).
-template <int THREADS, int APF, bool FUSED>
+//
+// Round 5 (the kernel was paced by its instruction count: 9 vector instructions per matrix instruction, of which the
+// normalise phase issued 45 %):
+//  * every A fragment is `uniform base (SGPR pair) + one 32-bit lane offset`: no 64-bit vector address arithmetic.  The
+//    two level-0 tiles that touch the ends of the signal read the 32 edge rows (above), whose row pitch makes the lane
+//    offset the same as into the audio;
+//  * the epilogue works on the accumulators as they are: with s = sqrt(len_b) 2^-12 (nnaudio.py:649-650 and the taps'
+//    scale) the reference's 10 log10((s re)^2 + (s im)^2 + eps) is kln2 [log2(re^2 + im^2 + eps / s^2) + log2(s^2)]; the
+//    two per-bin constants come from an LDS table (built at the kernel's start): 7 instead of 13 operations per value
+//    and no sqrt (the reference takes the root for the magnitude and squares it again, nnaudio.py:661, signal.py:174);
+//  * FUSED: a lane keeps running extrema over all its tasks of a window; one DPP reduction per wave and window;
+//  * the normalise phase runs over three index spaces (bins that come back from L2, bins in LDS, the one mixed group
+//    of four) with compile-time divisors, the affine map folded to (lp - min) * (bn_a / range) + bn_b.
+template <int THREADS, int APF, bool FUSED, bool EXT>
 __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
     const uint16_t* __restrict__ pl, const float* __restrict__ audio, int64_t audio_stride,
-    const uint4* __restrict__ bfrag, const float* __restrict__ sqrt_len, float* __restrict__ lp, float2* __restrict__ mmp,
+    const uint4* __restrict__ bfrag, const float* __restrict__ bin_eps, float* __restrict__ lp, float2* __restrict__ mmp,
     uint32_t* __restrict__ zp, int n_windows, LogConsts kc, PlGeo g, unsigned per_window_magic) {
+  constexpr int NB = EXT ? kBinsExt : kBins;
+  constexpr int NL = EXT ? kOctavesExt : kOctaves;
+  constexpr int HOP0 = EXT ? 512 : 256;
+  constexpr int kLog2Hop0 = EXT ? 9 : 8;
+  constexpr int kPerWindow = NL * kPlTilesPerLevel;
+  constexpr int kWaves = THREADS / 64;
+  static_assert(kPlTilesPerLevel == 11, "the multiply-shift below divides by 11");
   __shared__ __attribute__((aligned(16))) uint4 bfr[kPlFbFrags * 2 * 64];
-  // sqrt(lengths) and the level offsets from LDS, not from global / constant memory: a wave's memory counters are in
-  // order, so a global load in the epilogue would wait for every A fragment prefetched for the next task before it
-  __shared__ float s_sqrt_len[kBinsExt];
+  // the per-bin constants and the level offsets from LDS, not from global / constant memory: a wave's memory counters are
+  // in order, so a global load in the epilogue would wait for every A fragment prefetched for the next task before it
+  __shared__ float2 s_bin[NB];
   __shared__ int s_off[10];
   __shared__ int s_next;
-  __shared__ float2 s_mm[FUSED ? 10 * kPlTilesPerLevel : 1];
+  __shared__ float2 s_mm[FUSED ? kWaves : 1];
   // FUSED: the log-power values of the four top levels (144 bins x 172 frames = 97 KB: what is left of the CU's LDS) wait
   // for the normalise phase here instead of making the round trip through L2 / HBM
   constexpr int kLdsBins = 4 * kBpo;
+  constexpr int kLdsBin0 = NB - kLdsBins;  // bins from here on wait in LDS
   __shared__ float s_lp[FUSED ? kFrames * kLdsBins : 1];
-#if defined(PL_FB_PROF)
-  const unsigned long long pentry = __builtin_amdgcn_s_memtime();
-#endif
+  PL_STAMP(1, 0);
+  PL_STAMP_RT(1, 14);
+  // log2 -> 10 log10 (uniform: kept in a scalar register)
+  const float kln2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(0.69314718055994531f * kc.s0 * kc.s1)));
   if (threadIdx.x == 0) s_next = 0;
   for (int i = threadIdx.x; i < kPlFbFrags * 2 * 64; i += THREADS) bfr[i] = bfrag[i];
-  for (int i = threadIdx.x; i < g.n_bins; i += THREADS) s_sqrt_len[i] = sqrt_len[i];
+  {
+    // The per-bin pair {eps_b = eps / s^2, c_b = kln2 log2(s^2)}.  c_b is derived HERE, with the very instructions the
+    // epilogue uses, as c_b = rn(v0 - log2(eps_b) kln2), v0 = the log-power of a silent bin (10 log10(eps), the value
+    // every bin had before round 5): a bin whose power vanishes beside eps_b (digital silence) then evaluates to
+    // rn(log2(eps_b) kln2 + c_b) = v0 EXACTLY, whatever its bin (|c_b| < 64 rounds to 2^-19, half an ulp of v0 ~ -100 is
+    // 2^-18) — the window's range is exactly 0 and divide_no_nan yields the reference's constant map (signal.py:179-183).
+    // With a table rounded on the host the silent window's extrema differed in the last bit and the normalisation blew
+    // that up to a full-scale pattern.
+    const float v0 = __fmul_rn(__builtin_amdgcn_logf(kc.eps), kln2);
+    for (int i = threadIdx.x; i < NB; i += THREADS) {
+      const float e = bin_eps[i];
+      s_bin[i] = make_float2(e, __fmaf_rn(-__builtin_amdgcn_logf(e), kln2, v0));
+    }
+  }
   if (threadIdx.x < 10) s_off[threadIdx.x] = g.off[threadIdx.x];
   __syncthreads();
+  PL_STAMP(1, 1);
   int lane = threadIdx.x & 63;
-  const int per_window = g.n_levels * kPlTilesPerLevel;
-  const int n_tasks = n_windows * per_window;
-  const float kln2 = 0.69314718055994531f * kc.s0 * kc.s1;  // log2 -> 10 log10
+  const int n_tasks = n_windows * kPerWindow;
+  const float kInf = __int_as_float(0x7f800000);
+  // D row (frame of the tile) = 4 kg + r, column (filter of the group) = t.  Every per-lane offset below is re-derived
+  // from the (opaque) lane index inside the task loop — a handful of operations per task — instead of living in a dozen
+  // registers through it: at 128 registers per lane the kernel would spill them.
+  int t = lane & 15, kg = lane >> 4;
   // Tasks of this workgroup: blockIdx.x + gridDim.x * j, j = 0, 1, ...; its waves DRAW j from a counter in LDS instead of
   // owning a fixed share: the SIMD's issue arbitration favours the older waves of a workgroup (phase clocks: wave 0
   // finishes a task in 7.5 k cycles, wave 10 in 19.5 k), so with fixed shares the old waves ran out of work at 40 % of
@@ -623,47 +864,49 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
     int j = 0;
     if ((threadIdx.x & 63) == 0) j = atomicAdd(&s_next, 1);
     j = __builtin_amdgcn_readfirstlane(j);
-    if constexpr (FUSED) return j < per_window ? win * per_window + j : -1;
+    if constexpr (FUSED) return j < kPerWindow ? win * kPerWindow + j : -1;
     const int task_ = blockIdx.x + gridDim.x * j;
     return task_ < n_tasks ? task_ : -1;
   };
   auto pos_of = [&](int task_) {  // task / per_window by multiply-shift (exact below 2^32 / 95 for 99, 2^32 / 4 for 110)
-    if constexpr (FUSED) return Pos{win, task_ - win * per_window};
+    if constexpr (FUSED) return Pos{win, task_ - win * kPerWindow};
     const int b_ = (int)__umulhi((unsigned)task_, per_window_magic);
-    return Pos{b_, task_ - b_ * per_window};
+    return Pos{b_, task_ - b_ * kPerWindow};
   };
-  // Where a task's A fragments come from.  Planes: 16 bytes of the hi plane per k-step (32 elements apart), the lo
-  // plane g.stride elements behind it.  Level 0 (round 4): the fp32 audio itself — 8 samples = two 16-byte loads per
-  // k-step, split to hi / lo in registers when the k-step is consumed (every level-0 sample feeds at most one frame: hop
-  // >= window, so nothing is split twice); level 0 has no planes any more: -45 MB written and -45 MB read per 256 windows.
+  // Where a task's A fragments come from: two uniform bases (first / second 16-byte half of a k-step's fragment) + this
+  // lane's byte offset + step * s.  Planes: 16 bytes of the hi plane per k-step (32 elements apart), the lo plane g.stride
+  // elements behind it.  Level 0: the fp32 audio itself — 8 samples = two 16-byte loads per k-step, split to hi / lo in
+  // registers when the k-step is consumed (every level-0 sample feeds at most one frame: hop >= window, so nothing is
+  // split twice) — or, for the two tiles at the ends of the signal, the edge rows.
   struct Src {
-    const char* p;     // this lane's first fragment
-    int step;          // bytes between k-steps
-    int64_t second;    // bytes from the first to the second 16-byte half (lo plane / samples 4..7)
-    bool raw;          // fp32 samples: split at consumption
+    const char* p0;
+    const char* p1;
+    uint32_t voff;
+    int step;  // bytes between k-steps
+    int raw;   // fp32 samples: split at consumption (an int: a bool's padding bytes made the struct copies go through scratch)
   };
-  const int f_edge = pl_edge_frame(g.len[0], g.hop0);
   auto src_of = [&](Pos p) -> Src {
     const int level_ = (p.rem * 745) >> 13;  // rem / 11 for rem < 2700
     const int tile_ = p.rem - level_ * kPlTilesPerLevel;
-    if (audio != nullptr && level_ == 0) {  // wave-uniform
-      const int f = 16 * tile_ + (lane & 15);
-      const float* a = audio + (int64_t)p.b * audio_stride + f * g.hop0 - kPlPad;
-      if (f == 0 || f >= f_edge)  // a mirrored window: the edge rows the decimator left where level 0's planes were
-        a = reinterpret_cast<const float*>(pl + (int64_t)p.b * 2 * g.stride + s_off[0]) + 256 * (f == 0 ? 0 : 1 + f - f_edge);
-      return Src{reinterpret_cast<const char*>(a + 16 + 8 * (lane >> 4)), 128, 16, true};
+    const uint16_t* wpl = pl + (int64_t)p.b * 2 * g.stride;
+    if (level_ == 0) {  // wave-uniform
+      const float* a = (tile_ == 0 || tile_ == kPlTilesPerLevel - 1)
+                           ? reinterpret_cast<const float*>(wpl + __builtin_amdgcn_readfirstlane(s_off[0])) + (tile_ ? 16 * HOP0 : 0)
+                           : audio + (int64_t)p.b * audio_stride + (16 * tile_ * HOP0 - kPlPad);
+      const char* c = reinterpret_cast<const char*>(a);
+      return Src{c, c + 16, (uint32_t)(t * HOP0 + 16 + 8 * kg) * 4u, 128, 1};  // fp32 samples, frame pitch = hop0
     }
-    const uint16_t* q = pl + (int64_t)p.b * 2 * g.stride + s_off[level_] + (16 * tile_ + (lane & 15)) * (g.hop0 >> level_) + 16 +
-                        8 * (lane >> 4);
-    return Src{reinterpret_cast<const char*>(q), 64, 2 * g.stride, false};
+    const int sh = kLog2Hop0 - level_;  // log2(hop of the level)
+    const char* c = reinterpret_cast<const char*>(wpl + __builtin_amdgcn_readfirstlane(s_off[level_]) + ((16 * tile_) << sh));
+    return Src{c, c + 2 * g.stride, (((uint32_t)t << sh) << 1) + 32u + 16u * (uint32_t)kg, 64, 0};  // f16 elements
   };
-  auto load16 = [](const char* p) {
+  auto load16 = [](const char* base, uint32_t off) {
     uint4 v;
-    __builtin_memcpy(&v, __builtin_assume_aligned(p, 2), 16);  // 2-byte alignment at the hop-1 level; dword at least elsewhere
+    __builtin_memcpy(&v, __builtin_assume_aligned(base + off, 2), 16);  // 2-byte alignment at the hop-1 level; dword at least elsewhere
     return v;
   };
-  static_assert(kPlTilesPerLevel == 11, "the multiply-shift above divides by 11");
   for (; win < (FUSED ? n_windows : blockIdx.x + 1); win += gridDim.x) {
+  float rmin = kInf, rmax = -kInf;  // FUSED: this lane's extrema over its tasks of the window
   int task = grab();
   int ntask = task >= 0 ? grab() : -1;
   if (task >= 0) {
@@ -676,23 +919,17 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
   {
 #pragma unroll
     for (int s = 0; s < APF; ++s) {
-      ah[s] = load16(src.p + src.step * s);
-      al[s] = load16(src.p + src.second + src.step * s);
+      ah[s] = load16(src.p0, src.voff + src.step * s);
+      al[s] = load16(src.p1, src.voff + src.step * s);
     }
   }
-#if defined(PL_FB_PROF)
-  unsigned long long pk = 0, pe = 0, pn_ = 0, pstart = __builtin_amdgcn_s_memtime();
-#endif
   for (;;) {
-#if defined(PL_FB_PROF)
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
-#endif
     // keep the filter fragments in LDS: without an opaque offset the compiler hoists all 58 loop-invariant reads
     asm volatile("" : "+v"(lane));
+    t = lane & 15, kg = lane >> 4;
     const int nntask = ntask >= 0 ? grab() : -1;  // drawn a task ahead: its LDS round trip is nobody's critical path
     const int b = pos.b, rem = pos.rem;
     const int level = (rem * 745) >> 13, tile = rem - level * kPlTilesPerLevel;
-    const int t = lane & 15, kg = lane >> 4;
     const uint4* bl = bfr + lane;
     const bool more = ntask >= 0;
     const Pos npos = more ? pos_of(ntask) : pos;
@@ -729,53 +966,48 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
       if (i + 1 == kPlFbFrags || item(i + 1).s != s) {  // last product of k-step s: its ring slot takes step s + APF
         const int sn = s + APF;
         if (sn < 7) {
-          ah[sn] = load16(src.p + src.step * sn);
-          al[sn] = load16(src.p + src.second + src.step * sn);
+          ah[sn] = load16(src.p0, src.voff + src.step * sn);
+          al[sn] = load16(src.p1, src.voff + src.step * sn);
         } else {
-          ah[sn - 7] = load16(nsrc.p + nsrc.step * (sn - 7));
-          al[sn - 7] = load16(nsrc.p + nsrc.second + nsrc.step * (sn - 7));
+          ah[sn - 7] = load16(nsrc.p0, nsrc.voff + nsrc.step * (sn - 7));
+          al[sn - 7] = load16(nsrc.p1, nsrc.voff + nsrc.step * (sn - 7));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
 
-#if defined(PL_FB_PROF)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(hh[0]), "+v"(xx[4]));
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
-#endif
     // epilogue: D row (frame) = 4 kg + r, column (filter of the group) = lane & 15
-    const int bin0 = (g.n_levels - 1 - level) * kBpo - 15;  // nnaudio.py:640-642
-    float* lp_t = lp + ((int64_t)b * kFrames + 16 * tile + 4 * kg) * g.n_bins + bin0;
+    const int bin0 = (NL - 1 - level) * kBpo - 15;  // nnaudio.py:640-642
+    char* lp_t = reinterpret_cast<char*>(lp + ((int64_t)b * kFrames + 16 * tile) * NB + bin0);
     const int fr0 = 16 * tile + 4 * kg;
-    float vmin = __int_as_float(0x7f800000), vmax = -__int_as_float(0x7f800000);
+    const uint32_t so_kg = __umul24((unsigned)kg, 16u * NB);             // lp stores: + (r NB + 16 group) floats
+    const uint32_t so_hbm = so_kg + 4u * (unsigned)t, so_hbm4 = so_kg + 4u * (32u + ((unsigned)t & 3u));
+    const int so_lds = 4 * kg * kLdsBins + t, so_lds4 = 4 * kg * kLdsBins + 32 + (t & 3);
+    float vmin = FUSED ? rmin : kInf, vmax = FUSED ? rmax : -kInf;
     // `masked` (wave-uniform): the tile has padding frames (the 11th tile) or the level has bins below the CQT's first
     // (the deepest level): 8 of 10 tasks have neither, and then only group 4's unused columns need a predicate
     const bool masked = tile == kPlTilesPerLevel - 1 || bin0 < 0;
     const bool to_lds = FUSED && level < 4;  // wave-uniform
-    float* lds_t = s_lp + (16 * tile + 4 * kg) * kLdsBins + (3 - level) * kBpo;
+    float* lds_t = s_lp + 16 * tile * kLdsBins + (3 - level) * kBpo;
     auto finish = [&](auto masked_c, auto lds_c, const f32x4& hr, const f32x4& xr, const f32x4& hi_, const f32x4& xi, int k,
-                      bool col_ok) {
+                      int grp, bool col_ok) {
       constexpr bool kMasked = decltype(masked_c)::value, kLds = decltype(lds_c)::value;
       const bool bin_ok = col_ok && (!kMasked || bin0 + k >= 0);
-      // * sqrt(lengths) (nnaudio.py:650, before squaring) and the taps' 2^-12 in one factor: a power of two commutes
-      // with the rounding of the product
-      const float slk = s_sqrt_len[bin_ok ? bin0 + k : 0] * kPlFmTapUnscale;
+      const float2 bc = s_bin[kMasked ? (bin0 + k >= 0 ? bin0 + k : 0) : bin0 + k];
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float re = __fmul_rn(hr[r] + xr[r] * kLoUnscale, slk);
-        const float im = __fmul_rn(hi_[r] + xi[r] * kLoUnscale, slk);
-        // nnaudio.py:661 magnitude, signal.py:174-175 power and 10 log10 on the hardware's 1-ulp sqrt / log2
-        const float mag = __builtin_amdgcn_sqrtf(__fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)));
-        const float pw = __fmul_rn(mag, mag);
-        v[r] = __fmul_rn(__builtin_amdgcn_logf(__fadd_rn(pw, kc.eps)), kln2);
+        const float re = __fmaf_rn(xr[r], kLoUnscale, hr[r]);
+        const float im = __fmaf_rn(xi[r], kLoUnscale, hi_[r]);
+        const float pw = __fmaf_rn(im, im, __fmul_rn(re, re));
+        // nnaudio.py:649-661 and signal.py:174-175 in accumulator units (see the header), hardware 1-ulp log2
+        v[r] = __fmaf_rn(__builtin_amdgcn_logf(__fadd_rn(pw, bc.x)), kln2, bc.y);
       }
       auto put = [&](int r) {
         if constexpr (kLds)
-          lds_t[r * kLdsBins + k] = v[r];
+          lds_t[(grp == 2 ? so_lds4 : so_lds + 16 * grp) + r * kLdsBins] = v[r];
         else
-          lp_t[r * g.n_bins + k] = v[r];
+          *reinterpret_cast<float*>(lp_t + (grp == 2 ? so_hbm4 : so_hbm) + (grp == 2 ? 0 : 64 * grp) + r * NB * 4) = v[r];
       };
       if constexpr (kMasked) {
 #pragma unroll
@@ -801,9 +1033,9 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
     const f32x4 xi4 = {pl_from_lane_plus4(xx[4][0]), pl_from_lane_plus4(xx[4][1]), pl_from_lane_plus4(xx[4][2]),
                        pl_from_lane_plus4(xx[4][3])};
     auto finish_all = [&](auto mc, auto lc) {
-      finish(mc, lc, hh[0], xx[0], hh[1], xx[1], t, true);
-      finish(mc, lc, hh[2], xx[2], hh[3], xx[3], 16 + t, true);
-      finish(mc, lc, hh[4], xx[4], hi4, xi4, 32 + (t & 3), t < 4);
+      finish(mc, lc, hh[0], xx[0], hh[1], xx[1], t, 0, true);
+      finish(mc, lc, hh[2], xx[2], hh[3], xx[3], 16 + t, 1, true);
+      finish(mc, lc, hh[4], xx[4], hi4, xi4, 32 + (t & 3), 2, t < 4);
     };
     if (to_lds) {
       if (masked)
@@ -816,20 +1048,13 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
       else
         finish_all(std::false_type{}, std::false_type{});
     }
-    vmin = wave_min_lane63(vmin);
-    vmax = wave_max_lane63(vmax);
-    if ((threadIdx.x & 63) == 63) {
-      if constexpr (FUSED)
-        s_mm[rem] = make_float2(vmin, vmax);
-      else
-        mmp[(int64_t)b * per_window + rem] = make_float2(vmin, vmax);
+    if constexpr (FUSED) {
+      rmin = vmin, rmax = vmax;
+    } else {
+      vmin = wave_min_lane63(vmin);
+      vmax = wave_max_lane63(vmax);
+      if ((threadIdx.x & 63) == 63) mmp[(int64_t)b * kPerWindow + rem] = make_float2(vmin, vmax);
     }
-#if defined(PL_FB_PROF)
-    {
-      const unsigned long long c2 = __builtin_amdgcn_s_memtime();
-      pk += c1 - c0, pe += c2 - c1, ++pn_;
-    }
-#endif
     if (!more) break;
     pos = npos, src = nsrc, task = ntask, ntask = nntask;
   }
@@ -837,68 +1062,91 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
   if constexpr (!FUSED) break;
   if constexpr (FUSED) {
     // ---- the window is complete: normalise + BatchNorm + split, as zpack_kernel (conv_branch.hip) ----
-    __syncthreads();  // every tile's log-power values (global stores of this workgroup) and extrema (LDS) are visible
-    float vmin = __int_as_float(0x7f800000), vmax = -__int_as_float(0x7f800000);
-    for (int i = threadIdx.x & 63; i < per_window; i += 64) {
-      vmin = fminf(vmin, s_mm[i].x);
-      vmax = fmaxf(vmax, s_mm[i].y);
+    PL_STAMP(1, 2);
+    rmin = wave_min_lane63(rmin);
+    rmax = wave_max_lane63(rmax);
+    if ((threadIdx.x & 63) == 63) s_mm[threadIdx.x >> 6] = make_float2(rmin, rmax);
+    __syncthreads();  // every tile's log-power values (global stores of this workgroup / LDS) and the waves' extrema are visible
+    PL_STAMP(1, 3);
+    float vmin = kInf, vmax = -kInf;
+    if ((threadIdx.x & 63) < kWaves) {
+      const float2 e = s_mm[threadIdx.x & 63];
+      vmin = e.x, vmax = e.y;
     }
     const float mn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_min_lane63(vmin)), 63));
     const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_max_lane63(vmax)), 63));
-    const float range = mx - mn;
-    const float* lpb = lp + (int64_t)win * kFrames * g.n_bins;
-    uint32_t* zb = zp + (int64_t)win * kZWin;
+    const float nk = norm_scale(mn, mx, kc);
+    const float* lpb = lp + (int64_t)win * kFrames * NB;
     // only the words that carry bins: `zp`'s pad frames / pad words are zero since bp_create and nobody writes them
-    const int row_u4 = (g.n_bins + 3) / 4;  // uint4 per frame that hold bins (kZPadL is a multiple of 4)
-    // loads of kZb items in flight per thread (the values come back from L2): issued one by one, every item would pay
-    // the round trip on its own.  The last item of a row reads up to 3 floats of the next row (masked below; `lp` is
-    // allocated with that much slack behind its last row).
-    constexpr int kZb = 7;
-    const int n_items = kFrames * row_u4;
-    for (int i0 = threadIdx.x; i0 < n_items; i0 += kZb * THREADS) {
-      const int lds_bin0 = g.n_bins - kLdsBins;  // bins from here on wait in LDS
+    uint32_t* zb = zp + (int64_t)win * kZWin + kZRow + kZPadL;  // frame 0, bin 0 (kZPadL is a multiple of 4)
+    constexpr int kJ = (NB + 3) / 4;     // groups of four bins per frame
+    constexpr int kJH = kLdsBin0 / 4;    // groups whose four bins all come back from L2
+    static_assert(kLdsBin0 % 4 == 1 && NB % 4 == 1, "group kJH is {1 bin from L2, 3 from LDS}; the last group holds one bin");
+    constexpr int kJL = kJ - kJH - 1;    // groups whose bins all wait in LDS: columns 4 j' + 3 .. 4 j' + 6
+    // (the thread index through an opaque copy: the index arithmetic below does not depend on the window, and hoisted out
+    // of the window loop it would sit in ~40 registers through the task loop — the compiler spilled them to scratch)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const char* lpc = reinterpret_cast<const char*>(lpb);
+    char* zc = reinterpret_cast<char*>(zb);
+    // i / d and i % d for the three small index spaces on the full-rate 24-bit multiplier (the generic 32-bit forms are
+    // quarter rate): q = (i M) >> 20 with M = ceil(2^20 / d), exact while i (M d - 2^20) < 2^20
+    auto divmod = [](int i, auto d_c, auto n_c) {
+      constexpr unsigned d = decltype(d_c)::value, n = decltype(n_c)::value, M = ((1u << 20) + d - 1) / d;
+      static_assert((unsigned long long)n * (M * d - (1u << 20)) < (1u << 20) && (unsigned long long)n * M < (1ull << 32), "exact");
+      const unsigned q = __umul24((unsigned)i, M) >> 20;
+      return uint2{q, (unsigned)i - __umul24(q, d)};
+    };
+    // (A) from L2: all loads of a thread in flight at once (issued one by one, every item would pay the round trip; the
+    // memory clobber keeps the compiler from sinking each load into the block that uses it)
+    {
+      constexpr int nA = kFrames * kJH;
+      constexpr int kZb = (nA + THREADS - 1) / THREADS;
       float4 v[kZb];
 #pragma unroll
       for (int k = 0; k < kZb; ++k) {
-        const int i = i0 + k * THREADS;
-        const int ic = i < n_items ? i : n_items - 1;
-        const int t_ = ic / row_u4, g0 = 4 * (ic - t_ * row_u4);
-        v[k] = float4{0.f, 0.f, 0.f, 0.f};
-        if (g0 < lds_bin0) v[k] = *reinterpret_cast<const float4*>(lpb + t_ * g.n_bins + g0);  // dword alignment is enough
+        const int i = tid + k * THREADS;
+        const uint2 tj = divmod(i < nA ? i : nA - 1, std::integral_constant<unsigned, kJH>{}, std::integral_constant<unsigned, nA>{});
+        v[k] = *reinterpret_cast<const float4*>(lpc + (__umul24(tj.x, NB * 4u) + 16u * tj.y));  // dword alignment is enough
       }
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int k = 0; k < kZb; ++k) {
-        const int i = i0 + k * THREADS;
-        if (i >= n_items) break;
-        const int t_ = i / row_u4, g0 = 4 * (i - t_ * row_u4);
-        float x4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-        if (g0 + 3 >= lds_bin0) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int c = g0 + e - lds_bin0;
-            if (c >= 0 && c < kLdsBins) x4[e] = s_lp[t_ * kLdsBins + c];
-          }
+        const int i = tid + k * THREADS;
+        if (i < nA) {
+          const uint2 tj = divmod(i, std::integral_constant<unsigned, kJH>{}, std::integral_constant<unsigned, nA>{});
+          const float x4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+          *reinterpret_cast<uint4*>(zc + (__umul24(tj.x, kZRow * 4u) + 16u * tj.y)) = pl_zp_pack4(x4, mn, nk, kc.bn_b);
         }
-        uint32_t u[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float z = norm_bn(x4[e], mn, range, kc);
-          const _Float16 hi = (_Float16)z;
-          const _Float16 lo = (_Float16)((z - (float)hi) * kLoScale);
-          const uint32_t w = (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
-          u[e] = g0 + e < g.n_bins ? w : 0u;
-        }
-        *reinterpret_cast<uint4*>(zb + (t_ + 1) * kZRow + kZPadL + g0) = uint4{u[0], u[1], u[2], u[3]};
       }
     }
-    __syncthreads();  // s_mm and the task counter are free for the next window
+    PL_STAMP(1, 4);
+    // (B) from LDS
+    {
+      constexpr int nB = kFrames * kJL;
+      for (int i = tid; i < nB; i += THREADS) {
+        const uint2 tj = divmod(i, std::integral_constant<unsigned, kJL>{}, std::integral_constant<unsigned, nB>{});
+        const float* row = s_lp + __umul24(tj.x, (unsigned)kLdsBins) + 4u * tj.y + 3u;
+        const bool last = tj.y == kJL - 1;  // bins NB - 1 .. NB + 2: one bin, three pad words
+        const float x4[4] = {row[0], last ? 0.f : row[1], last ? 0.f : row[2], last ? 0.f : row[3]};
+        uint4 w = pl_zp_pack4(x4, mn, nk, kc.bn_b);
+        if (last) w.y = w.z = w.w = 0u;
+        *reinterpret_cast<uint4*>(zc + (__umul24(tj.x, kZRow * 4u) + 16u * (tj.y + kJH + 1))) = w;
+      }
+    }
+    // (C) the mixed group: bin 4 kJH from L2, the next three from LDS
+    if (tid < kFrames) {
+      const float x4[4] = {lpb[tid * NB + 4 * kJH], s_lp[tid * kLdsBins], s_lp[tid * kLdsBins + 1], s_lp[tid * kLdsBins + 2]};
+      *reinterpret_cast<uint4*>(zc + (__umul24((unsigned)tid, kZRow * 4u) + 16u * kJH)) = pl_zp_pack4(x4, mn, nk, kc.bn_b);
+    }
+    PL_STAMP(1, 5);
+    __syncthreads();  // s_lp, s_mm and the task counter are free for the next window
+    PL_STAMP(1, 6);
+    PL_STAMP_RT(1, 15);
     if (threadIdx.x == 0) s_next = 0;
     __syncthreads();
   }
   }  // windows
-#if defined(PL_FB_PROF)
-  (void)pentry;
-#endif
 }
 
 // ================================================================================================
@@ -927,18 +1175,17 @@ void launch_planes_unsplit(const uint16_t* pl, int level, float* dst, int64_t ds
                      g.off[level], g.len[level], dst, dst_stride);
 }
 
-// levels 0 (planes) and 1 .. n-1 from the fp32 audio: one wide launch for level 0 -> 1, then the rest per window
+// levels 1 .. n-1 (planes) and level 0's edge rows from the fp32 audio
 void launch_pyramid_planes(const float* audio, int64_t audio_stride, uint16_t* pl, const void* tfrag, int n_windows, int n_cu,
                            bool ext, hipStream_t stream) {
   const PlGeo g = make_pl_geo(ext);
   const uint4* tf = static_cast<const uint4*>(tfrag);
-  // with at least half a window per CU the whole pyramid is ONE launch (a workgroup per window, level 1 from the audio
-  // included); BP_PYR=wide keeps the wide level-0 -> 1 launch in front (A/B runs)
-  static const bool wide = [] {
-    const char* e = getenv("BP_PYR");
-    return e && strcmp(e, "wide") == 0;
-  }();
-  const bool one_launch = !wide && n_windows >= n_cu / 2;
+  // with at least half a window per CU the whole pyramid is ONE launch, a workgroup per window
+  const bool one_launch = n_windows >= n_cu / 2;
+  if (one_launch && !ext) {
+    hipLaunchKernelGGL(pl_pyramid_window_kernel, dim3(n_windows), dim3(kPwThreads), 0, stream, audio, audio_stride, pl, g, tf);
+    return;
+  }
   if (!one_launch) {
     const int tiles = (g.len[1] + kPlTileOut - 1) / kPlTileOut;
     const int items = tiles * n_windows;
@@ -949,7 +1196,7 @@ void launch_pyramid_planes(const float* audio, int64_t audio_stride, uint16_t* p
   }
   // with fewer windows than CUs the per-window kernel would leave most of the chip idle on the long levels: those run wide
   int first_tail = one_launch ? 1 : 2;
-  if (n_windows < n_cu / 2)
+  if (!one_launch)
     for (; first_tail < g.n_levels && g.len[first_tail] > 16 * kPlTileOut; ++first_tail) {
       const int k = first_tail;
       const int tiles = (g.len[k] + kPlTileOut - 1) / kPlTileOut;
@@ -963,67 +1210,62 @@ void launch_pyramid_planes(const float* audio, int64_t audio_stride, uint16_t* p
     // levels kept in LDS: as many of the deepest ones as fit (22.05 kHz: all from level 2; extended pyramid: from level 3)
     int lds_first = first_tail < 2 ? 2 : first_tail;
     while (pl_tail_lds_need(g, lds_first, g.n_levels - 1) > kPlTailLdsElems) ++lds_first;
-    int last = g.n_levels - 1;
-#ifdef BP_PLANES_DEBUG_HOOKS  // tools only (tools/build_variant.sh ... -DBP_PLANES_DEBUG_HOOKS): garbage results
-    if (const char* e = getenv("BP_TAIL_LAST")) last = atoi(e);  // timing of the first levels
-#endif
     hipLaunchKernelGGL(pl_decimate_tail_kernel, dim3(n_windows), dim3(kPlTailThreads), 0, stream, audio, audio_stride, pl, g,
-                       PlTail{first_tail, last, lds_first}, tf);
+                       PlTail{first_tail, g.n_levels - 1, lds_first}, tf);
   }
 }
 
 int filterbank_planes_partials(bool ext) { return make_pl_geo(ext).n_levels * kPlTilesPerLevel; }
 
+// The per-bin constant of the filterbank's epilogue (see the kernel's header): eps / s^2 with s = sqrt(len_b) 2^-12,
+// evaluated in float64 and rounded once.  (Its partner kln2 log2(s^2) is derived on the device: see the kernel.)
+void filterbank_planes_bin_consts(const float* sqrt_len, int n_bins, LogConsts kc, float* out) {
+  for (int b = 0; b < n_bins; ++b) {
+    const double s = (double)sqrt_len[b] * (double)kPlFmTapUnscale;
+    out[b] = (float)((double)kc.eps / (s * s));
+  }
+}
+
 // zp != null and enough windows to give every CU its own: the fused kernel (filterbank + normalise / BatchNorm / split of
 // whole windows per workgroup) — returns true, `zp` is complete; otherwise tasks strided over the chip, extrema partials in
 // `scratch` (fold them with launch_zpack_partials or launch_mm_reduce) — returns false.
-// `audio` (may be null: every level from the planes): the fp32 signal the level-0 planes were made from; the interior tiles
-// of level 0 then read it directly and the level-0 planes need to hold the two edge tiles only.
+// `audio`: the fp32 signal (level 0 has no planes: the interior tiles of level 0 read it directly, the two tiles at the
+// ends of the signal read the edge rows the pyramid kernel / launch_planes_edge_rows left where level 0's planes were).
 bool launch_filterbank_planes(const uint16_t* pl, const float* audio, int64_t audio_stride, const void* bfrag,
-                              const float* sqrt_len, float* lp, float* scratch, uint32_t* zp, int n_windows, LogConsts kc,
+                              const float* bin_consts, float* lp, float* scratch, uint32_t* zp, int n_windows, LogConsts kc,
                               int n_cu, bool ext, hipStream_t stream) {
-  PlGeo g = make_pl_geo(ext);
-#ifdef BP_PLANES_DEBUG_HOOKS  // tools only: timing of one level's tasks; results are garbage
-  if (const char* e = getenv("BP_FB_ONLY_LEVEL")) {
-    const int k = atoi(e);
-    g.hop0 >>= k, g.off[0] = g.off[k], g.len[0] = g.len[k], g.n_levels = 1;
-    zp = nullptr;
-    if (k > 0) audio = nullptr;
-  }
-#endif
+  const PlGeo g = make_pl_geo(ext);
   const int tasks = n_windows * g.n_levels * kPlTilesPerLevel;
-  static const int variant = [] {  // BP_FB_WAVES=16 / 12 / 11: waves per workgroup (A/B runs); default 16
-    const char* e = getenv("BP_FB_WAVES");
-    return e ? atoi(e) : 16;
-  }();
-  static const bool no_fuse = getenv("BP_FB_NOFUSE") != nullptr;  // A/B runs: the separate zpack launch
   const uint4* bf = static_cast<const uint4*>(bfrag);
+  const float* bk = bin_consts;
   float2* mm = reinterpret_cast<float2*>(scratch);
   const unsigned per_window = (unsigned)(g.n_levels * kPlTilesPerLevel);
   const unsigned magic = (unsigned)((0x100000000ull + per_window - 1) / per_window);
-  const bool fused = zp != nullptr && !no_fuse && 2 * n_windows >= n_cu;
-  auto grid_for = [&](int waves) {
-    if (fused) return n_windows < n_cu ? n_windows : n_cu;
-    const int grid = (tasks + waves - 1) / waves;
-    return grid > n_cu ? n_cu : grid;
-  };
-#define BP_PL_FB_LAUNCH(T, A, W)                                                                                         \
-  do {                                                                                                                   \
-    if (fused)                                                                                                           \
-      hipLaunchKernelGGL((cqt_filterbank_planes_kernel<T, A, true>), dim3(grid_for(W)), dim3(T), 0, stream, pl, audio,   \
-                         audio_stride, bf, sqrt_len, lp, mm, zp, n_windows, kc, g, magic);                               \
-    else                                                                                                                 \
-      hipLaunchKernelGGL((cqt_filterbank_planes_kernel<T, A, false>), dim3(grid_for(W)), dim3(T), 0, stream, pl, audio,  \
-                         audio_stride, bf, sqrt_len, lp, mm, zp, n_windows, kc, g, magic);                               \
-  } while (0)
-  if (variant == 11)
-    BP_PL_FB_LAUNCH(704, 7, 11);
-  else if (variant == 12)
-    BP_PL_FB_LAUNCH(768, 7, 12);
-  else
-    BP_PL_FB_LAUNCH(1024, 3, 16);
+  const bool fused = zp != nullptr && 2 * n_windows >= n_cu;
+  constexpr int kThreads = 1024, kApf = 3;
+  int grid;
+  if (fused) {
+    grid = n_windows < n_cu ? n_windows : n_cu;
+  } else {
+    grid = (tasks + kThreads / 64 - 1) / (kThreads / 64);
+    if (grid > n_cu) grid = n_cu;
+  }
+#define BP_PL_FB_LAUNCH(F, E)                                                                                           \
+  hipLaunchKernelGGL((cqt_filterbank_planes_kernel<kThreads, kApf, F, E>), dim3(grid), dim3(kThreads), 0, stream, pl,   \
+                     audio, audio_stride, bf, bk, lp, mm, zp, n_windows, kc, g, magic)
+  if (fused) {
+    if (ext) BP_PL_FB_LAUNCH(true, true); else BP_PL_FB_LAUNCH(true, false);
+  } else {
+    if (ext) BP_PL_FB_LAUNCH(false, true); else BP_PL_FB_LAUNCH(false, false);
+  }
 #undef BP_PL_FB_LAUNCH
   return fused;
 }
+
+#ifdef PL_PROF
+extern "C" int bp_debug_pl_prof(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pl_prof), sizeof(g_pl_prof));
+}
+#endif
 
 }  // namespace bp

@@ -183,7 +183,7 @@ void notes_csv(const bp_note_event* ev, int64_t n, const int32_t* bends, std::st
     out += std::to_string(ev[i].pitch_midi);
     out += ',';
     out += std::to_string(velocity_of(ev[i].amplitude));
-    for (int32_t k = 0; k < ev[i].n_bends; ++k) {
+    for (int32_t k = 0; bends && k < ev[i].n_bends; ++k) {  // bends may be NULL (no pitch bends), as in notes_midi
       out += ',';
       out += std::to_string(bends[ev[i].bend_offset + k]);
     }
@@ -447,19 +447,33 @@ int wav_pcm_format(const WavInfo& w) {
   return w.bits == 32 ? BP_PCM_F32 : BP_PCM_F64;
 }
 
+// inference.py:401-404: never overwrite.  O_EXCL makes the existence check and the creation one step (two processes
+// writing into the same directory cannot both win), and a short or failed write removes the partial file, so that a retry
+// does not find a corpse and report "already exists".
 bool write_new_file(const std::string& path, const void* data, size_t n) {
-  struct stat st;
-  if (stat(path.c_str(), &st) == 0) {  // inference.py:401-404: never overwrite
-    g_file_error = path + " already exists and would be overwritten.";
+  const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_CLOEXEC, 0666);
+  if (fd < 0) {
+    g_file_error = errno == EEXIST ? path + " already exists and would be overwritten." : "cannot write " + path + ": " + std::strerror(errno);
     return false;
   }
-  FILE* f = std::fopen(path.c_str(), "wb");
-  if (!f || (n && std::fwrite(data, 1, n, f) != n)) {
-    if (f) std::fclose(f);
-    g_file_error = "cannot write " + path;
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  size_t done = 0;
+  while (done < n) {
+    const ssize_t w = write(fd, p + done, n - done);
+    if (w < 0 && errno == EINTR) continue;
+    if (w <= 0) {
+      g_file_error = "cannot write " + path + ": " + std::strerror(errno);
+      close(fd);
+      unlink(path.c_str());
+      return false;
+    }
+    done += (size_t)w;
+  }
+  if (close(fd) != 0) {
+    g_file_error = "cannot write " + path + ": " + std::strerror(errno);
+    unlink(path.c_str());
     return false;
   }
-  std::fclose(f);
   return true;
 }
 
@@ -581,6 +595,17 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
       g_file_error = "bp_transcribe_files: null handle";
       return BP_ERR_INVALID_ARG;
     }
+  // every lane must be of the same mode: a file's output buffers are sized from handles[0] and the device call runs on
+  // whichever lane is free (a default and an EXT_CQT_44K handle would disagree on rate and frame count)
+  for (int i = 1; i < n_handles; ++i) {
+    const int64_t probe = 1 << 20;
+    if (bp_handle_sample_rate(handles[i]) != bp_handle_sample_rate(handles[0]) ||
+        bp_handle_track_n_frames(handles[i], probe) != bp_handle_track_n_frames(handles[0], probe) ||
+        bp_handle_resampled_length(handles[i], probe, 44100) != bp_handle_resampled_length(handles[0], probe, 44100)) {
+      g_file_error = "bp_transcribe_files: the handles are of different modes (sample rate / frame geometry)";
+      return BP_ERR_INVALID_ARG;
+    }
+  }
   struct stat st;
   if (stat(out_dir, &st) != 0 || !S_ISDIR(st.st_mode)) {
     g_file_error = std::string(out_dir) + " is not a directory.";

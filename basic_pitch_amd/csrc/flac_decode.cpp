@@ -129,7 +129,10 @@ struct BitReader {
           const int need = lz + 1 + k;
           if (need > cnt) break;
           const uint64_t r = k ? (buf << (lz + 1)) >> (64 - k) : 0;
-          buf <<= need;
+          // a code may fill the register exactly (need == cnt == 64: k = 0 and 63 zeros, after a byte-aligned load or a
+          // refill from a multiple of 8): `buf <<= 64` is undefined — on x86 a no-op that would leave the stop bit in the
+          // register, to be OR-ed onto the next refill — so the shift goes in two steps (need >= 1 always)
+          buf = (buf << (need - 1)) << 1;
           cnt -= need;
           const uint64_t v = ((uint64_t)lz << k) | r;
           out[j] = (int64_t)(v >> 1) ^ -(int64_t)(v & 1);

@@ -255,7 +255,7 @@ void launch_note_march(const float* contour, const void* wfrag, const float* wf3
   NoteMarchParams p{static_cast<const uint4*>(wfrag), wf32, contour, note, n_windows * chunks * kNmStrips, chunks};
   if (p.n_tasks <= 0) return;
   const int grid = (p.n_tasks + kNmWaves - 1) / kNmWaves;
-  static const bool prof = getenv("BP_BRANCH_PROF") != nullptr;
+  static const bool prof = ab_env("BP_BRANCH_PROF") != nullptr;
   if (prof) {  // tools only
     int resident = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, note_march_kernel<true>, 64 * kNmWaves, 0);

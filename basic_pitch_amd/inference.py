@@ -403,32 +403,45 @@ def unwrap_output(
 
 # `predict(path)` with a model PATH loads the model on every call in the reference (inference.py:291-292 -> Model(...)).
 # Loading is 60 ms here (parsing, packing the operand fragments, 0.8 GB of device buffers) against ~1 ms for the
-# reference's 10-second clip itself, so a loaded model is kept per (file identity, calling thread) and reused: the handle
-# is stateful and not for two threads at once, hence one per thread.
-_MODEL_CACHE: "Dict[Tuple[Any, ...], Model]" = {}
-_MODEL_CACHE_LOCK = threading.Lock()
-_MODEL_CACHE_MAX = 8
+# reference's 10-second clip itself, so a loaded model is kept and reused — PER THREAD (the handle is stateful and not for
+# two threads at once) and in thread-local storage, so that the models of a thread are released when the thread ends
+# (a process-wide table keyed by thread id kept up to 8 x 0.8 GB alive for threads long gone).  At most
+# _MODEL_CACHE_MAX models per thread, oldest evicted first; clear_model_cache() drops the calling thread's.
+_MODEL_CACHE_MAX = 2
+
+
+class _ThreadModels(threading.local):
+    def __init__(self) -> None:
+        self.models: "Dict[Tuple[Any, ...], Model]" = {}
+
+
+_MODEL_CACHE = _ThreadModels()
+
+
+def clear_model_cache() -> None:
+    """Forget the models `predict(path)` / `run_inference(path)` keep loaded for the calling thread (their device
+    buffers are freed when nobody else holds the Model)."""
+    _MODEL_CACHE.models.clear()
 
 
 def _model_from(model_or_model_path) -> Any:
-    """A Model (or anything shaped like one) as it is; a path as the cached Model loaded from that file."""
+    """A Model (or anything shaped like one) as it is; a path as the calling thread's cached Model loaded from that file."""
     if not isinstance(model_or_model_path, (str, os.PathLike)):
         return model_or_model_path
     try:
         real = os.path.realpath(os.fspath(model_or_model_path))
         st = os.stat(real)
-        key = (real, st.st_mtime_ns, st.st_size, threading.get_ident())
+        key = (real, st.st_mtime_ns, st.st_size)
     except OSError:
         return Model(model_or_model_path)  # raises what loading a missing file raises
-    with _MODEL_CACHE_LOCK:
-        model = _MODEL_CACHE.get(key)
-        if model is not None and model._handle.value:
-            return model
+    models = _MODEL_CACHE.models
+    model = models.get(key)
+    if model is not None and model._handle.value:
+        return model
     model = Model(model_or_model_path)
-    with _MODEL_CACHE_LOCK:
-        while len(_MODEL_CACHE) >= _MODEL_CACHE_MAX:
-            _MODEL_CACHE.pop(next(iter(_MODEL_CACHE)))  # oldest first; the handle is freed when nobody holds the Model
-        _MODEL_CACHE[key] = model
+    while len(models) >= _MODEL_CACHE_MAX:
+        models.pop(next(iter(models)))  # oldest first; the handle is freed when nobody holds the Model
+    models[key] = model
     return model
 
 

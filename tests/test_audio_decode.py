@@ -122,3 +122,22 @@ def test_flac_every_truncation_point_near_the_end_is_an_error(tmp_path):
         p.write_bytes(data[: len(data) - cut])
         with pytest.raises(ValueError):
             audio.read_audio(p)
+
+
+def test_flac_rice_code_that_fills_the_bit_register_exactly(tmp_path):
+    """A 64-bit Rice code (k = 0, residual -32: 63 zeros and the stop bit) at a byte-aligned position: the register-resident
+    Rice reader then holds exactly the code (need == cnt == 64) and must not shift by the register's width (round-4
+    advisor finding: `buf <<= 64` is undefined, on x86 a no-op, and every later residual of the partition was wrong)."""
+    from basic_pitch_amd import audio
+
+    n = 192
+    r = np.zeros(n, np.int64)
+    # after the 64-bit code sixty 1-bit codes, then 00001 across the next register's last bit: the stale stop bit that the
+    # no-op shift leaves in the register would be OR-ed onto that 0
+    r[0], r[61], r[100], r[150] = -32, 2, -32, 1
+    pcm = (r * 64)[:, None]  # six wasted bits: 8 + 6 header bits + 10 residual-header bits put the first code on a byte
+    data = FW.encode(pcm, 22050, 16, blocksize=n, plan=lambda fi: dict(kind="fixed0", porder=0, rice2=False, escape=False))
+    p = tmp_path / "r64.flac"
+    p.write_bytes(data)
+    y, sr = audio.read_audio(p)
+    assert sr == 22050 and np.array_equal(y[:, 0], (pcm[:, 0] / 32768.0).astype(np.float32))

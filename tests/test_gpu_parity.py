@@ -324,6 +324,72 @@ def test_extended_cqt_44k_mode(weights):
     m.close()
 
 
+@pytest.mark.parametrize("mode,batch", [("bf16_weights", 1024), ("ext_cqt_44k", 512)])
+def test_modes_are_batch_invariant_at_their_bench_batches(mode, batch):
+    """BASELINE.json configs[3] / configs[4] are benchmarked at B = 1024 / 512 and parity-tested above at a handful of
+    windows: a window's result must not depend on which of the two handles computed it (the small one takes the strided
+    filterbank + zpack launches and the wide decimators, the big one the per-window fused kernels; chunk counts of the
+    marches differ).  Bit-equality of probe windows between `max_windows = 8` and the bench-size handle, as
+    test_batch_invariance_and_chunking holds for the default mode."""
+    from basic_pitch_amd import Model
+
+    ext = mode == "ext_cqt_44k"
+    n_s = O.EXT_AUDIO_N_SAMPLES if ext else O.AUDIO_N_SAMPLES
+    rng = np.random.default_rng(31)
+    x = rng.uniform(-1, 1, (batch, n_s)).astype(np.float32)
+    x[5] = 0.0                                      # a silent window (range 0: divide_no_nan)
+    t = np.arange(n_s) / (44100.0 if ext else 22050.0)
+    x[6] = (0.5 * np.sin(2 * np.pi * 440.0 * t) + 0.01 * rng.standard_normal(n_s)).astype(np.float32)
+    x[batch - 1] *= 0.01
+    idx = [0, 5, 6, batch // 2, batch - 1]
+    big = Model(max_windows=batch, **{mode: True})
+    a = big.predict(x)
+    big.close()
+    small = Model(max_windows=8, **{mode: True})
+    b = small.predict(x[idx])
+    c = small.predict(x[: 3 * 8 + 5])               # four chunks incl. a ragged tail
+    small.close()
+    for k in a:
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k][idx], b[k]), (mode, k)
+        assert np.array_equal(a[k][: 3 * 8 + 5], c[k]), (mode, k)
+    # the silent window is the constant map of divide_no_nan in every mode: away from the window's ends (the
+    # convolutions' zero padding in time) all frames are alike
+    for k in a:
+        assert np.ptp(a[k][5][16:156], axis=0).max() <= 1e-6, (mode, k)
+
+
+def test_integration_md_binding_runs_verbatim(weights):
+    """INTEGRATION.md section 1 is the ctypes stub a maintainer of the reference would paste into inference.py: the code
+    block is executed here exactly as printed, against the built library and the shipped weights blob, and must return
+    what Model.predict returns (same bits: same library, same entry point)."""
+    import re
+
+    from basic_pitch_amd import Model, build
+
+    md = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "INTEGRATION.md")).read()
+    sec = md[md.index("## 1. The binding"):md.index("## 2.")]
+    (code,) = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#1", "exec"), ns)
+    blob = os.path.join(os.path.dirname(build.LIB_PATH), "..", "assets", "nmp_weights.bin")
+    stub = ns["_MI355X"](build.build_library(), blob, 0, 16)
+    x = make_windows("uniform", 3, seed=41)
+    note, onset, contour = stub.run(x[:, :, None])   # the reference's (n, 43844, 1)
+    m = Model(max_windows=16)
+    ref = m.predict(x)
+    m.close()
+    assert note.flags.writeable and note.flags.c_contiguous and note.dtype == np.float32
+    assert np.array_equal(note, ref["note"]) and np.array_equal(onset, ref["onset"]) and np.array_equal(contour, ref["contour"])
+    r64 = O.forward(x, weights, np.float64)
+    assert np.abs(note - r64["note"]).max() <= 2e-4
+    # an unloadable model is a ValueError, as for the reference's other loaders (inference.py:148-154)
+    bad = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conftest.py")
+    with pytest.raises(ValueError):
+        ns["_MI355X"](build.build_library(), bad)
+    del stub
+
+
 def _noise_aware(got, r32, r64, floor=1e-4, factor=2.0):
     """|hip - fp64| <= max(1e-4, 2 * |fp32 oracle - fp64|), per tensor (SURVEY.md §8c Tier A).
 
@@ -689,53 +755,78 @@ def test_predict_parameter_sweeps_of_the_reference():
 
 def test_model_path_is_loaded_once_per_thread():
     """predict(path) with a model PATH (the reference's default call): the loaded model is kept and reused by later calls
-    of the same thread, another thread gets its own (a handle is not for two threads at once), same results either way."""
+    of the same thread, another thread gets its own (a handle is not for two threads at once) — which dies with that
+    thread —, same results either way."""
+    import gc
     import threading
+    import weakref
 
     from basic_pitch_amd import inference as inf
 
     wav = os.path.join(GOLDEN, "vocadito_10.wav")
-    inf._MODEL_CACHE.clear()
+    inf.clear_model_cache()
     a, _, ev_a = inf.predict(wav)
-    assert len(inf._MODEL_CACHE) == 1
-    first = next(iter(inf._MODEL_CACHE.values()))
+    assert len(inf._MODEL_CACHE.models) == 1
+    first = next(iter(inf._MODEL_CACHE.models.values()))
     b, _, ev_b = inf.predict(wav, inf.ICASSP_2022_MODEL_PATH)
-    assert len(inf._MODEL_CACHE) == 1 and next(iter(inf._MODEL_CACHE.values())) is first
+    assert len(inf._MODEL_CACHE.models) == 1 and next(iter(inf._MODEL_CACHE.models.values())) is first
     got = {}
 
     def other():
         got["out"] = inf.predict(wav)
+        (theirs,) = inf._MODEL_CACHE.models.values()
+        got["is_own"] = theirs is not first
+        got["ref"] = weakref.ref(theirs)
 
     t = threading.Thread(target=other)
     t.start()
     t.join()
-    assert len(inf._MODEL_CACHE) == 2
+    assert got["is_own"] and len(inf._MODEL_CACHE.models) == 1
+    del t
+    gc.collect()
+    assert got["ref"]() is None  # the other thread's model went with the thread (0.8 GB of device buffers)
     for k in a:
         assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], got["out"][0][k]), k
     assert len(ev_a) == len(ev_b) == len(got["out"][2]) == 28
     with pytest.raises(ValueError):
         inf.predict(wav, os.path.join(GOLDEN, "no_such_model.onnx"))
-    inf._MODEL_CACHE.clear()
+    inf.clear_model_cache()
+    assert len(inf._MODEL_CACHE.models) == 0
 
 
-def test_resample_kernels_agree_bit_for_bit(monkeypatch):
+def _ab_env(**switches):
+    """Environment of a subprocess that runs an A/B variant of a kernel: the switches (BP_ONSET, BP_CONV1, BP_RESAMPLE, ...)
+    only exist in the A/B library (build.py: build_library(ab=True), -DBP_AB_KERNELS), which is built here if the tree
+    does not hold a current one; with no switches, the product library."""
+    e = dict(os.environ)
+    for k in ("BASIC_PITCH_AMD_LIB", "BP_ONSET", "BP_CONV1", "BP_RIM", "BP_RESAMPLE", "BP_CONTOUR_PARTS"):
+        e.pop(k, None)
+    if switches:
+        from basic_pitch_amd import build as B
+
+        e["BASIC_PITCH_AMD_LIB"] = B.build_library(ab=True)
+        e.update(switches)
+    return e
+
+
+def test_resample_kernels_agree_bit_for_bit(tmp_path):
     """The resampler's three kernels — one thread per output, the LDS-tiled one, the 2 : 1 register-window one — add the
     same products in the same order: identical float32 signals, at the signal's edges too (a 2 : 1 length that is not a
-    multiple of the block's 1024 outputs, a signal shorter than the filter)."""
-    from basic_pitch_amd import Model
+    multiple of the block's 1024 outputs, a signal shorter than the filter).  One process per kernel: the product library
+    (automatic choice) and the A/B library with BP_RESAMPLE=plain / tiled."""
+    import subprocess
+    import sys
 
-    rng = np.random.default_rng(8)
-    cases = [(44100, 2, 150001), (44100, 1, 2 * 1024 * 7), (44100, 1, 300), (88200, 1, 40000), (48000, 2, 9600), (16000, 1, 4000)]
-    sig = [rng.uniform(-1, 1, (n, ch)).astype(np.float32) for _, ch, n in cases]
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "experiments", "resample_ab.py")
     got = {}
     for mode in ("plain", "tiled", "auto"):
-        monkeypatch.setenv("BP_RESAMPLE", mode)
-        m = Model(max_windows=8)
-        got[mode] = [m.resample(x, sr) for x, (sr, _, _) in zip(sig, cases)]
-        m.close()
-    for i, c in enumerate(cases):
+        out = str(tmp_path / f"{mode}.npz")
+        subprocess.run([sys.executable, tool, out], check=True, timeout=600,
+                       env=_ab_env() if mode == "auto" else _ab_env(BP_RESAMPLE=mode))
+        got[mode] = np.load(out)
+    for k in got["plain"].files:
         for mode in ("tiled", "auto"):
-            assert np.array_equal(got["plain"][i].view(np.uint32), got[mode][i].view(np.uint32)), (c, mode)
+            assert np.array_equal(got["plain"][k].view(np.uint32), got[mode][k].view(np.uint32)), (k, mode)
 
 
 def test_predict_note_events_match_reference_golden(tmp_path):
@@ -919,11 +1010,7 @@ def test_onset_march_equals_workgroup_kernel(tmp_path):
     outs = {}
     for name, env in (("march16", {}), ("march32", {"BP_ONSET": "march32"}), ("ring", {"BP_ONSET": "ring"})):
         out = str(tmp_path / f"{name}.npy")
-        e = dict(os.environ, **env)
-        e.pop("BASIC_PITCH_AMD_LIB", None)
-        if not env:
-            e.pop("BP_ONSET", None)
-        subprocess.run([sys.executable, tool, out], check=True, env=e, timeout=300)
+        subprocess.run([sys.executable, tool, out], check=True, env=_ab_env(**env), timeout=600)
         outs[name] = np.load(out)
     assert np.isfinite(outs["march16"]).all()
     assert np.array_equal(outs["march32"], outs["ring"])
@@ -944,11 +1031,7 @@ def test_contour_march_equals_round_kernel(tmp_path):
     outs = {}
     for name, env in (("march", {}), ("rounds", {"BP_CONV1": "rounds"})):
         out = str(tmp_path / f"{name}.npy")
-        e = dict(os.environ, **env)
-        e.pop("BASIC_PITCH_AMD_LIB", None)
-        if not env:
-            e.pop("BP_CONV1", None)
-        subprocess.run([sys.executable, tool, out], check=True, env=e, timeout=300)
+        subprocess.run([sys.executable, tool, out], check=True, env=_ab_env(**env), timeout=600)
         outs[name] = np.load(out)
     assert np.isfinite(outs["march"]).all()
     d = np.abs(outs["march"] - outs["rounds"]).max()

@@ -248,3 +248,44 @@ def test_model_blob_is_extracted_from_the_reference_onnx_at_load(tmp_path):
         weights.load_model_blob(trunc)
     shutil.copy(REF_ONNX, tmp_path / "nmp.onnx")
     assert weights.load_model_blob(tmp_path / "nmp.onnx") == shipped
+
+
+def test_no_kernel_of_the_product_library_uses_scratch():
+    """Every kernel the product library carries fits its registers: no spill, `.private_segment_fixed_size` 0 (round-4
+    review: the two CQT kernels were the only default-path kernels with scratch).  Read from the code objects inside the
+    built library — what will actually run — not from a recompile."""
+    import sys
+
+    from basic_pitch_amd import build
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_resources import kernel_resources
+
+    rows = kernel_resources(build.build_library())
+    assert len(rows) >= 40, len(rows)
+    names = " ".join(r["name"] for r in rows)
+    for must in ("pl_pyramid_window_kernel", "cqt_filterbank_planes_kernel", "contour_conv1_march_kernel",
+                 "contour_conv1_rim_kernel", "contour_conv2_kernel", "note_march_kernel", "onset_march16_kernel"):
+        assert must in names, must
+    bad = [(r["name"], r["scratch"], r["vgpr_spill"], r["sgpr_spill"]) for r in rows
+           if r["scratch"] or r["vgpr_spill"] or r["sgpr_spill"]]
+    assert not bad, bad
+    for r in rows:
+        assert r["lds"] <= 160 * 1024, r
+
+
+def test_product_library_reads_no_behaviour_switch_from_the_environment():
+    """The BP_* switches and the superseded kernels they select live in the A/B library only (build_library(ab=True),
+    -DBP_AB_KERNELS): the product library does not even import getenv, and its sources call it in one place, the A/B gate."""
+    import subprocess
+
+    from basic_pitch_amd import build
+
+    und = subprocess.run(["nm", "-D", "--undefined-only", build.build_library()], capture_output=True, text=True).stdout
+    assert "getenv" not in und
+    n = 0
+    for f in os.listdir(build.CSRC):
+        n += len(re.findall(r"\bgetenv\s*\(", open(os.path.join(build.CSRC, f)).read()))
+    assert n <= 2, n
+    for src in build.AB_SOURCES:
+        assert src not in build.SOURCES
