@@ -100,7 +100,8 @@ class bp_transcribe_params(C.Structure):
         ("save_midi", C.c_int32),
         ("save_notes", C.c_int32),
         ("threads", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("host_decode", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -165,6 +166,9 @@ EXPORTED_SYMBOLS = [
     "bp_device_count",
     "bp_note_params_default",
     "bp_notes_decode",
+    "bp_note_candidates",
+    "bp_infer_pcm_raw_candidates",
+    "bp_notes_decode_candidates",
     "bp_notes_last_error",
     "bp_flac_info",
     "bp_flac_decode",
@@ -271,6 +275,16 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         vp, vp, vp, i64, C.POINTER(bp_note_params), vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64)
     ]
     lib.bp_notes_decode.restype = C.c_int
+    lib.bp_note_candidates.argtypes = [vp, vp, vp, vp, i64, C.POINTER(bp_note_params), C.c_int, vp, vp, vp, C.POINTER(C.c_int)]
+    lib.bp_note_candidates.restype = C.c_int
+    lib.bp_infer_pcm_raw_candidates.argtypes = [
+        vp, vp, C.c_int, i64, C.c_int, C.c_int, C.POINTER(bp_note_params), vp, vp, vp, C.POINTER(C.c_int)
+    ]
+    lib.bp_infer_pcm_raw_candidates.restype = C.c_int
+    lib.bp_notes_decode_candidates.argtypes = [
+        vp, vp, vp, i64, C.POINTER(bp_note_params), vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64)
+    ]
+    lib.bp_notes_decode_candidates.restype = C.c_int
     lib.bp_notes_last_error.argtypes = []
     lib.bp_notes_last_error.restype = C.c_char_p
     pi = C.POINTER(C.c_int)

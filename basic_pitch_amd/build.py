@@ -31,6 +31,7 @@ SOURCES = [
     "conv_branch.hip",
     "note_march.hip",
     "onset_march16.hip",
+    "note_device.hip",
     "audio_ingest.hip",
     "note_decode.cpp",
     "flac_decode.cpp",

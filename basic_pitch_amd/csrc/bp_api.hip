@@ -93,6 +93,9 @@ void launch_contour_conv2(const float* c1, const float* w2, float bias, float* c
                           hipStream_t stream);
 void launch_note_march(const float* contour, const void* wfrag, const float* wf32, float* note, int n_windows,
                        bool weights_have_lo, hipStream_t stream);
+void launch_note_candidates(float* note, float* onset, const float* contour, int64_t T, int lo, int hi, int infer,
+                            double onset_thresh, const void* tab, const double* gauss, void* stats, uint8_t* bits,
+                            int8_t* bend, hipStream_t s);
 void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, const void* wmx,
                          float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
 // the onset branch: the wave-private march on 16x16x32; the workgroup kernel for the fp8-correction mode (it carries the
@@ -254,6 +257,11 @@ struct bp_context {
   ResamplePlan plan{};
   float* track_out = nullptr;  // [T, 88+88+264] staging when outputs are host pointers
   int64_t track_out_cap = 0;
+  // device-side note candidates (note_device.hip): bitmap [T][11] + bend map [T][88] (bytes), stats, the bend tables
+  float* nd_buf = nullptr;
+  int64_t nd_cap = 0;          // floats
+  float* nd_tables = nullptr;  // [88] int4 windows, [51] double Gaussian, then the stats record
+  float* nd_stats_host = nullptr;  // page-locked copy of the stats record
 
   // stage timing: a ring of event sets, one per chunk, averaged by bp_get_stage_ms
   static constexpr int kTimedRing = 128;
@@ -770,7 +778,7 @@ int free_all(bp_handle h) {
   float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->d_pl_bin_k, h->planes, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->d_onset_w16, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wmarch, h->d_d1_wrim, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
-                   h->track_out, h->fb_scratch, h->pcm_dev, h->mono_dev, h->res_dev, reinterpret_cast<float*>(h->taps_dev)};
+                   h->track_out, h->nd_buf, h->nd_tables, h->fb_scratch, h->pcm_dev, h->mono_dev, h->res_dev, reinterpret_cast<float*>(h->taps_dev)};
   for (float* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->mm) (void)hipFree(h->mm);
@@ -778,6 +786,7 @@ int free_all(bp_handle h) {
     for (auto& row : h->ev)
       for (auto& e : row) (void)hipEventDestroy(e);
   if (h->done) (void)hipEventDestroy(h->done);
+  if (h->nd_stats_host) (void)hipHostFree(h->nd_stats_host);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   return BP_OK;
 }
@@ -1376,13 +1385,16 @@ static int wait_stream(bp_handle h) {
   return BP_OK;
 }
 
+// out_kind kTrackOutInternal: the un-overlapped maps stay in h->track_out ([T][88] note, [T][88] onset, [T][264] contour) and
+// the call returns with the work queued on the handle's stream (the caller goes on with device work on them)
+constexpr int kTrackOutInternal = 100;
 static int track_core(bp_handle h, const float* d_samples, int64_t n_samples, float* note, float* onset,
                       float* contour, int out_kind) {
   hipStream_t s = h->stream;
   const int64_t n_win = h_track_n_windows(h, n_samples);
   const int64_t T = h_track_n_frames(h, n_samples);
   float *d_note = note, *d_onset = onset, *d_contour = contour;
-  if (out_kind == BP_MEM_HOST) {
+  if (out_kind == BP_MEM_HOST || out_kind == kTrackOutInternal) {
     const int64_t need = T * (88 + 88 + 264);
     if (need > h->track_out_cap) {
       if (h->track_out) BP_HIP(hipFree(h->track_out));
@@ -1407,6 +1419,7 @@ static int track_core(bp_handle h, const float* d_samples, int64_t n_samples, fl
     }
   }
   BP_HIP(hipGetLastError());
+  if (out_kind == kTrackOutInternal) return BP_OK;
   if (out_kind == BP_MEM_HOST && T > 0) {
     BP_HIP(hipMemcpyAsync(note, d_note, (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
     BP_HIP(hipMemcpyAsync(onset, d_onset, (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
@@ -1674,6 +1687,100 @@ int bp_infer_pcm_raw(bp_handle h, const void* pcm, int format, int64_t n_frames,
 int bp_infer_pcm(bp_handle h, const float* pcm, int64_t n_frames, int channels, int sample_rate, float* note,
                  float* onset, float* contour, int mem_kind) {
   return bp_infer_pcm_raw(h, pcm, BP_PCM_F32, n_frames, channels, sample_rate, note, onset, contour, mem_kind);
+}
+
+// ---- device-side note candidates (note_device.hip): what note decoding needs of a track's posteriorgrams
+extern "C" void bp_internal_bend_tables(int32_t* tab, double* gauss);
+extern "C" void bp_internal_freq_limits(const bp_note_params* prm, int* lo, int* hi);
+
+// d_note / d_onset / d_contour: device maps of T frames (note / onset are modified when the parameters set a frequency
+// range, like constrain_frequency does).  Outputs: host buffers.
+static int candidates_core(bp_handle h, float* d_note, float* d_onset, const float* d_contour, int64_t T,
+                           const bp_note_params* prm, float* note_out, uint8_t* cand_out, int8_t* bend_out, int* status) {
+  hipStream_t s = h->stream;
+  *status = 0;
+  if (T <= 0) return wait_stream(h);
+  constexpr size_t kTabBytes = 88 * 16, kGaussBytes = 51 * 8, kStatsBytes = 16;
+  if (!h->nd_tables) {
+    std::vector<float> raw((kTabBytes + kGaussBytes + kStatsBytes) / 4, 0.f);
+    bp_internal_bend_tables(reinterpret_cast<int32_t*>(raw.data()), reinterpret_cast<double*>(raw.data() + kTabBytes / 4));
+    int rc = upload(h, raw, &h->nd_tables);
+    if (rc) return rc;
+    BP_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->nd_stats_host), kStatsBytes, hipHostMallocPortable));
+  }
+  const int64_t bits_bytes = (T * 11 + 15) & ~(int64_t)15, bend_bytes = T * 88;
+  int rc = grow(h, &h->nd_buf, &h->nd_cap, (bits_bytes + bend_bytes + 3) / 4);
+  if (rc) return rc;
+  uint8_t* d_bits = reinterpret_cast<uint8_t*>(h->nd_buf);
+  int8_t* d_bend = reinterpret_cast<int8_t*>(d_bits + bits_bytes);
+  char* tables = reinterpret_cast<char*>(h->nd_tables);
+  void* d_stats = tables + kTabBytes + kGaussBytes;
+  int lo = 0, hi = 88;
+  bp_internal_freq_limits(prm, &lo, &hi);
+  const bool want_bends = prm->include_pitch_bends != 0 && bend_out != nullptr;
+  launch_note_candidates(d_note, d_onset, d_contour, T, lo, hi, prm->infer_onsets != 0, prm->onset_threshold, tables,
+                         reinterpret_cast<const double*>(tables + kTabBytes), d_stats, d_bits, want_bends ? d_bend : nullptr, s);
+  BP_HIP(hipGetLastError());
+  BP_HIP(hipMemcpyAsync(h->nd_stats_host, d_stats, kStatsBytes, hipMemcpyDeviceToHost, s));
+  BP_HIP(hipMemcpyAsync(note_out, d_note, (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
+  BP_HIP(hipMemcpyAsync(cand_out, d_bits, (size_t)T * 11, hipMemcpyDeviceToHost, s));
+  if (want_bends) BP_HIP(hipMemcpyAsync(bend_out, d_bend, (size_t)bend_bytes, hipMemcpyDeviceToHost, s));
+  rc = wait_stream(h);
+  if (rc) return rc;
+  const int nan_flag = reinterpret_cast<const int*>(h->nd_stats_host)[1];
+  // numpy's rules for NaN cells, and an onset threshold <= 0 (every cell that is not a peak qualifies), need the maps
+  // themselves: the host decoder takes over (bp_infer_* + bp_notes_decode)
+  if (nan_flag || !(prm->onset_threshold > 0.0)) *status = 1;
+  return BP_OK;
+}
+
+int bp_note_candidates(bp_handle h, const float* note, const float* onset, const float* contour, int64_t n_frames,
+                       const bp_note_params* params, int mem_kind, float* note_out, uint8_t* cand_bits, int8_t* bend_map,
+                       int* status) {
+  if (!h) return BP_ERR_INVALID_ARG;
+  if (!params || !status || n_frames < 0 || (mem_kind != BP_MEM_HOST && mem_kind != BP_MEM_DEVICE) ||
+      (n_frames > 0 && (!note || !onset || !contour || !note_out || !cand_bits))) {
+    h->err = "bp_note_candidates: null pointer, negative frame count or bad mem_kind";
+    return BP_ERR_INVALID_ARG;
+  }
+  BP_HIP(hipSetDevice(h->device));
+  const int64_t T = n_frames;
+  // a private copy on the device: the frequency limits are applied in place
+  int rc = grow(h, &h->track_out, &h->track_out_cap, T * (88 + 88 + 264));
+  if (rc) return rc;
+  float *d_note = h->track_out, *d_onset = d_note + T * 88, *d_contour = d_onset + T * 88;
+  const hipMemcpyKind kind = mem_kind == BP_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  if (T > 0) {
+    BP_HIP(hipMemcpyAsync(d_note, note, (size_t)T * 88 * 4, kind, h->stream));
+    BP_HIP(hipMemcpyAsync(d_onset, onset, (size_t)T * 88 * 4, kind, h->stream));
+    BP_HIP(hipMemcpyAsync(d_contour, contour, (size_t)T * 264 * 4, kind, h->stream));
+  }
+  return candidates_core(h, d_note, d_onset, d_contour, T, params, note_out, cand_bits, bend_map, status);
+}
+
+int bp_infer_pcm_raw_candidates(bp_handle h, const void* pcm, int format, int64_t n_frames, int channels, int sample_rate,
+                                const bp_note_params* params, float* note_out, uint8_t* cand_bits, int8_t* bend_map,
+                                int* status) {
+  if (!h) return BP_ERR_INVALID_ARG;
+  if (!params || !status) {
+    h->err = "bp_infer_pcm_raw_candidates: null params / status";
+    return BP_ERR_INVALID_ARG;
+  }
+  const float* d = nullptr;
+  int64_t n = 0;
+  int rc = ingest(h, pcm, format, n_frames, channels, sample_rate, BP_MEM_HOST, &d, &n);
+  if (rc) return rc;
+  *status = 0;
+  const int64_t T = h_track_n_frames(h, n);
+  if (h_track_n_windows(h, n) == 0 || T == 0) return wait_stream(h);
+  if (!note_out || !cand_bits) {
+    h->err = "bp_infer_pcm_raw_candidates: null output pointer";
+    return BP_ERR_INVALID_ARG;
+  }
+  rc = track_core(h, d, n, nullptr, nullptr, nullptr, kTrackOutInternal);
+  if (rc) return rc;
+  float *d_note = h->track_out, *d_onset = d_note + T * 88, *d_contour = d_onset + T * 88;
+  return candidates_core(h, d_note, d_onset, d_contour, T, params, note_out, cand_bits, bend_map, status);
 }
 
 void* bp_host_alloc(size_t bytes) {

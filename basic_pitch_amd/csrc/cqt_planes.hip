@@ -306,6 +306,29 @@ __device__ __forceinline__ void pl_split8(const float4& a, const float4& c, uint
 // second copy into an LDS image of the level (`mir_hi` = its sample 0, lo plane `mir_stride` elements behind; no padding
 // there; null = none), and — the tiles that hold samples 1..128 and L-129..L-2 — the level's reflect padding
 // (nnaudio.py:300-301).  Shared by every decimator kernel: a level's bits do not depend on which kernel made it.
+// 8 / 16 bytes to global memory that only a LATER launch reads (planes, zp).  -DPL_STORE_SC1 (tools: A/B): write-through
+// stores that do not leave the line in the XCD's L2 (MI355X_MICROARCH.md, "stores of each flavour").
+__device__ __forceinline__ void pl_store8(void* p, uint2 v) {
+#ifdef PL_STORE_SC1
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v.x | ((unsigned long long)v.y << 32),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *reinterpret_cast<uint2*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void pl_store16(void* p, uint4 v) {
+#ifdef PL_STORE_SC1
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+  const u32x4 d = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+#else
+  *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+
+// TAIL = false: the level's reflect padding is written by somebody else (pl_reflect_pad_from_lds); the level's last,
+// partial group of four is stored here either way.
+template <bool TAIL = true>
 __device__ __forceinline__ void pl_tile_store(const f32x4& hh, const f32x4& xx, uint16_t* __restrict__ out_hi, int64_t stride,
                                               int L_out, int tile, int lane, uint16_t* mir_hi, int mir_stride) {
   const int m = lane & 15, kg = lane >> 4;
@@ -319,8 +342,8 @@ __device__ __forceinline__ void pl_tile_store(const f32x4& hh, const f32x4& xx, 
   split_f16x2_rn(f32x2{v[2], v[3]}, h2.y, l2.y);
   uint16_t* oh = out_hi + kPlPad + n0;
   if (n0 + 3 < L_out) {
-    *reinterpret_cast<uint2*>(oh) = h2;
-    *reinterpret_cast<uint2*>(oh + stride) = l2;
+    pl_store8(oh, h2);
+    pl_store8(oh + stride, l2);
   }
   if (mir_hi != nullptr) {  // wave-uniform
     uint16_t* mh = mir_hi + n0;
@@ -336,7 +359,7 @@ __device__ __forceinline__ void pl_tile_store(const f32x4& hh, const f32x4& xx, 
   }
   // the level's last (partial) group of four, and the reflect padding: the tiles that hold samples 1..128 and
   // L-129..L-2 write their mirror images (nnaudio.py:300-301).  Wave-uniform conditions, 16-bit stores.
-  const bool tail = o0 + kPlTileOut > L_out - 130 || tile == 0;
+  const bool tail = TAIL ? (o0 + kPlTileOut > L_out - 130 || tile == 0) : o0 + kPlTileOut > L_out;
   if (tail) {
     const uint16_t eh[4] = {(uint16_t)(h2.x & 0xffffu), (uint16_t)(h2.x >> 16), (uint16_t)(h2.y & 0xffffu), (uint16_t)(h2.y >> 16)};
     const uint16_t el[4] = {(uint16_t)(l2.x & 0xffffu), (uint16_t)(l2.x >> 16), (uint16_t)(l2.y & 0xffffu), (uint16_t)(l2.y >> 16)};
@@ -348,16 +371,36 @@ __device__ __forceinline__ void pl_tile_store(const f32x4& hh, const f32x4& xx, 
         oh[r] = eh[r];
         oh[stride + r] = el[r];
       }
-      if (n >= 1 && n <= kPlPad) {
-        out_hi[kPlPad - n] = eh[r];
-        out_hi[stride + kPlPad - n] = el[r];
-      }
-      if (n <= L_out - 2 && n >= L_out - 1 - kPlPad) {
-        const int q = kPlPad + 2 * (L_out - 1) - n;
-        out_hi[q] = eh[r];
-        out_hi[stride + q] = el[r];
+      if constexpr (TAIL) {
+        if (n >= 1 && n <= kPlPad) {
+          out_hi[kPlPad - n] = eh[r];
+          out_hi[stride + kPlPad - n] = el[r];
+        }
+        if (n <= L_out - 2 && n >= L_out - 1 - kPlPad) {
+          const int q = kPlPad + 2 * (L_out - 1) - n;
+          out_hi[q] = eh[r];
+          out_hi[stride + q] = el[r];
+        }
       }
     }
+  }
+}
+
+// A level's reflect padding in its HBM planes (nnaudio.py:300-301: 128 mirrored samples in front and behind, the edge
+// sample not repeated) from the level's LDS image (`img` = its sample 0, lo plane `img_stride` elements behind), by ONE
+// wave: out[kPlPad - n] = s[n], n = 1 .. 128, and out[kPlPad + L + j] = s[L - 2 - j], j = 0 .. 127 — two elements per
+// lane, end and plane.  The bits pl_tile_store<true> writes; off the tiles' critical path (below level 4 every tile of a
+// level holds padding samples, and the scattered 16-bit stores were a third of a one-tile level's time).
+__device__ __forceinline__ void pl_reflect_pad_from_lds(const uint16_t* img, int img_stride, int L, uint16_t* __restrict__ out_hi,
+                                                        int64_t stride, int lane) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int n = 2 * lane + 1 + e;  // 1 .. 128
+    out_hi[kPlPad - n] = img[n];
+    out_hi[stride + kPlPad - n] = img[img_stride + n];
+    const int j = 2 * lane + e;      // 0 .. 127
+    out_hi[kPlPad + L + j] = img[L - 2 - j];
+    out_hi[stride + kPlPad + L + j] = img[img_stride + L - 2 - j];
   }
 }
 
@@ -451,7 +494,7 @@ __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, int64_t str
 // an edge tile, and below level 4 every tile is one) a one-tile level took 2.2 us, half of it the masks.
 // At the natural 64-byte row pitch lanes m and m + 4 share banks (2-way: 8 instead of 4 LDS cycles per read, ~70 cycles a
 // tile).  The same matrix instructions in the same order on the same operands as pl_dec_tile: the same bits.
-template <int PF>
+template <int PF, bool TAIL>
 __device__ __forceinline__ void pl_dec_tile_lds(const uint16_t* in_hi, int in_stride, uint16_t* __restrict__ out_hi,
                                                 int64_t stride, int L_out, int tile, const uint4 (&th)[kPlDmSteps],
                                                 const uint4* __restrict__ tlo, int lane, uint16_t* mir_hi, int mir_stride) {
@@ -479,7 +522,7 @@ __device__ __forceinline__ void pl_dec_tile_lds(const uint16_t* in_hi, int in_st
     xb = BP_PL_MFMA16(th[s], xl[s % (PF + 1)], xb);
     __builtin_amdgcn_sched_barrier(0);
   }
-  pl_tile_store(hh, xa + xb, out_hi, stride, L_out, tile, lane, mir_hi, mir_stride);
+  pl_tile_store<TAIL>(hh, xa + xb, out_hi, stride, L_out, tile, lane, mir_hi, mir_stride);
 }
 
 // The filter's hi fragments live in registers (36 VGPRs), its lo fragments in LDS (9 KB, one ds_read_b128 per k-step):
@@ -660,6 +703,56 @@ __device__ __forceinline__ void pw_zero(uint16_t* hi, int stride, int from, int 
   }
 }
 
+// levels 2 .. 8 with compile-time geometry (the kernel serves the 22.05 kHz pyramid only): no scalar loads of the level's
+// lengths and offsets between the barriers of a 1-microsecond level
+template <int K>
+struct PwLevel {
+  static constexpr int kLen = level_len(K), kLenIn = level_len(K - 1);
+  static constexpr int kTiles = (kLen + kPlTileOut - 1) / kPlTileOut;
+  static constexpr bool kKeep = K < kOctaves - 1;  // somebody reads this level again: it gets an LDS image
+  // element offset of the level's region (its zero guard) inside its LDS plane: level 1 and 3 open region A, 2 opens B
+  static constexpr int region_off() {
+    int off = 0;
+    for (int j = 3; j < K; ++j) off += pw_level_elems(j);
+    return K <= 3 ? 0 : off;
+  }
+};
+
+template <int K>
+__device__ __forceinline__ void pw_level(uint16_t* reg_a, uint16_t* b16, uint16_t* w, const int (&off)[10], int64_t stride,
+                                         const uint4 (&th)[kPlDmSteps], const uint4* tlo, int wave, int lane) {
+  using G = PwLevel<K>;
+  using GI = PwLevel<K - 1>;
+  constexpr int kWaves = kPwThreads / 64;
+  // input: level K - 1 (region A for K = 2 and K >= 4, region B for K = 3); output image: B for K = 2, A otherwise
+  const uint16_t* in_hi = (K == 3 ? b16 : reg_a) + GI::region_off();
+  constexpr int in_stride = K == 3 ? kPwPlaneB : kPwPlaneA;
+  uint16_t* img = (K == 2 ? b16 : reg_a) + G::region_off() + kPwGuard;  // sample 0 of level K's image
+  constexpr int img_stride = K == 2 ? kPwPlaneB : kPwPlaneA;
+  if constexpr (K == 2) {  // level 2's zero surroundings in region B (the row images' space)
+    pw_zero(b16, kPwPlaneB, 0, kPwGuard);
+    pw_zero(b16, kPwPlaneB, kPwGuard + ((G::kLen + 3) & ~3), kPwPlaneB);
+  }
+  if constexpr (K == 3) {  // those of levels 3 .. 7 in region A (level 1 is dead): one contiguous stretch behind each level
+    pw_zero(reg_a, kPwPlaneA, 0, kPwGuard);
+    pw_zero(reg_a, kPwPlaneA, PwLevel<3>::region_off() + kPwGuard + ((level_len(3) + 3) & ~3), PwLevel<4>::region_off() + kPwGuard);
+    pw_zero(reg_a, kPwPlaneA, PwLevel<4>::region_off() + kPwGuard + ((level_len(4) + 3) & ~3), PwLevel<5>::region_off() + kPwGuard);
+    pw_zero(reg_a, kPwPlaneA, PwLevel<5>::region_off() + kPwGuard + ((level_len(5) + 3) & ~3), PwLevel<6>::region_off() + kPwGuard);
+    pw_zero(reg_a, kPwPlaneA, PwLevel<6>::region_off() + kPwGuard + ((level_len(6) + 3) & ~3), PwLevel<7>::region_off() + kPwGuard);
+    pw_zero(reg_a, kPwPlaneA, PwLevel<7>::region_off() + kPwGuard + ((level_len(7) + 3) & ~3), PwLevel<7>::region_off() + pw_level_elems(7));
+  }
+  // the reflect padding of level K - 1's planes, from its image, by the youngest wave (it has the fewest tiles): levels
+  // 2 .. 7; level 1 and level 8 (no image) write theirs from the tiles
+  if constexpr (K >= 3)
+    if (wave == kWaves - 1)
+      pl_reflect_pad_from_lds(in_hi + kPwGuard, in_stride, GI::kLen, w + off[K - 1], stride, lane);
+  for (int tile = wave; tile < G::kTiles; tile += kWaves)
+    pl_dec_tile_lds<3, !G::kKeep>(in_hi, in_stride, w + off[K], stride, G::kLen, tile, th, tlo, lane, G::kKeep ? img : nullptr,
+                                  img_stride);
+  lds_barrier();  // level K is complete
+  PL_STAMP(0, 3 + K);
+}
+
 __global__ __launch_bounds__(kPwThreads) void pl_pyramid_window_kernel(const float* __restrict__ audio, int64_t audio_stride,
                                                                       uint16_t* __restrict__ pl, PlGeo g,
                                                                       const uint4* __restrict__ tfrag) {
@@ -673,70 +766,58 @@ __global__ __launch_bounds__(kPwThreads) void pl_pyramid_window_kernel(const flo
   uint16_t* w = pl + (int64_t)blockIdx.x * 2 * g.stride;
   uint16_t* const b16 = reinterpret_cast<uint16_t*>(reg_b);
   const float* x = audio + (int64_t)blockIdx.x * audio_stride;
-  const int tiles1 = (g.len[1] + kPlTileOut - 1) / kPlTileOut;
+  constexpr int kL0 = kAudioN, kL1 = level_len(1);
+  constexpr int tiles1 = (kL1 + kPlTileOut - 1) / kPlTileOut;
   PL_STAMP(0, 0);
   PL_STAMP_RT(0, 14);
-  // the kernel's first memory round trips all at once: the first tile's rows, the edge rows' samples, the filter fragments
+  // The kernel's first memory round trips ALL AT ONCE (issued one behind the other they were 5.6 us of a 36 us kernel):
+  // the first tile's rows, the filter fragments (hi: registers, lo: one 16-byte piece per thread for LDS), the samples of
+  // this wave's two edge rows.
   int tile = wave;
-  PlRaw<true> raw = pl_fetch_rows<true>(x, nullptr, 0, g.len[0], tile < tiles1 ? tile : 0, lane);
-  // level 0's 32 edge rows, two per wave
-  pl_write_edge_row_pair(x, g.len[0], reinterpret_cast<float*>(w + g.off[0]), g.hop0, wave, lane);
-  PL_STAMP(0, 1);
-  // level 1's zero surroundings in region A (its samples come from the tiles below)
-  pw_zero(reg_a, kPwPlaneA, 0, kPwGuard);
-  pw_zero(reg_a, kPwPlaneA, kPwGuard + ((g.len[1] + 3) & ~3), kPwPlaneA);
+  PlRaw<true> raw = pl_fetch_rows<true>(x, nullptr, 0, kL0, tile, lane);
   uint4 th[kPlDmSteps];
-  pl_load_tfrag(tfrag, th, tlo);
+#pragma unroll
+  for (int s = 0; s < kPlDmSteps; ++s) th[s] = tfrag[s * 64 + lane];
+  static_assert(kPlDmSteps * 64 <= kPwThreads, "one lo-fragment piece per thread");
+  uint4 tlo_piece = uint4{0u, 0u, 0u, 0u};
+  if (threadIdx.x < kPlDmSteps * 64) tlo_piece = tfrag[kPlDmSteps * 64 + threadIdx.x];
+  float* edge_rows = reinterpret_cast<float*>(w + g.off[0]);
+  const float4 er_a = pl_edge_row_load(x, kL0, wave, g.hop0, lane);
+  const float4 er_b = pl_edge_row_load(x, kL0, (kPlTilesPerLevel - 1) * 16 + wave, g.hop0, lane);
+  // (nothing above waits) level 1's zero surroundings in region A — its samples come from the tiles below
+  pw_zero(reg_a, kPwPlaneA, 0, kPwGuard);
+  pw_zero(reg_a, kPwPlaneA, kPwGuard + ((kL1 + 3) & ~3), kPwPlaneA);
+  if (threadIdx.x < kPlDmSteps * 64) tlo[threadIdx.x] = tlo_piece;
+  *reinterpret_cast<float4*>(edge_rows + wave * g.hop0 + 4 * lane) = er_a;
+  *reinterpret_cast<float4*>(edge_rows + (16 + wave) * g.hop0 + 4 * lane) = er_b;
+  PL_STAMP(0, 1);
+  lds_barrier();  // the lo fragments are in LDS
   PL_STAMP(0, 2);
+  int off[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) off[k] = g.off[k];
   {
     // level 0 -> 1: a wave walks tiles wave, wave + 16, ... (86 tiles: the six oldest waves have six, the others five),
     // the next tile's rows in flight during the current one's matrix work
     uint4* rows = reg_b + wave * kPlRowsU;
-    if (tile < tiles1) {
-      for (;;) {
-        const int ntile = tile + kWaves;
-        const PlRaw<true> nraw = pl_fetch_rows<true>(x, nullptr, 0, g.len[0], ntile < tiles1 ? ntile : tile, lane);
-        pl_dec_tile<true, true, 1>(raw, g.stride, g.len[0], w + g.off[1], g.len[1], tile, th, tlo, rows, lane,
-                                   reg_a + kPwGuard, kPwPlaneA);
-        if (ntile >= tiles1) break;
-        raw = nraw, tile = ntile;
-      }
+    for (;;) {
+      const int ntile = tile + kWaves;
+      const PlRaw<true> nraw = pl_fetch_rows<true>(x, nullptr, 0, kL0, ntile < tiles1 ? ntile : tile, lane);
+      pl_dec_tile<true, true, 1>(raw, g.stride, kL0, w + off[1], kL1, tile, th, tlo, rows, lane, reg_a + kPwGuard, kPwPlaneA);
+      if (ntile >= tiles1) break;
+      raw = nraw, tile = ntile;
     }
   }
   PL_STAMP(0, 3);
   lds_barrier();  // level 1 is complete in region A; the row images are dead
   PL_STAMP(0, 4);
-  // levels 2 .. 8: input region (element 0 = kPlPad in front of the level's sample 0), output image (its sample 0)
-  const uint16_t* in_hi = reg_a;
-  int in_stride = kPwPlaneA;
-  uint16_t* mir = b16 + kPwGuard;
-  int mir_stride = kPwPlaneB;
-  for (int k = 2; k < g.n_levels; ++k) {
-    const int tiles = (g.len[k] + kPlTileOut - 1) / kPlTileOut;
-    const bool keep = k + 1 < g.n_levels;  // somebody reads this level again
-    if (k == 2) {  // level 2's zero surroundings in region B (the row images' space)
-      pw_zero(b16, kPwPlaneB, 0, kPwGuard);
-      pw_zero(b16, kPwPlaneB, kPwGuard + ((g.len[2] + 3) & ~3), kPwPlaneB);
-    } else if (k == 3) {  // those of levels 3 .. 7 in region A (level 1 is dead): in front of level 3, behind every level
-      pw_zero(reg_a, kPwPlaneA, 0, kPwGuard);
-      int off = 0;
-      for (int j = 3; j + 1 < g.n_levels; ++j) {
-        const int next = off + kPwGuard + ((g.len[j] + 7) & ~7) + kPwTail;  // the next level's region: its guard follows
-        pw_zero(reg_a, kPwPlaneA, off + kPwGuard + ((g.len[j] + 3) & ~3), j + 2 < g.n_levels ? next + kPwGuard : next);
-        off = next;
-      }
-    }
-    for (int tile_k = wave; tile_k < tiles; tile_k += kWaves)
-      pl_dec_tile_lds<3>(in_hi, in_stride, w + g.off[k], g.stride, g.len[k], tile_k, th, tlo, lane, keep ? mir : nullptr,
-                         mir_stride);
-    lds_barrier();  // level k is complete
-    PL_STAMP(0, 3 + k);
-    // level k becomes the input; level k + 1 goes to region A: at its start for k + 1 = 3, behind its predecessor after that
-    in_hi = mir - kPwGuard;
-    in_stride = mir_stride;
-    mir = k == 2 ? reg_a + kPwGuard : mir + ((g.len[k] + 7) & ~7) + kPwTail + kPwGuard;
-    mir_stride = kPwPlaneA;
-  }
+  pw_level<2>(reg_a, b16, w, off, g.stride, th, tlo, wave, lane);
+  pw_level<3>(reg_a, b16, w, off, g.stride, th, tlo, wave, lane);
+  pw_level<4>(reg_a, b16, w, off, g.stride, th, tlo, wave, lane);
+  pw_level<5>(reg_a, b16, w, off, g.stride, th, tlo, wave, lane);
+  pw_level<6>(reg_a, b16, w, off, g.stride, th, tlo, wave, lane);
+  pw_level<7>(reg_a, b16, w, off, g.stride, th, tlo, wave, lane);
+  pw_level<8>(reg_a, b16, w, off, g.stride, th, tlo, wave, lane);
   PL_STAMP_RT(0, 15);
 }
 
@@ -1116,7 +1197,7 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
         if (i < nA) {
           const uint2 tj = divmod(i, std::integral_constant<unsigned, kJH>{}, std::integral_constant<unsigned, nA>{});
           const float x4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-          *reinterpret_cast<uint4*>(zc + (__umul24(tj.x, kZRow * 4u) + 16u * tj.y)) = pl_zp_pack4(x4, mn, nk, kc.bn_b);
+          pl_store16(zc + (__umul24(tj.x, kZRow * 4u) + 16u * tj.y), pl_zp_pack4(x4, mn, nk, kc.bn_b));
         }
       }
     }
@@ -1131,13 +1212,13 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
         const float x4[4] = {row[0], last ? 0.f : row[1], last ? 0.f : row[2], last ? 0.f : row[3]};
         uint4 w = pl_zp_pack4(x4, mn, nk, kc.bn_b);
         if (last) w.y = w.z = w.w = 0u;
-        *reinterpret_cast<uint4*>(zc + (__umul24(tj.x, kZRow * 4u) + 16u * (tj.y + kJH + 1))) = w;
+        pl_store16(zc + (__umul24(tj.x, kZRow * 4u) + 16u * (tj.y + kJH + 1)), w);
       }
     }
     // (C) the mixed group: bin 4 kJH from L2, the next three from LDS
     if (tid < kFrames) {
       const float x4[4] = {lpb[tid * NB + 4 * kJH], s_lp[tid * kLdsBins], s_lp[tid * kLdsBins + 1], s_lp[tid * kLdsBins + 2]};
-      *reinterpret_cast<uint4*>(zc + (__umul24((unsigned)tid, kZRow * 4u) + 16u * kJH)) = pl_zp_pack4(x4, mn, nk, kc.bn_b);
+      pl_store16(zc + (__umul24((unsigned)tid, kZRow * 4u) + 16u * kJH), pl_zp_pack4(x4, mn, nk, kc.bn_b));
     }
     PL_STAMP(1, 5);
     __syncthreads();  // s_lp, s_mm and the task counter are free for the next window

@@ -723,6 +723,11 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
       float* note = static_cast<float*>(maps.p);
       float* onset = note + T * 88;
       float* contour = onset + T * 88;
+      // device-side candidates (the default): the same page-locked buffer holds the note map, the onset-peak bitmap
+      // (T x 11 bytes, from a 16-byte boundary) and the pitch-bend map (T x 88 bytes) instead of the onset / contour maps
+      uint8_t* cand_bits = reinterpret_cast<uint8_t*>(onset);
+      int8_t* bend_map = reinterpret_cast<int8_t*>(cand_bits + ((T * 11 + 15) & ~(int64_t)15));
+      bool use_cand = !prm.host_decode && prm.notes.onset_threshold > 0.0;
       rep->ms_read = lap();
       const int lane = acquire();
       rep->ms_lane_wait = lap();
@@ -730,7 +735,14 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
       int rc = BP_OK;
       std::string err;
       if (T > 0) {
-        rc = bp_infer_pcm_raw(h, pcm, format, n_frames, channels, sr, note, onset, contour, BP_MEM_HOST);
+        if (use_cand) {
+          int status = 0;
+          rc = bp_infer_pcm_raw_candidates(h, pcm, format, n_frames, channels, sr, &prm.notes, note, cand_bits,
+                                           prm.notes.include_pitch_bends ? bend_map : nullptr, &status);
+          if (rc == BP_OK && status != 0) use_cand = false;  // a NaN in the maps: numpy's rules need the maps themselves
+        }
+        if (rc == BP_OK && !use_cand)
+          rc = bp_infer_pcm_raw(h, pcm, format, n_frames, channels, sr, note, onset, contour, BP_MEM_HOST);
         if (rc != BP_OK) err = bp_last_error(h);
       }
       release(lane);
@@ -745,9 +757,12 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
       size_t cap_ev = (size_t)std::max<int64_t>(256, T / 4), cap_b = (size_t)std::max<int64_t>(4096, 4 * T);
       for (int attempt = 0; attempt < 2; ++attempt) {
         events.resize(cap_ev), bends.resize(cap_b);
-        rc = T > 0 ? bp_notes_decode(note, onset, contour, T, &prm.notes, events.data(), (int64_t)cap_ev, bends.data(),
-                                     (int64_t)cap_b, &n_ev, &n_b)
-                   : BP_OK;
+        rc = T <= 0 ? BP_OK
+             : use_cand ? bp_notes_decode_candidates(note, cand_bits, prm.notes.include_pitch_bends ? bend_map : nullptr, T,
+                                                     &prm.notes, events.data(), (int64_t)cap_ev, bends.data(), (int64_t)cap_b,
+                                                     &n_ev, &n_b)
+                        : bp_notes_decode(note, onset, contour, T, &prm.notes, events.data(), (int64_t)cap_ev, bends.data(),
+                                          (int64_t)cap_b, &n_ev, &n_b);
         if (rc == BP_OK || !((size_t)n_ev > cap_ev || (size_t)n_b > cap_b)) break;
         cap_ev = std::max(cap_ev, (size_t)n_ev), cap_b = std::max(cap_b, (size_t)n_b);
       }

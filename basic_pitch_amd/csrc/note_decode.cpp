@@ -170,10 +170,17 @@ void bp_note_params_default(bp_note_params* p) {
   p->max_freq_hz = 0.0;
 }
 
-int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_frames,
-                    const bp_note_params* prm, bp_note_event* events, int64_t max_events, int32_t* bends,
-                    int64_t max_bends, int64_t* n_events_out, int64_t* n_bends_out) {
-  if (!prm || !n_events_out || !n_bends_out || n_frames < 0 || (n_frames > 0 && (!note || !onset || !contour))) {
+// The decoder.  Two sources for the onset peaks and the pitch bends:
+//   cand_bits == null: the onset and contour maps (bp_notes_decode: everything on the host);
+//   cand_bits != null: the device extracted them (bp_note_candidates, csrc/note_device.hip): bit f of byte row t
+//     ([T][11] bytes) marks an onset peak that reaches the threshold, bend_map [T][88] holds the pitch bend of bin f at
+//     frame t; `note` is already frequency-constrained, `onset` / `contour` are not looked at.
+static int decode_core(float* note, float* onset, const float* contour, const uint8_t* cand_bits, const int8_t* bend_map,
+                       int64_t n_frames, const bp_note_params* prm, bp_note_event* events, int64_t max_events,
+                       int32_t* bends, int64_t max_bends, int64_t* n_events_out, int64_t* n_bends_out) {
+  const bool cand = cand_bits != nullptr;
+  if (!prm || !n_events_out || !n_bends_out || n_frames < 0 ||
+      (n_frames > 0 && (!note || (!cand && (!onset || !contour)) || (cand && prm->include_pitch_bends && !bend_map)))) {
     g_notes_error = "bp_notes_decode: null pointer or negative frame count";
     return BP_ERR_INVALID_ARG;
   }
@@ -192,6 +199,10 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
   const int64_t T = n_frames;
   if (T == 0) return BP_OK;
 
+  if (cand && !(prm->onset_threshold > 0.0)) {
+    g_notes_error = "bp_notes_decode_candidates: an onset threshold <= 0 needs the onset map (every cell that is not a peak qualifies)";
+    return BP_ERR_INVALID_ARG;
+  }
   // ---- constrain_frequency (in place, note_creation.py:338-341)
   int64_t min_idx = 0, max_idx = kF;
   if (prm->min_freq_hz > 0.0)
@@ -202,7 +213,7 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
     // numpy slice semantics: [:a] and [b:] with negative / overshooting bounds
     auto norm = [](int64_t i) { return i < 0 ? (i + kF < 0 ? 0 : i + kF) : (i > kF ? kF : i); };
     const int64_t lo = norm(min_idx), hi = norm(max_idx);
-    for (int64_t t = 0; t < T; ++t) {
+    for (int64_t t = 0; t < T && !cand; ++t) {
       for (int64_t f = 0; f < lo; ++f) note[t * kF + f] = onset[t * kF + f] = 0.0f;
       for (int64_t f = hi; f < kF; ++f) note[t * kF + f] = onset[t * kF + f] = 0.0f;
     }
@@ -218,7 +229,7 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
   std::vector<double>& row_fd = g_scratch.row_fd;
   row_on.resize((size_t)T), row_fd.assign((size_t)T, 0.0);
   bool on_nan = false;
-  for (int64_t t = 0; t < T; ++t) {
+  for (int64_t t = 0; t < T && !cand; ++t) {
     const float* o = onset + t * kF;
     float m[8];
     int nan = 0;
@@ -234,7 +245,7 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
     row_on[(size_t)t] = r;
     on_nan |= nan != 0;
   }
-  if (infer) {
+  if (infer && !cand) {
     // np.max of the onset map: NaN if it holds one
     float max_on = row_on[0];
     for (int64_t t = 1; t < T; ++t) max_on = row_on[(size_t)t] > max_on ? row_on[(size_t)t] : max_on;
@@ -292,7 +303,41 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
   // qualifies with its 0, first frame included.  Either way the exact value decides.
   const bool filter = onset_thresh > 0.0 && !on_nan && (!infer || max_fd > 0.0);
   const double lim = onset_thresh * max_fd * (1.0 - 1e-9);
-  for (int64_t t = T - 2; t >= 0; --t) {
+  // a note from the onset peak (t, f): follow the energy forward (note_creation.py:404-446)
+  auto track_from = [&](int64_t t, int f) {
+    const int64_t start = t;
+    if (start >= T - 1) return;
+    int64_t i = start + 1;
+    int k = 0;
+    while (i < T - 1 && k < energy_tol) {
+      if ((double)energy[i * kF + f] < frame_thresh)
+        ++k;
+      else
+        k = 0;
+      ++i;
+    }
+    i -= k;
+    if (i - start <= prm->min_note_len) return;
+    for (int64_t r = start; r < i; ++r) {
+      energy[r * kF + f] = 0;
+      if (f < kMaxFreqIdx) energy[r * kF + f + 1] = 0;
+      if (f > 0) energy[r * kF + f - 1] = 0;
+    }
+    notes.push_back({(int32_t)start, (int32_t)i, f + kMidiOffset, mean_f32(note, start, i, f)});
+  };
+  if (cand) {
+    // the device's peaks, visited like the loop below: backwards in time, downwards in frequency
+    for (int64_t t = T - 2; t >= 1; --t) {
+      const uint8_t* row = cand_bits + t * 11;
+      uint64_t lo8;
+      std::memcpy(&lo8, row, 8);
+      const uint32_t hi3 = (uint32_t)row[8] | ((uint32_t)row[9] << 8) | ((uint32_t)row[10] << 16);
+      if (!(lo8 | hi3)) continue;
+      for (int f = kF - 1; f >= 0; --f)
+        if (f < 64 ? (lo8 >> f) & 1 : (hi3 >> (f - 64)) & 1) track_from(t, f);
+    }
+  }
+  for (int64_t t = cand ? -1 : T - 2; t >= 0; --t) {
     if (t == 0 && onset_thresh > 0.0) break;  // never a peak: its 0 is below the threshold
     const float *o0 = onset + t * kF, *n0 = note + t * kF, *n1 = t >= 1 ? n0 - kF : n0, *n2 = t >= 2 ? n1 - kF : n1;
     uint8_t flag[kF];
@@ -322,25 +367,7 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
       double v = on_at(t, f);
       if (!(t >= 1 && v > on_at(t - 1, f) && v > on_at(t + 1, f))) v = 0.0;  // scipy.signal.argrelmax along time
       if (!(v >= onset_thresh)) continue;
-      const int64_t start = t;
-      if (start >= T - 1) continue;
-      int64_t i = start + 1;
-      int k = 0;
-      while (i < T - 1 && k < energy_tol) {
-        if ((double)energy[i * kF + f] < frame_thresh)
-          ++k;
-        else
-          k = 0;
-        ++i;
-      }
-      i -= k;
-      if (i - start <= prm->min_note_len) continue;
-      for (int64_t r = start; r < i; ++r) {
-        energy[r * kF + f] = 0;
-        if (f < kMaxFreqIdx) energy[r * kF + f + 1] = 0;
-        if (f > 0) energy[r * kF + f - 1] = 0;
-      }
-      notes.push_back({(int32_t)start, (int32_t)i, f + kMidiOffset, mean_f32(note, start, i, f)});
+      track_from(t, f);
     }
   }
 
@@ -420,6 +447,11 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
     ev.bend_offset = bo;
     ev.n_bends = 0;
     if (!prm->include_pitch_bends) continue;
+    if (cand) {  // get_pitch_bends evaluated on the device for every (frame, bin): note_device.hip nd_bend_kernel
+      for (int64_t t = r.start; t < r.end; ++t) bends[bo++] = (int32_t)bend_map[t * kF + (r.pitch - kMidiOffset)];
+      ev.n_bends = (int32_t)(r.end - r.start);
+      continue;
+    }
     const double pitch_hz = 440.0 * std::pow(2.0, ((double)r.pitch - 69.0) / 12.0);
     const int64_t freq_idx = round_half_even(12.0 * 3.0 * std::log2(pitch_hz / 27.5));
     const int64_t tol = 25;
@@ -442,6 +474,55 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
     ev.n_bends = (int32_t)(r.end - r.start);
   }
   return BP_OK;
+}
+
+int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_frames,
+                    const bp_note_params* prm, bp_note_event* events, int64_t max_events, int32_t* bends,
+                    int64_t max_bends, int64_t* n_events_out, int64_t* n_bends_out) {
+  return decode_core(note, onset, contour, nullptr, nullptr, n_frames, prm, events, max_events, bends, max_bends, n_events_out,
+                     n_bends_out);
+}
+
+int bp_notes_decode_candidates(const float* note, const uint8_t* cand_bits, const int8_t* bend_map, int64_t n_frames,
+                               const bp_note_params* prm, bp_note_event* events, int64_t max_events, int32_t* bends,
+                               int64_t max_bends, int64_t* n_events_out, int64_t* n_bends_out) {
+  if (!cand_bits) {
+    g_notes_error = "bp_notes_decode_candidates: null candidate bitmap";
+    return BP_ERR_INVALID_ARG;
+  }
+  // the note map is only read in this mode (frequency limits were applied where the candidates were made)
+  return decode_core(const_cast<float*>(note), nullptr, nullptr, cand_bits, bend_map, n_frames, prm, events, max_events, bends,
+                     max_bends, n_events_out, n_bends_out);
+}
+
+// The per-pitch windows of get_pitch_bends (note_creation.py:182-219) for note bins 0 .. 87, and its Gaussian: the tables
+// the device kernel uses, computed by the expressions decode_core uses for a single note (so that both pick the same bins)
+void bp_internal_bend_tables(int32_t* tab /* [88][4]: f0, n, g0, shift */, double* gauss /* [51] */) {
+  for (int i = 0; i < 51; ++i) {
+    const double n = (double)i - 25.0;
+    gauss[i] = std::exp(-(n * n) / (2.0 * 5.0 * 5.0));
+  }
+  for (int b = 0; b < kF; ++b) {
+    const int pitch = b + kMidiOffset;
+    const double pitch_hz = 440.0 * std::pow(2.0, ((double)pitch - 69.0) / 12.0);
+    const int64_t freq_idx = round_half_even(12.0 * 3.0 * std::log2(pitch_hz / 27.5));
+    const int64_t tol = 25;
+    const int64_t f0 = freq_idx - tol > 0 ? freq_idx - tol : 0;
+    const int64_t f1 = freq_idx + tol + 1 < kFC ? freq_idx + tol + 1 : kFC;
+    const int64_t g0 = tol - freq_idx > 0 ? tol - freq_idx : 0;
+    tab[4 * b] = (int32_t)f0, tab[4 * b + 1] = (int32_t)(f1 - f0), tab[4 * b + 2] = (int32_t)g0, tab[4 * b + 3] = (int32_t)(tol - g0);
+  }
+}
+
+// the [lo, hi) bins constrain_frequency keeps (note_creation.py:314-343), as decode_core computes them
+void bp_internal_freq_limits(const bp_note_params* prm, int* lo_out, int* hi_out) {
+  int64_t min_idx = 0, max_idx = kF;
+  if (prm->min_freq_hz > 0.0)
+    min_idx = round_half_even(12.0 * (std::log2(prm->min_freq_hz) - std::log2(440.0)) + 69.0 - kMidiOffset);
+  if (prm->max_freq_hz > 0.0)
+    max_idx = round_half_even(12.0 * (std::log2(prm->max_freq_hz) - std::log2(440.0)) + 69.0 - kMidiOffset);
+  auto norm = [](int64_t i) { return i < 0 ? (i + kF < 0 ? 0 : i + kF) : (i > kF ? kF : i); };
+  *lo_out = (int)norm(min_idx), *hi_out = (int)norm(max_idx);
 }
 
 }  // extern "C"

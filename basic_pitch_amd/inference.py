@@ -301,6 +301,40 @@ class Model:
         _native.check(self._lib, self._handle, rc, "bp_resample")
         return out
 
+    def note_candidates(self, output: Dict[str, Any], prm) -> Tuple[np.ndarray, np.ndarray, Optional[np.ndarray], int]:
+        """The dense half of note decoding on the device (`bp_note_candidates`, csrc/note_device.hip) for the posteriorgrams
+        `output` (numpy arrays or CUDA tensors of T frames): (note map after constrain_frequency, onset-peak bitmap
+        (T, 11) uint8, pitch-bend map (T, 88) int8 or None, status).  status 1: a NaN in the maps or an onset threshold
+        <= 0 — decode the maps themselves (`note_creation.model_output_to_notes`).  `prm`: `note_creation._note_params`."""
+        on_dev = _is_torch_cuda(output["note"])
+        maps = {}
+        for k, w in (("note", N_FREQ_BINS_NOTES), ("onset", N_FREQ_BINS_NOTES), ("contour", N_FREQ_BINS_CONTOURS)):
+            a = output[k]
+            if on_dev:
+                a = a.contiguous().float()
+            else:
+                a = np.require(a, np.float32, ["C"])
+            if a.ndim != 2 or a.shape[1] != w:
+                raise ValueError(f"{k}: expected (T, {w})")
+            maps[k] = a
+        T = int(maps["note"].shape[0])
+        note = np.empty((T, N_FREQ_BINS_NOTES), np.float32)
+        bits = np.empty((T, 11), np.uint8)
+        bend = np.empty((T, N_FREQ_BINS_NOTES), np.int8) if prm.include_pitch_bends else None
+        status = C.c_int(0)
+        ptr = (lambda a: a.data_ptr()) if on_dev else (lambda a: a.ctypes.data)
+        if on_dev:
+            import torch
+
+            torch.cuda.current_stream(maps["note"].device).synchronize()
+        rc = self._lib.bp_note_candidates(
+            self._handle, ptr(maps["note"]), ptr(maps["onset"]), ptr(maps["contour"]), T, C.byref(prm),
+            _native.BP_MEM_DEVICE if on_dev else _native.BP_MEM_HOST, note.ctypes.data, bits.ctypes.data,
+            bend.ctypes.data if bend is not None else None, C.byref(status),
+        )
+        _native.check(self._lib, self._handle, rc, "bp_note_candidates")
+        return note, bits, bend, int(status.value)
+
     def predict_pcm(self, pcm: np.ndarray, sample_rate: int) -> Dict[str, np.ndarray]:
         """Decoded PCM at any rate / channel count -> un-overlapped posteriorgrams: downmix, resampling, windowing,
         CQT + CNN and un-overlapping all on the device (bp_infer_pcm)."""
@@ -801,6 +835,15 @@ def predict_and_save_many(
     return report
 
 
+def lane_models(model_path: Union[str, pathlib.Path] = ICASSP_2022_MODEL_PATH, devices: Optional[Sequence[int]] = None,
+                lanes: int = 3) -> List[Model]:
+    """The GPU lanes of a native file job: `lanes` models on every device of `devices` (default: device 0), device-major
+    — lane i sits on devices[i // lanes].  Small workspaces (128 windows: one 3-minute track is 110), blocking waits so
+    that a host thread parked on a lane leaves its core to the workers."""
+    return [Model(model_path, device=int(d), max_windows=128, blocking_wait=True)
+            for d in (devices if devices is not None else [0]) for _ in range(max(1, int(lanes)))]
+
+
 def transcribe_files(
     audio_path_list,
     output_directory: Union[pathlib.Path, str],
@@ -819,6 +862,7 @@ def transcribe_files(
     lanes: int = 3,
     threads: int = 0,
     devices: Optional[Sequence[int]] = None,
+    host_decode: bool = False,
 ) -> List[Dict[str, Any]]:
     """The batch job of `predict_and_save` (inference.py:509-604) for WAV / FLAC input and MIDI / note-event output, run
     natively: ONE call into the library (`bp_transcribe_files`, csrc/file_pipeline.cpp), C++ worker threads from the
@@ -828,14 +872,15 @@ def transcribe_files(
     whichever is free, so ONE call shards its files over all GPUs of a node by itself (file-granular, no collective).
     Returns per file `{"status": 0 | bp_status, "n_note_events": k, "n_frames": T, "message": str, "ms": {stage: wall
     milliseconds of the worker}}`; per-file
-    failures are reported, not raised (the reference's per-file try / except)."""
+    failures are reported, not raised (the reference's per-file try / except).  By default the dense half of note
+    decoding runs on the device and 7 MB per 3-minute track come back instead of 27.6 (`host_decode=True`: the round-4
+    path, all three posteriorgrams decoded on the host; same bytes)."""
     own: List[Model] = []
     if models is None:
         if isinstance(model_or_model_path, Model):
             models = [model_or_model_path]
         else:
-            own = [Model(model_or_model_path, device=int(d), max_windows=128, blocking_wait=True)
-                   for d in (devices if devices is not None else [0]) for _ in range(max(1, int(lanes)))]
+            own = lane_models(model_or_model_path, devices, lanes)
             models = own
     try:
         lib = models[0]._lib
@@ -852,6 +897,7 @@ def transcribe_files(
         prm.midi_tempo = float(midi_tempo)
         prm.multiple_pitch_bends = int(bool(multiple_pitch_bends))
         prm.save_midi, prm.save_notes, prm.threads = int(bool(save_midi)), int(bool(save_notes)), int(threads)
+        prm.host_decode = int(bool(host_decode))
         handles = (C.c_void_p * len(models))(*[m._handle for m in models])
         cpaths = (C.c_char_p * max(1, n))(*paths)
         reports = (_native.bp_file_report * max(1, n))()

@@ -95,6 +95,53 @@ def _decode(
         raise ValueError(f"bp_notes_decode: {lib.bp_notes_last_error().decode(errors='replace')}")
 
 
+def _note_params(onset_thresh, frame_thresh, min_note_len, infer_onsets, max_freq, min_freq, melodia_trick, energy_tol,
+                 include_pitch_bends):
+    prm = _native.bp_note_params()
+    _native.load_library().bp_note_params_default(C.byref(prm))
+    prm.onset_threshold, prm.frame_threshold = float(onset_thresh), float(frame_thresh)
+    prm.min_note_len, prm.energy_tol = int(min_note_len), int(energy_tol)
+    prm.infer_onsets, prm.melodia_trick = int(bool(infer_onsets)), int(bool(melodia_trick))
+    prm.include_pitch_bends = int(bool(include_pitch_bends))
+    prm.min_freq_hz = float(min_freq) if min_freq is not None else 0.0
+    prm.max_freq_hz = float(max_freq) if max_freq is not None else 0.0
+    return prm
+
+
+def decode_candidates(note: np.ndarray, cand_bits: np.ndarray, bend_map: Optional[np.ndarray], prm) -> List[NoteEvent]:
+    """The sequential half of note decoding from what the device extracted (`bp_note_candidates` /
+    `bp_infer_pcm_raw_candidates`: the frequency-constrained note map, the bitmap of onset peaks, the pitch-bend map):
+    note_creation.py:404-509 + the bends and frame times of 182-219, 346-357 -> [(start_s, end_s, pitch, amplitude, bends)]."""
+    lib = _native.load_library()
+    note = np.require(note, np.float32, ["C"])
+    cand_bits = np.require(cand_bits, np.uint8, ["C"])
+    T = note.shape[0]
+    if note.ndim != 2 or note.shape[1] != N_FREQ_BINS_NOTES or cand_bits.shape != (T, 11):
+        raise ValueError("expected note (T, 88) float32 and cand_bits (T, 11) uint8")
+    if bend_map is not None:
+        bend_map = np.require(bend_map, np.int8, ["C"])
+        if bend_map.shape != (T, N_FREQ_BINS_NOTES):
+            raise ValueError("expected bend_map (T, 88) int8")
+    n_ev, n_b = C.c_int64(0), C.c_int64(0)
+    cap_ev, cap_b = max(256, T // 4), max(4096, 4 * T)
+    while True:
+        events = (_native.bp_note_event * cap_ev)()
+        bends = np.empty(cap_b, dtype=np.int32)
+        rc = lib.bp_notes_decode_candidates(
+            note.ctypes.data, cand_bits.ctypes.data, bend_map.ctypes.data if bend_map is not None else None, T,
+            C.byref(prm), C.addressof(events), cap_ev, bends.ctypes.data, cap_b, C.byref(n_ev), C.byref(n_b),
+        )
+        if rc == _native.BP_OK:
+            with_bends = bool(prm.include_pitch_bends)
+            return [(float(e.start_s), float(e.end_s), int(e.pitch_midi), np.float32(e.amplitude),
+                     bends[e.bend_offset : e.bend_offset + e.n_bends].tolist() if with_bends else None)
+                    for e in events[: n_ev.value]]
+        if n_ev.value > cap_ev or n_b.value > cap_b:
+            cap_ev, cap_b = max(cap_ev, n_ev.value), max(cap_b, n_b.value)
+            continue
+        raise ValueError(f"bp_notes_decode_candidates: {lib.bp_notes_last_error().decode(errors='replace')}")
+
+
 def output_to_notes_polyphonic(
     frames: np.ndarray, onsets: np.ndarray, onset_thresh: float, frame_thresh: float, min_note_len: int,
     infer_onsets: bool, max_freq: Optional[float], min_freq: Optional[float], melodia_trick: bool = True,

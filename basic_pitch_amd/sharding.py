@@ -19,6 +19,24 @@ import os
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
 
+def usable_cpus() -> int:
+    """Cores this process may really use: the affinity mask, capped by a cgroup CPU quota (a container on a 256-thread
+    host may own 16) — what csrc/file_pipeline.cpp::default_threads counts for the native pipeline's workers."""
+    import os
+
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def plan_shards(costs: Sequence[float], world_size: int) -> List[List[int]]:
     """Greedy LPT: heaviest item first onto the least-loaded rank.  Deterministic on every rank."""
     if world_size <= 0:

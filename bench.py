@@ -197,17 +197,25 @@ def run_tracks(args, torch, dist, world, rank, local_rank) -> None:
         print(json.dumps(line), flush=True)
 
 
-def run_files(args) -> None:
-    """End-to-end `predict()` over FILES on one GPU (not the headline metric: host decode, H2D of the PCM, device
-    resampling, CQT + CNN, D2H of the posteriorgrams and C++ note decoding on host threads are all inside the timed
-    region): `--files` synthetic 16-bit stereo 44.1 kHz WAV files of `--file-seconds` each in a temporary directory,
-    through basic_pitch_amd.predict_many.  Reports files/s and audio-seconds per second."""
+def run_files(args, torch=None, dist=None, world: int = 1, rank: int = 0, local_rank: int = 0) -> None:
+    """End-to-end `predict()` over FILES (not the headline metric: host decode, H2D of the PCM, device
+    resampling, CQT + CNN, D2H of what note decoding needs and note decoding on host threads are all inside the timed
+    region): `--files` synthetic 16-bit stereo 44.1 kHz WAV files of `--file-seconds` each in a temporary directory.
+    Reports files/s and audio-seconds per second.  With `--gpus N --native` (BASELINE.json configs[2] as a FILE job) the
+    files are sharded over the ranks (file i -> rank i mod N: the files are equally long; no collective on the data path),
+    every rank runs the native pipeline on its own GPU with its share of the host cores, the timed region is bracketed by
+    barriers and closed by the slowest rank; rank 0 reports the whole-job rate, the per-rank rates and their imbalance."""
     import tempfile
     import wave
 
     from basic_pitch_amd.inference import Model, predict_many
 
-    rng = np.random.default_rng(7)
+    if world > 1 and not args.native:
+        raise SystemExit("--workload files on several GPUs runs the native pipeline: add --native")
+    total_files = args.files
+    mine = list(range(rank, total_files, world))
+    args.files = len(mine)
+    rng = np.random.default_rng(7 + rank)
     n = int(args.file_seconds * 44100)
     t = np.arange(n) / 44100.0
     with tempfile.TemporaryDirectory() as d:
@@ -228,21 +236,34 @@ def run_files(args) -> None:
                 w.setframerate(44100)
                 w.writeframes(pcm.tobytes())
             paths.append(p)
-        model = Model(max_windows=256)
+        model = Model(device=local_rank, max_windows=256)
         windows = sum(int(model._lib.bp_track_n_windows(int(np.ceil(n / 2)))) for _ in paths)
+        per_rank = None
         if args.native:
             # the native pipeline: one bp_transcribe_files call, C++ worker threads from the file's bytes to its .mid + .csv
             from basic_pitch_amd import transcribe_files
+            from basic_pitch_amd.sharding import usable_cpus
 
             model.close()
-            lanes = [Model(max_windows=128, blocking_wait=True) for _ in range(args.lanes)]
+            threads = args.native_threads or (max(2, usable_cpus() // world) if world > 1 else 0)
+            lanes = [Model(device=local_rank, max_windows=128, blocking_wait=True) for _ in range(args.lanes)]
             out_dir, warm_dir = os.path.join(d, "out"), os.path.join(d, "warm")
             os.mkdir(out_dir)
             os.mkdir(warm_dir)
-            transcribe_files(paths[: min(8, len(paths))], warm_dir, models=lanes, threads=args.native_threads)  # warm-up
+            kw = dict(models=lanes, threads=threads, host_decode=args.host_decode)
+            transcribe_files(paths[: min(8, len(paths))], warm_dir, **kw)  # warm-up
+            if world > 1:
+                dist.barrier()
             t0 = time.perf_counter()
-            rep = transcribe_files(paths, out_dir, models=lanes, threads=args.native_threads)
+            rep = transcribe_files(paths, out_dir, **kw)
             el = time.perf_counter() - t0
+            if world > 1:
+                dist.barrier()
+                mine_t = torch.tensor([el, float(len(paths))], dtype=torch.float64)
+                allt = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(allt, mine_t)
+                per_rank = [(float(a[0]), int(a[1])) for a in allt]
+                el = max(e for e, _ in per_rank)
             bad = [r for r in rep if r["status"] != 0]
             if bad:
                 raise SystemExit(f"native pipeline: {len(bad)} files failed: {bad[0]}")
@@ -250,11 +271,13 @@ def run_files(args) -> None:
             stage_ms = {k: float(np.mean([r["ms"][k] for r in rep])) for k in rep[0]["ms"]}
             for m in lanes:
                 m.close()
-            how = (f"bp_transcribe_files: {args.lanes} GPU lanes (handles), "
-                   f"{args.native_threads or 'one per usable core'} C++ worker threads, each file from its bytes to its "
+            back = ("all three posteriorgrams back (27.6 MB per file), note decoding on the host" if args.host_decode else
+                    "inferred onsets, peak picking and the pitch bends on the device, the note map + onset-peak bitmap + bend map "
+                    "back (7.1 MB per file), the note tracker on the host")
+            how = (f"bp_transcribe_files: {args.lanes} GPU lanes (handles) per GPU, "
+                   f"{threads or 'one per usable core'} C++ worker threads per process, each file from its bytes to its "
                    ".mid + .csv without Python (file read into page-locked memory, the 16-bit samples over PCIe as stored, "
-                   "conversion + downmix + resampling on the device, CQT + CNN, posteriorgrams back, note decoding, MIDI / CSV "
-                   "encoding, file writes)")
+                   f"conversion + downmix + resampling on the device, CQT + CNN, {back}, MIDI / CSV encoding, file writes)")
         elif args.save_workers > 0:
             # the batch job: predict_and_save_sharded, `--save-workers` host processes on the one GPU, every worker writes
             # its own MIDI + note CSV (nothing but small reports crosses process boundaries)
@@ -292,12 +315,23 @@ def run_files(args) -> None:
             n_events = sum(len(r[2]) for r in res)
             how = ("predict_many (host WAV read on a thread pool, PCM over PCIe, device resampling, note decoding on host "
                    "threads)")
+    if rank != 0:
+        return
+    n_all = total_files if per_rank else len(paths)
+    extra = {}
+    if per_rank:
+        rates = [k / e for e, k in per_rank]
+        extra = {"scaling": "strong", "per_rank_files_per_s": rates, "per_rank_elapsed_s": [e for e, _ in per_rank],
+                 "imbalance_max_over_min_elapsed": max(e for e, _ in per_rank) / min(e for e, _ in per_rank)}
+        windows = windows * n_all / max(1, len(paths))
     print(json.dumps({
-        "metric": "files/sec end-to-end predict() (decode + resample + CQT + CNN + note decoding), 1 MI355X",
-        "value": len(paths) / el, "unit": "files/s", "n_gpus": 1, "higher_is_better": True, "data": "synthetic",
-        "audio_seconds_per_s": len(paths) * args.file_seconds / el, "windows_per_s": windows / el,
-        "config": {"workload": f"{len(paths)} synthetic 16-bit stereo 44.1 kHz WAV files ({min(len(paths), 32)} distinct signals) of {args.file_seconds:g} s through "
-                   + how, "host_threads": min(16, os.cpu_count() or 1), "note_events": n_events},
+        "metric": f"files/sec end-to-end predict() (decode + resample + CQT + CNN + note decoding), {world} MI355X",
+        "value": n_all / el, "unit": "files/s", "n_gpus": world, "higher_is_better": True, "data": "synthetic",
+        "audio_seconds_per_s": n_all * args.file_seconds / el, "windows_per_s": windows / el,
+        "config": {"workload": f"{n_all} synthetic 16-bit stereo 44.1 kHz WAV files ({min(len(paths), 32)} distinct signals per rank) of {args.file_seconds:g} s through "
+                   + how, "host_threads": min(16, os.cpu_count() or 1), "note_events": n_events,
+                   "sharding": "file i -> rank i mod N, no collective on the data path"},
+        **extra,
         **({"worker_ms_per_file": stage_ms} if args.native else {}),
     }), flush=True)
 
@@ -414,6 +448,9 @@ def main() -> None:
     ap.add_argument("--native", action="store_true",
                     help="--workload files: the native pipeline (bp_transcribe_files: C++ worker threads, no Python in the loop)")
     ap.add_argument("--lanes", type=int, default=3, help="--native: GPU lanes (handles) the workers queue for")
+    ap.add_argument("--host-decode", action="store_true",
+                    help="--native: bring all three posteriorgrams back and decode on the host (the round-4 path) instead of "
+                         "extracting the onset peaks and pitch bends on the device")
     ap.add_argument("--native-threads", type=int, default=0, help="--native: C++ worker threads (0: one per hardware thread)")
     ap.add_argument("--save-workers", type=int, default=0,
                     help="--workload files: run the job as predict_and_save_sharded with this many host processes on the GPU")
@@ -489,7 +526,9 @@ def main() -> None:
 
     args.reduce_over_ranks = reduce_over_ranks
     if args.workload == "files":
-        run_files(args)
+        run_files(args, torch, dist, world, rank, local_rank)
+        if world > 1:
+            dist.destroy_process_group()
         return
     if args.workload == "tracks":
         run_tracks(args, torch, dist, world, rank, local_rank)

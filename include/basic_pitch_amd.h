@@ -348,6 +348,32 @@ void bp_note_params_default(bp_note_params* p);
 int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_frames,
                     const bp_note_params* params, bp_note_event* events, int64_t max_events, int32_t* bends,
                     int64_t max_bends, int64_t* n_events, int64_t* n_bends);
+
+/* ---- Note decoding with the dense half on the device (round 5; SURVEY.md 8f rank 1: onset inference, peak picking and
+ * thresholding note_creation.py:289-311, 394-402; the pitch bends of get_pitch_bends 182-219 for every (frame, bin)).
+ * What the sequential note tracker needs of a track's posteriorgrams is the note map, WHERE the onset peaks are and the
+ * pitch bend per (frame, note bin): 7.1 MB per 3-minute track instead of 27.6 MB across PCIe, and the three dense scans
+ * leave the host cores.  Same events as bp_notes_decode, bit for bit (tests/test_gpu_parity.py).
+ *
+ *   note_out  [n_frames][88] float32  the note map, frequency-constrained like constrain_frequency (314-343)
+ *   cand_bits [n_frames][11] bytes    bit (f & 7) of byte f >> 3 in row t: (t, f) is an onset peak >= onset_threshold
+ *   bend_map  [n_frames][88] int8     pitch bend of note bin f at frame t in 1/3 semitones; may be NULL without pitch bends
+ *   *status   0: decode with bp_notes_decode_candidates;  1: the maps hold a NaN or onset_threshold <= 0 (numpy's
+ *             propagation rules / every non-peak qualifies): decode the maps themselves with bp_notes_decode.
+ * bp_note_candidates takes the three maps from host or device memory (mem_kind) and leaves them untouched;
+ * bp_infer_pcm_raw_candidates is bp_infer_pcm_raw (inference.py:239 onwards) whose posteriorgrams stay on the device.
+ * All outputs are host buffers (page-locked ones from bp_host_alloc make the copies asynchronous). */
+int bp_note_candidates(bp_handle h, const float* note, const float* onset, const float* contour, int64_t n_frames,
+                       const bp_note_params* params, int mem_kind, float* note_out, uint8_t* cand_bits, int8_t* bend_map,
+                       int* status);
+int bp_infer_pcm_raw_candidates(bp_handle h, const void* pcm, int format, int64_t n_frames, int channels, int sample_rate,
+                                const bp_note_params* params, float* note_out, uint8_t* cand_bits, int8_t* bend_map,
+                                int* status);
+/* The sequential half (host): output_to_notes_polyphonic from the candidates (note_creation.py:404-509), pitch bends read
+ * from bend_map, frame times as bp_notes_decode.  `note` is only read. */
+int bp_notes_decode_candidates(const float* note, const uint8_t* cand_bits, const int8_t* bend_map, int64_t n_frames,
+                               const bp_note_params* params, bp_note_event* events, int64_t max_events, int32_t* bends,
+                               int64_t max_bends, int64_t* n_events, int64_t* n_bends);
 const char* bp_notes_last_error(void);
 
 /* ---- whole files, natively: decode -> posteriorgrams -> note events -> .mid / .csv (host C++ threads) ----------
@@ -368,7 +394,11 @@ typedef struct bp_transcribe_params {
   int32_t save_midi;            /* 1 */
   int32_t save_notes;           /* 1 */
   int32_t threads;              /* host worker threads; <= 0: one per hardware thread (at most 64) */
-  int32_t reserved[4];
+  int32_t host_decode;          /* 0 (default): the dense half of note decoding runs on the device and the note map, the
+                                   onset-peak bitmap and the pitch-bend map come back (bp_infer_pcm_raw_candidates: 7 MB per
+                                   3-minute track); 1: all three posteriorgrams come back (27.6 MB) and the host decodes
+                                   them (bp_notes_decode) — the round-4 path, same events */
+  int32_t reserved[3];
 } bp_transcribe_params;
 
 typedef struct bp_file_report {

@@ -232,3 +232,30 @@ def drop_overlapping_pitch_bends(events):
             note_events[i] = note_events[i][:-1] + (None,)
             note_events[j] = note_events[j][:-1] + (None,)
     return note_events
+
+
+def note_candidates(output, onset_thresh, infer_onsets=True, min_freq=None, max_freq=None, include_pitch_bends=True):
+    """What the device extracts for the host's note tracker (csrc/note_device.hip, bp_note_candidates), restated with the
+    functions above: (note map after constrain_frequency, bitmap [T][11] uint8 of the onset peaks that reach the
+    threshold — bit f & 7 of byte f >> 3 —, pitch-bend map [T][88] int8 or None).  note_creation.py:289-311, 314-343,
+    394-402, 182-219."""
+    frames = np.array(output["note"], dtype=np.float32, copy=True)
+    onsets = np.array(output["onset"], dtype=np.float32, copy=True)
+    contours = np.asarray(output["contour"], dtype=np.float32)
+    T = frames.shape[0]
+    onsets, frames = constrain_frequency(onsets, frames, max_freq, min_freq)
+    on = get_infered_onsets(onsets, frames) if infer_onsets else onsets
+    peak_thresh_mat = np.zeros(on.shape)
+    peaks = argrelmax_axis0(on)
+    peak_thresh_mat[peaks] = on[peaks]
+    cand = peak_thresh_mat >= onset_thresh
+    cand[-1:] = False  # a note cannot start in the last frame (note_creation.py:405-406); the device never marks it
+    bits = np.packbits(np.concatenate([cand, np.zeros((T, 0), bool)], axis=1), axis=1, bitorder="little")
+    assert bits.shape == (T, 11)
+    bend = None
+    if include_pitch_bends:
+        bend = np.zeros((T, 88), np.int8)
+        for b in range(88):
+            ev = get_pitch_bends(contours, [(0, T, b + MIDI_OFFSET, 0.0)])
+            bend[:, b] = np.asarray(ev[0][4], dtype=np.int64)
+    return frames, np.ascontiguousarray(bits), bend

@@ -191,7 +191,7 @@ def test_transcribe_files_equals_predict_and_save(tmp_path):
     _native.load_library().bp_files_release_buffers()
     out2 = tmp_path / "out2"
     out2.mkdir()
-    rep2 = transcribe_files(good, out2, models=[model], threads=2)
+    rep2 = transcribe_files(good, out2, models=[model], threads=2, host_decode=True)  # the round-4 path: all three maps back
     assert [r["status"] for r in rep2] == [0] * len(good)
     for p in good:
         stem = os.path.splitext(os.path.basename(str(p)))[0]
@@ -285,3 +285,48 @@ def test_raw_pcm_formats_equal_the_float_path(kind):
         for a, o, w in zip(ref, (0, T * 88, T * 176), (88, 88, 264)):
             assert np.array_equal(a.view(np.uint32).ravel(), got[o : o + T * w].view(np.uint32)), (kind, ch, w)
     assert lib.bp_infer_pcm_raw(model._handle, None, 99, 10, 1, 22050, None, None, None, 0) == _native.BP_ERR_INVALID_ARG
+
+
+@pytest.mark.gpu
+def test_lanes_on_two_devices_in_one_process(tmp_path):
+    """VERDICT r4 item 5c.  One native file job whose lanes live on different GPUs: with two or more devices on the box
+    bp_transcribe_files gets handles created with different device ordinals and must write the bytes of the one-device
+    job; on a one-GPU box the lane-to-device map of `lane_models` is asserted (device-major, `lanes` per device) and the job
+    runs with the same device named twice."""
+    import shutil
+
+    from basic_pitch_amd import Model, transcribe_files
+    from basic_pitch_amd.inference import lane_models
+
+    lib = _native.load_library()
+    n_dev = int(lib.bp_device_count())
+    assert n_dev >= 1
+    devs = [0, 1] if n_dev >= 2 else [0, 0]
+    models = lane_models(devices=devs, lanes=2)
+    try:
+        assert [m.info()["device"] for m in models] == [devs[0], devs[0], devs[1], devs[1]]
+        src = tmp_path / "in"
+        src.mkdir()
+        paths = []
+        for i in range(6):
+            shutil.copy(os.path.join(GOLDEN, "vocadito_10.wav"), src / f"c{i}.wav")
+            paths.append(src / f"c{i}.wav")
+        out_a, out_b = tmp_path / "a", tmp_path / "b"
+        out_a.mkdir(), out_b.mkdir()
+        rep = transcribe_files(paths, out_a, models=models, threads=4)
+        assert [r["status"] for r in rep] == [0] * 6 and all(r["n_note_events"] == 28 for r in rep)
+        one = Model(max_windows=64)
+        rep1 = transcribe_files(paths[:1], out_b, models=[one])
+        one.close()
+        assert rep1[0]["status"] == 0
+        ref_mid, ref_csv = (out_b / "c0_basic_pitch.mid").read_bytes(), (out_b / "c0_basic_pitch.csv").read_bytes()
+        for i in range(6):
+            assert (out_a / f"c{i}_basic_pitch.mid").read_bytes() == ref_mid and (out_a / f"c{i}_basic_pitch.csv").read_bytes() == ref_csv
+        # handles of different modes in one job are refused (the buffers of a file are sized from the first lane)
+        ext = Model(max_windows=8, ext_cqt_44k=True)
+        with pytest.raises(ValueError):
+            transcribe_files(paths[:1], tmp_path, models=[models[0], ext])
+        ext.close()
+    finally:
+        for m in models:
+            m.close()

@@ -1036,3 +1036,80 @@ def test_contour_march_equals_round_kernel(tmp_path):
     assert np.isfinite(outs["march"]).all()
     d = np.abs(outs["march"] - outs["rounds"]).max()
     assert d <= 2e-6, d
+
+
+def test_device_note_candidates_give_the_host_decoders_events(tmp_path):
+    """The dense half of note decoding on the device (csrc/note_device.hip: constrain_frequency, inferred onsets, peak
+    picking + threshold as a bitmap, the pitch bends of every (frame, bin); note_creation.py:289-343, 394-402, 182-219)
+    against its numpy restatement — bit-equal note map, bitmap and bend map on the 16 reference-generated cases and on
+    seeded fuzz maps — and, decoded by the host half, the events of bp_notes_decode bit for bit.  NaN maps and thresholds
+    <= 0 are reported back (status 1) for the map decoder."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import note_cases
+    from basic_pitch_amd import Model, note_creation as NC
+    from oracle import note_oracle as NO
+
+    m = Model(max_windows=8)
+
+    def check(out, args):
+        pb = args.get("include_pitch_bends", True)
+        prm = NC._note_params(args["onset_thresh"], args["frame_thresh"], args.get("min_note_len", 11),
+                              args.get("infer_onsets", True), args.get("max_freq"), args.get("min_freq"),
+                              args.get("melodia_trick", True), NC.ENERGY_TOLERANCE, pb)
+        before = {k: np.array(v, dtype=np.float32, copy=True) for k, v in out.items()}
+        note, bits, bend, status = m.note_candidates(out, prm)
+        for k in before:  # the caller's maps are left alone
+            assert np.array_equal(before[k], np.asarray(out[k], dtype=np.float32), equal_nan=True), k
+        if status:
+            return status
+        r_note, r_bits, r_bend = NO.note_candidates(out, args["onset_thresh"], args.get("infer_onsets", True),
+                                                    args.get("min_freq"), args.get("max_freq"), pb)
+        assert np.array_equal(note, r_note) and np.array_equal(bits, r_bits)
+        assert (bend is None and r_bend is None) or np.array_equal(bend, r_bend)
+        a = {k: v.copy() for k, v in before.items()}
+        raw, bends, n = NC._decode(a["note"], a["onset"], a["contour"], args["onset_thresh"], args["frame_thresh"],
+                                   args.get("min_note_len", 11), args.get("infer_onsets", True), args.get("max_freq"),
+                                   args.get("min_freq"), args.get("melodia_trick", True), NC.ENERGY_TOLERANCE, pb)
+        full = [(float(raw[i].start_s), float(raw[i].end_s), int(raw[i].pitch_midi), np.float32(raw[i].amplitude),
+                 bends[raw[i].bend_offset : raw[i].bend_offset + raw[i].n_bends].tolist() if pb else None) for i in range(n)]
+        got = NC.decode_candidates(note, bits, bend, prm)
+        assert len(got) == len(full)
+        for x, y in zip(got, full):
+            assert x[:3] == y[:3] and np.float32(x[3]).tobytes() == np.float32(y[3]).tobytes() and x[4] == y[4]
+        return 0
+
+    n_events = 0
+    for name in note_cases.CASES:
+        out, args = note_cases.case_args(name)
+        args = {k: v for k, v in args.items() if k not in ("multiple_pitch_bends", "midi_tempo")}
+        assert check(out, args) == 0, name
+    rng = np.random.default_rng(5)
+    for trial in range(12):
+        T = int(rng.integers(3, 3000))
+        out = {"note": rng.random((T, 88), dtype=np.float32) ** 3, "onset": rng.random((T, 88), dtype=np.float32) ** 4,
+               "contour": rng.random((T, 264), dtype=np.float32)}
+        if trial % 3 == 0:  # note-like structure: runs along time
+            out["note"] = np.repeat(out["note"][:: 7], 7, axis=0)[:T].copy()
+        args = dict(onset_thresh=float(rng.choice([0.2, 0.5, 0.9])), frame_thresh=float(rng.choice([0.1, 0.3])),
+                    infer_onsets=bool(rng.integers(0, 2)), melodia_trick=bool(trial % 2), min_note_len=int(rng.choice([3, 11])),
+                    include_pitch_bends=bool(rng.integers(0, 2)), min_freq=float(rng.choice([0, 100.0])) or None,
+                    max_freq=float(rng.choice([0, 2000.0])) or None)
+        assert check(out, args) == 0, trial
+    # device-resident maps (what the track path hands over), a silent map, and the two cases the host must take
+    import torch
+
+    out, args = note_cases.case_args("clip_default")
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda() for k, v in out.items()}
+    prm = NC._note_params(0.5, 0.3, 11, True, None, None, True, NC.ENERGY_TOLERANCE, True)
+    n1, b1, e1, s1 = m.note_candidates(dev, prm)
+    n2, b2, e2, s2 = m.note_candidates(out, prm)
+    assert s1 == s2 == 0 and np.array_equal(n1, n2) and np.array_equal(b1, b2) and np.array_equal(e1, e2)
+    zero = {"note": np.zeros((50, 88), np.float32), "onset": np.zeros((50, 88), np.float32), "contour": np.zeros((50, 264), np.float32)}
+    assert check(zero, dict(onset_thresh=0.5, frame_thresh=0.3)) == 0
+    bad = {k: v.copy() for k, v in zero.items()}
+    bad["onset"][7, 3] = np.nan
+    assert check(bad, dict(onset_thresh=0.5, frame_thresh=0.3)) == 1
+    assert check(zero, dict(onset_thresh=0.0, frame_thresh=0.3)) == 1
+    m.close()

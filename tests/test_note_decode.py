@@ -386,3 +386,66 @@ def test_drop_overlapping_pitch_bends_known_answer():
     midi = NC.note_events_to_midi([tuple(e) for e in events], multiple_pitch_bends=False)
     bends = [pb.time for inst in midi.instruments for pb in inst.pitch_bends]
     assert bends and all(1.0 <= t <= 1.2 for t in bends), bends
+
+
+def _events_both_ways(out, args):
+    """(events of bp_notes_decode on the maps, events of bp_notes_decode_candidates on oracle-built candidates)"""
+    from basic_pitch_amd import note_creation as NC
+
+    a = {k: np.ascontiguousarray(v, dtype=np.float32).copy() for k, v in out.items()}
+    raw, bends, n = NC._decode(a["note"], a["onset"], a["contour"], args["onset_thresh"], args["frame_thresh"],
+                               args.get("min_note_len", 11), args.get("infer_onsets", True), args.get("max_freq"),
+                               args.get("min_freq"), args.get("melodia_trick", True), NC.ENERGY_TOLERANCE,
+                               args.get("include_pitch_bends", True))
+    pb = args.get("include_pitch_bends", True)
+    full = [(float(raw[i].start_s), float(raw[i].end_s), int(raw[i].pitch_midi), np.float32(raw[i].amplitude),
+             bends[raw[i].bend_offset : raw[i].bend_offset + raw[i].n_bends].tolist() if pb else None) for i in range(n)]
+    prm = NC._note_params(args["onset_thresh"], args["frame_thresh"], args.get("min_note_len", 11),
+                          args.get("infer_onsets", True), args.get("max_freq"), args.get("min_freq"),
+                          args.get("melodia_trick", True), NC.ENERGY_TOLERANCE, pb)
+    note, bits, bend = NO.note_candidates(out, args["onset_thresh"], args.get("infer_onsets", True), args.get("min_freq"),
+                                          args.get("max_freq"), pb)
+    return full, NC.decode_candidates(note, bits, bend, prm)
+
+
+@pytest.mark.parametrize("name", list(note_cases.CASES))
+def test_candidate_decoder_equals_map_decoder_on_the_reference_cases(name):
+    """bp_notes_decode_candidates — the host half of the device-assisted decoding (round 5): the onset peaks as a bitmap
+    and the pitch bends as a (frame, bin) map instead of the onset and contour maps — gives the events of bp_notes_decode,
+    bit for bit, on every reference-generated case.  The candidates here are built by the numpy restatement
+    (oracle/note_oracle.py::note_candidates); the gpu suite holds the device kernels to the same restatement."""
+    out, args = note_cases.case_args(name)
+    args = {k: v for k, v in args.items() if k not in ("multiple_pitch_bends", "midi_tempo")}
+    full, cand = _events_both_ways(out, args)
+    assert len(full) > 0
+    _same_events(cand, full)
+
+
+def test_candidate_decoder_fuzz():
+    rng = np.random.default_rng(77)
+    for trial in range(30):
+        T = int(rng.integers(3, 400))
+        out = _fuzz_maps(rng, T, "plain" if trial % 2 else "flat")
+        args = dict(onset_thresh=float(rng.choice([0.05, 0.2, 0.5, 0.9, 1.5])), frame_thresh=float(rng.choice([0.0, 0.1, 0.3, 0.6])),
+                    infer_onsets=bool(rng.integers(0, 2)), melodia_trick=bool(rng.integers(0, 2)),
+                    min_note_len=int(rng.choice([0, 3, 11])), include_pitch_bends=bool(rng.integers(0, 2)),
+                    min_freq=float(rng.choice([0, 100.0])) or None, max_freq=float(rng.choice([0, 2000.0])) or None)
+        full, cand = _events_both_ways(out, args)
+        _same_events(cand, full)
+
+
+def test_candidate_decoder_refuses_what_needs_the_maps():
+    """An onset threshold <= 0 makes every cell that is not a peak a candidate (note_creation.py:398-402): that takes the
+    onset map, and the candidate entry point says so instead of decoding something else."""
+    import ctypes as C
+
+    from basic_pitch_amd import _native, note_creation as NC
+
+    lib = _native.load_library()
+    prm = NC._note_params(0.0, 0.3, 11, True, None, None, True, NC.ENERGY_TOLERANCE, False)
+    note = np.zeros((10, 88), np.float32)
+    bits = np.zeros((10, 11), np.uint8)
+    n_ev, n_b = C.c_int64(), C.c_int64()
+    rc = lib.bp_notes_decode_candidates(note.ctypes.data, bits.ctypes.data, None, 10, C.byref(prm), None, 0, None, 0,
+                                        C.byref(n_ev), C.byref(n_b))
+    assert rc == _native.BP_ERR_INVALID_ARG and b"onset threshold" in lib.bp_notes_last_error()

@@ -45,3 +45,10 @@ for kern, kn in ((0, "pyramid"), (1, "filterbank")):
             row = [(t[w, i] - t[w, 0]) * scale[w] for i in range(1, n)]
             mhz = ticks[w] / rt[w] if rt[w] > 0 else 0
             print(f"   {w:4d}  {(t[w, 0] - e0) * scale[w]:13.2f} " + " ".join(f"{v:11.2f}" for v in row) + f"   | {rt[w]:7.2f} {mhz:7.0f}")
+
+# the boundary between the two launches as the device's 100 MHz clock saw it (same workgroup slot, wave 0)
+for slot in (0, 1):
+    pyr_in, pyr_out = a[0, slot, 0, 14], a[0, slot, 0, 15]
+    fb_in, fb_out = a[1, slot, 0, 14], a[1, slot, 0, 15]
+    print(f"slot {slot}: pyramid in-kernel {(pyr_out - pyr_in) / 100.0:.2f} us | exit -> filterbank entry {(fb_in - pyr_out) / 100.0:.2f} us | "
+          f"filterbank in-kernel {(fb_out - fb_in) / 100.0:.2f} us | pyramid entry -> filterbank exit {(fb_out - pyr_in) / 100.0:.2f} us")
