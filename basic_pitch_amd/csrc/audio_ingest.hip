@@ -132,18 +132,38 @@ __device__ __forceinline__ float pcm_sample(const uint8_t* __restrict__ raw, int
   return reinterpret_cast<const float*>(raw)[i];
 }
 
+// Four frames per thread (round 5: one frame per thread moved 63 MB in 34 us, a quarter of what the memory system streams;
+// in a file job this kernel runs once per file).  16-bit stereo — what a CD-quality WAV holds — takes them as one 16-byte
+// load and one 16-byte store; every format and channel count computes a frame exactly as before.
 template <int FMT>
 __global__ __launch_bounds__(256) void downmix_raw_kernel(const uint8_t* __restrict__ raw, int64_t n_frames, int channels,
                                                           float* __restrict__ mono) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_frames) return;
-  if (channels == 1) {
-    mono[i] = pcm_sample<FMT>(raw, i);
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n_frames) return;
+  if (FMT == BP_PCM_S16 && channels == 2 && i4 + 4 <= n_frames &&
+      ((reinterpret_cast<uintptr_t>(raw) | reinterpret_cast<uintptr_t>(mono)) & 15) == 0) {
+    const uint4 v = *reinterpret_cast<const uint4*>(raw + i4 * 4);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float s = 0.0f;
+      s += (float)(int16_t)(w[k] & 0xffffu) * (1.0f / 32768.0f);
+      s += (float)(int16_t)(w[k] >> 16) * (1.0f / 32768.0f);
+      o[k] = s / 2.0f;
+    }
+    *reinterpret_cast<float4*>(mono + i4) = float4{o[0], o[1], o[2], o[3]};
     return;
   }
-  float s = 0.0f;
-  for (int c = 0; c < channels; ++c) s += pcm_sample<FMT>(raw, i * channels + c);
-  mono[i] = s / (float)channels;
+  for (int64_t i = i4; i < i4 + 4 && i < n_frames; ++i) {
+    if (channels == 1) {
+      mono[i] = pcm_sample<FMT>(raw, i);
+      continue;
+    }
+    float s = 0.0f;
+    for (int c = 0; c < channels; ++c) s += pcm_sample<FMT>(raw, i * channels + c);
+    mono[i] = s / (float)channels;
+  }
 }
 
 // y[k] = sum_j x[j] h[k * down + centre - j * up], the signal zero outside [0, n_in)
@@ -293,7 +313,7 @@ void launch_downmix(const float* pcm, int64_t n_frames, int channels, float* mon
 
 void launch_downmix_raw(const void* raw, int format, int64_t n_frames, int channels, float* mono, hipStream_t stream) {
   if (n_frames <= 0) return;
-  const dim3 grid((unsigned)((n_frames + 255) / 256));
+  const dim3 grid((unsigned)((n_frames + 1023) / 1024));  // four frames per thread
   const uint8_t* p = static_cast<const uint8_t*>(raw);
   switch (format) {
     case BP_PCM_S16: hipLaunchKernelGGL(downmix_raw_kernel<BP_PCM_S16>, grid, dim3(256), 0, stream, p, n_frames, channels, mono); break;

@@ -24,6 +24,8 @@ void launch_window_tracks(const TrackSegs& ts, int n_slots, float* audio, int wi
                           hipStream_t stream);
 void launch_unwrap_tracks(const TrackSegs& ts, int n_slots, const float* note, const float* onset, const float* contour,
                           hipStream_t stream);
+void launch_unwrap3(const float* note, const float* onset, const float* contour, int64_t first_window, int n_windows,
+                    int64_t total_rows, float* o_note, float* o_onset, float* o_contour, hipStream_t stream);
 void launch_unwrap(const float* win_out, int n_freq, int64_t first_window, int n_windows,
                    int64_t total_rows, float* out, hipStream_t s);
 size_t filterbank_scratch_floats(int n_windows);
@@ -96,6 +98,10 @@ void launch_note_march(const float* contour, const void* wfrag, const float* wf3
 void launch_note_candidates(float* note, float* onset, const float* contour, int64_t T, int lo, int hi, int infer,
                             double onset_thresh, const void* tab, const double* gauss, void* stats, uint8_t* bits,
                             int8_t* bend, hipStream_t s);
+void launch_note_export(const void* note, void* note_dst, int64_t note_bytes, const void* bits, void* bits_dst,
+                        int64_t bits_bytes, const void* bend, void* bend_dst, int64_t bend_bytes, void* stats,
+                        void* stats_dst, hipStream_t s);
+void launch_note_stats_init(void* stats, hipStream_t s);
 void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, const void* wmx,
                          float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
 // the onset branch: the wave-private march on 16x16x32; the workgroup kernel for the fp8-correction mode (it carries the
@@ -262,6 +268,8 @@ struct bp_context {
   int64_t nd_cap = 0;          // floats
   float* nd_tables = nullptr;  // [88] int4 windows, [51] double Gaussian, then the stats record
   float* nd_stats_host = nullptr;  // page-locked copy of the stats record
+  void* nd_stats_host_dev = nullptr;  // the same buffer as the device sees it
+  bool nd_stats_ready = false;     // the device record holds its initial values (the export kernel leaves it so)
 
   // stage timing: a ring of event sets, one per chunk, averaged by bp_get_stage_ms
   static constexpr int kTimedRing = 128;
@@ -1412,11 +1420,7 @@ static int track_core(bp_handle h, const float* d_samples, int64_t n_samples, fl
     launch_window_track(d_samples, n_samples, w0, n, h->audio, h->win_len, h->hop, h->lead, s);
     int rc = run_chunk(h, h->audio, n, h->note, h->onset, h->contour);
     if (rc) return rc;
-    if (T > 0) {
-      launch_unwrap(h->note, 88, w0, n, T, d_note, s);
-      launch_unwrap(h->onset, 88, w0, n, T, d_onset, s);
-      launch_unwrap(h->contour, 264, w0, n, T, d_contour, s);
-    }
+    if (T > 0) launch_unwrap3(h->note, h->onset, h->contour, w0, n, T, d_note, d_onset, d_contour, s);
   }
   BP_HIP(hipGetLastError());
   if (out_kind == kTrackOutInternal) return BP_OK;
@@ -1707,24 +1711,50 @@ static int candidates_core(bp_handle h, float* d_note, float* d_onset, const flo
     int rc = upload(h, raw, &h->nd_tables);
     if (rc) return rc;
     BP_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->nd_stats_host), kStatsBytes, hipHostMallocPortable));
+    BP_HIP(hipHostGetDevicePointer(&h->nd_stats_host_dev, h->nd_stats_host, 0));
   }
-  const int64_t bits_bytes = (T * 11 + 15) & ~(int64_t)15, bend_bytes = T * 88;
-  int rc = grow(h, &h->nd_buf, &h->nd_cap, (bits_bytes + bend_bytes + 3) / 4);
+  const int64_t bits_bytes = T * BP_NOTE_CAND_ROW_BYTES, bend_bytes = T * 88;  // multiples of 4
+  int rc = grow(h, &h->nd_buf, &h->nd_cap, (((bits_bytes + 15) & ~(int64_t)15) + bend_bytes + 3) / 4);
   if (rc) return rc;
   uint8_t* d_bits = reinterpret_cast<uint8_t*>(h->nd_buf);
-  int8_t* d_bend = reinterpret_cast<int8_t*>(d_bits + bits_bytes);
+  int8_t* d_bend = reinterpret_cast<int8_t*>(d_bits + ((bits_bytes + 15) & ~(int64_t)15));
   char* tables = reinterpret_cast<char*>(h->nd_tables);
   void* d_stats = tables + kTabBytes + kGaussBytes;
   int lo = 0, hi = 88;
   bp_internal_freq_limits(prm, &lo, &hi);
   const bool want_bends = prm->include_pitch_bends != 0 && bend_out != nullptr;
+  if (!h->nd_stats_ready) launch_note_stats_init(d_stats, s);
+  h->nd_stats_ready = false;
   launch_note_candidates(d_note, d_onset, d_contour, T, lo, hi, prm->infer_onsets != 0, prm->onset_threshold, tables,
                          reinterpret_cast<const double*>(tables + kTabBytes), d_stats, d_bits, want_bends ? d_bend : nullptr, s);
   BP_HIP(hipGetLastError());
-  BP_HIP(hipMemcpyAsync(h->nd_stats_host, d_stats, kStatsBytes, hipMemcpyDeviceToHost, s));
-  BP_HIP(hipMemcpyAsync(note_out, d_note, (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
-  BP_HIP(hipMemcpyAsync(cand_out, d_bits, (size_t)T * 11, hipMemcpyDeviceToHost, s));
-  if (want_bends) BP_HIP(hipMemcpyAsync(bend_out, d_bend, (size_t)bend_bytes, hipMemcpyDeviceToHost, s));
+  // The results go home.  Into page-locked buffers (bp_host_alloc) a kernel of this stream writes them over PCIe itself:
+  // the copy engine serialises the copies of all lanes in both directions (measured: a lane's 27 MB of posteriorgrams
+  // going out kept the next file's samples from coming in), and it is busy with the inbound samples.  Pageable
+  // destinations take ordinary copies.
+  auto device_view = [](void* p) -> void* {
+    if (!p) return nullptr;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+  };
+  void *v_note = device_view(note_out), *v_bits = device_view(cand_out), *v_bend = want_bends ? device_view(bend_out) : nullptr;
+  const bool aligned = !((reinterpret_cast<uintptr_t>(v_note) | reinterpret_cast<uintptr_t>(v_bits) | reinterpret_cast<uintptr_t>(v_bend)) & 3);
+  if (v_note && v_bits && (v_bend || !want_bends) && aligned) {
+    // ... the stats record with them; the same kernel leaves the device record initialised for the next track
+    launch_note_export(d_note, v_note, T * 88 * 4, d_bits, v_bits, bits_bytes, d_bend, v_bend, bend_bytes, d_stats,
+                       h->nd_stats_host_dev, s);
+    BP_HIP(hipGetLastError());
+    h->nd_stats_ready = true;
+  } else {
+    BP_HIP(hipMemcpyAsync(h->nd_stats_host, d_stats, kStatsBytes, hipMemcpyDeviceToHost, s));
+    BP_HIP(hipMemcpyAsync(note_out, d_note, (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
+    BP_HIP(hipMemcpyAsync(cand_out, d_bits, (size_t)bits_bytes, hipMemcpyDeviceToHost, s));
+    if (want_bends) BP_HIP(hipMemcpyAsync(bend_out, d_bend, (size_t)bend_bytes, hipMemcpyDeviceToHost, s));
+  }
   rc = wait_stream(h);
   if (rc) return rc;
   const int nan_flag = reinterpret_cast<const int*>(h->nd_stats_host)[1];

@@ -1041,9 +1041,18 @@ __global__ __launch_bounds__(THREADS) void cqt_filterbank_planes_kernel(
         pl_split8(a, c, ah[s], al[s]);
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifdef PL_FB_PAIRED
+      // tools (A/B): the second correction product of item i - 1 behind the first two of item i, so that the two updates of
+      // an xx accumulator are three matrix instructions apart instead of back to back (same order per accumulator: same bits)
+      hh[q] = BP_PL_MFMA16(ah[s], bh[i], hh[q]);
+      xx[q] = BP_PL_MFMA16(al[s], bh[i], xx[q]);
+      if (i > 0) xx[item(i - 1).q] = BP_PL_MFMA16(ah[item(i - 1).s], bw[i - 1], xx[item(i - 1).q]);
+      if (i + 1 == kPlFbFrags) xx[q] = BP_PL_MFMA16(ah[s], bw[i], xx[q]);
+#else
       hh[q] = BP_PL_MFMA16(ah[s], bh[i], hh[q]);
       xx[q] = BP_PL_MFMA16(al[s], bh[i], xx[q]);
       xx[q] = BP_PL_MFMA16(ah[s], bw[i], xx[q]);
+#endif
       if (i + 1 == kPlFbFrags || item(i + 1).s != s) {  // last product of k-step s: its ring slot takes step s + APF
         const int sn = s + APF;
         if (sn < 7) {
@@ -1261,8 +1270,10 @@ void launch_pyramid_planes(const float* audio, int64_t audio_stride, uint16_t* p
                            bool ext, hipStream_t stream) {
   const PlGeo g = make_pl_geo(ext);
   const uint4* tf = static_cast<const uint4*>(tfrag);
-  // with at least half a window per CU the whole pyramid is ONE launch, a workgroup per window
-  const bool one_launch = n_windows >= n_cu / 2;
+  // with at least half a window per CU the whole pyramid is ONE launch, a workgroup per window (the 22.05 kHz kernel from
+  // a third: a 3-minute track is 110 windows, and the four wide launches it took below half the CUs cost 55 us where
+  // 110 workgroups of the per-window kernel take 40)
+  const bool one_launch = ext ? n_windows >= n_cu / 2 : 3 * n_windows >= n_cu;
   if (one_launch && !ext) {
     hipLaunchKernelGGL(pl_pyramid_window_kernel, dim3(n_windows), dim3(kPwThreads), 0, stream, audio, audio_stride, pl, g, tf);
     return;

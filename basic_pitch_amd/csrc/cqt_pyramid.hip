@@ -143,6 +143,30 @@ __global__ __launch_bounds__(256) void unwrap_kernel(const float* __restrict__ w
   }
 }
 
+// the three maps of a chunk in ONE launch (blockIdx.z = map): three launches of this small kernel cost a track ~30 us
+__global__ __launch_bounds__(256) void unwrap3_kernel(const float* __restrict__ note, const float* __restrict__ onset,
+                                                      const float* __restrict__ contour, int64_t first_window,
+                                                      int64_t total_rows, float* __restrict__ o_note,
+                                                      float* __restrict__ o_onset, float* __restrict__ o_contour) {
+  const int m = blockIdx.z;
+  const int n_freq = m == 2 ? kFreqC : kFreqN;
+  const float* win_out = m == 0 ? note : (m == 1 ? onset : contour);
+  float* out = m == 0 ? o_note : (m == 1 ? o_onset : o_contour);
+  const int lw = blockIdx.y;
+  const int64_t row0 = (first_window + lw) * 142;
+  const float* src = win_out + ((int64_t)lw * kFrames + 15) * n_freq;
+  const int n = 142 * n_freq;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int64_t row = row0 + i / n_freq;
+    if (row < total_rows) out[row0 * n_freq + i] = src[i];
+  }
+}
+void launch_unwrap3(const float* note, const float* onset, const float* contour, int64_t first_window, int n_windows,
+                    int64_t total_rows, float* o_note, float* o_onset, float* o_contour, hipStream_t stream) {
+  hipLaunchKernelGGL(unwrap3_kernel, dim3(16, n_windows, 3), dim3(256), 0, stream, note, onset, contour, first_window,
+                     total_rows, o_note, o_onset, o_contour);
+}
+
 void launch_unwrap(const float* win_out, int n_freq, int64_t first_window, int n_windows,
                    int64_t total_rows, float* out, hipStream_t stream) {
   hipLaunchKernelGGL(unwrap_kernel, dim3(16, n_windows), dim3(256), 0, stream, win_out, n_freq,

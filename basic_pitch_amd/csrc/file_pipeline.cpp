@@ -724,9 +724,9 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
       float* onset = note + T * 88;
       float* contour = onset + T * 88;
       // device-side candidates (the default): the same page-locked buffer holds the note map, the onset-peak bitmap
-      // (T x 11 bytes, from a 16-byte boundary) and the pitch-bend map (T x 88 bytes) instead of the onset / contour maps
+      // (T x 12 bytes) and, from a 16-byte boundary, the pitch-bend map (T x 88 bytes) instead of the onset / contour maps
       uint8_t* cand_bits = reinterpret_cast<uint8_t*>(onset);
-      int8_t* bend_map = reinterpret_cast<int8_t*>(cand_bits + ((T * 11 + 15) & ~(int64_t)15));
+      int8_t* bend_map = reinterpret_cast<int8_t*>(cand_bits + ((T * BP_NOTE_CAND_ROW_BYTES + 15) & ~(int64_t)15));
       bool use_cand = !prm.host_decode && prm.notes.onset_threshold > 0.0;
       rep->ms_read = lap();
       const int lane = acquire();

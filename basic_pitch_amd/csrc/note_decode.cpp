@@ -173,7 +173,7 @@ void bp_note_params_default(bp_note_params* p) {
 // The decoder.  Two sources for the onset peaks and the pitch bends:
 //   cand_bits == null: the onset and contour maps (bp_notes_decode: everything on the host);
 //   cand_bits != null: the device extracted them (bp_note_candidates, csrc/note_device.hip): bit f of byte row t
-//     ([T][11] bytes) marks an onset peak that reaches the threshold, bend_map [T][88] holds the pitch bend of bin f at
+//     ([T][12] bytes, BP_NOTE_CAND_ROW_BYTES) marks an onset peak that reaches the threshold, bend_map [T][88] holds the pitch bend of bin f at
 //     frame t; `note` is already frequency-constrained, `onset` / `contour` are not looked at.
 static int decode_core(float* note, float* onset, const float* contour, const uint8_t* cand_bits, const int8_t* bend_map,
                        int64_t n_frames, const bp_note_params* prm, bp_note_event* events, int64_t max_events,
@@ -328,7 +328,7 @@ static int decode_core(float* note, float* onset, const float* contour, const ui
   if (cand) {
     // the device's peaks, visited like the loop below: backwards in time, downwards in frequency
     for (int64_t t = T - 2; t >= 1; --t) {
-      const uint8_t* row = cand_bits + t * 11;
+      const uint8_t* row = cand_bits + t * BP_NOTE_CAND_ROW_BYTES;
       uint64_t lo8;
       std::memcpy(&lo8, row, 8);
       const uint32_t hi3 = (uint32_t)row[8] | ((uint32_t)row[9] << 8) | ((uint32_t)row[10] << 16);

@@ -2,9 +2,11 @@
 // peak picking, thresholding").  The posteriorgrams of a track are already in HBM when the CNN is done; what the host's
 // note tracker (csrc/note_decode.cpp, the sequential half) needs of them is
 //   * the note map (T x 88 float32) — it follows energies along a pitch and averages amplitudes,
-//   * WHERE the onset peaks are: a bitmap (T x 88 bits), not the onset map,
+//   * WHERE the onset peaks are: a bitmap (T x 12 bytes: 88 bits per frame), not the onset map,
 //   * the pitch bend of bin f at frame t: T x 88 int8, not the 264-bin contour map,
-// 7.1 MB per 3-minute track instead of 27.6 MB over PCIe, and the three dense scans leave the host cores.
+// 7.0 MB per 3-minute track instead of 27.6 MB over PCIe — written into page-locked host memory by the kernels
+// themselves when the caller's buffers are (no copy engine: the engine is busy bringing the next file in) —, and the
+// three dense scans leave the host cores.
 //
 // Reference lines (spotify/basic-pitch v0.4.0, basic_pitch/note_creation.py):
 //   constrain_frequency   314-343   bins outside [min, max] zeroed in the note and onset maps
@@ -19,6 +21,7 @@
 namespace bp {
 
 constexpr int kNdF = 88, kNdFC = 264;
+constexpr int kNdBitsRow = 12;  // bytes per frame of the onset-peak bitmap: 88 bits + 8 zero bits (rows of whole dwords)
 
 struct NdStats {
   int max_on_ord;                  // f2ord(max onset)
@@ -34,32 +37,39 @@ __global__ __launch_bounds__(256) void nd_constrain_kernel(float* __restrict__ n
   if (f < lo || f >= hi) note[i] = onset[i] = 0.0f;
 }
 
-__global__ __launch_bounds__(256) void nd_stats_init_kernel(NdStats* st) {
-  st->max_on_ord = f2ord(-__int_as_float(0x7f800000));
-  st->nan = 0;
-  st->max_fd_bits = 0ull;
+__global__ __launch_bounds__(64) void nd_stats_init_kernel(NdStats* st) {
+  if (threadIdx.x == 0) {
+    st->max_on_ord = f2ord(-__int_as_float(0x7f800000));
+    st->nan = 0;
+    st->max_fd_bits = 0ull;
+  }
 }
 
-// one wave per frame: lanes take bins lane and lane + 64
+// Extrema of the two maps.  A wave walks frames (lanes take bins lane and lane + 64), a workgroup folds its four waves in
+// LDS and publishes ONE atomic per quantity (as first written, every frame's wave published its own: 15 k serialised
+// atomics per 3-minute track on three addresses, 0.36 ms — more than the CQT of the track).
 __global__ __launch_bounds__(256) void nd_stats_kernel(const float* __restrict__ note, const float* __restrict__ onset, int64_t T,
                                                        int infer, NdStats* __restrict__ st) {
-  const int lane = threadIdx.x & 63;
-  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= T) return;
+  __shared__ float s_mo[4];
+  __shared__ double s_fd[4];
+  __shared__ int s_nan[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float mo = -__int_as_float(0x7f800000);
   double mfd = 0.0;
   int nan = 0;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < T; t += (int64_t)gridDim.x * 4) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int f = lane + 64 * h;
-    if (f >= kNdF) break;
-    const float o = onset[t * kNdF + f], n0 = note[t * kNdF + f];
-    nan |= (o != o) | (n0 != n0);
-    mo = o > mo ? o : mo;
-    if (infer && t >= 2) {
-      const double d1 = (double)n0 - (double)note[(t - 1) * kNdF + f], d2 = (double)n0 - (double)note[(t - 2) * kNdF + f];
-      const double d = d1 < d2 ? d1 : d2;
-      mfd = d > mfd ? d : mfd;
+    for (int h = 0; h < 2; ++h) {
+      const int f = lane + 64 * h;
+      if (f >= kNdF) break;
+      const float o = onset[t * kNdF + f], n0 = note[t * kNdF + f];
+      nan |= (o != o) | (n0 != n0);
+      mo = o > mo ? o : mo;
+      if (infer && t >= 2) {
+        const double d1 = (double)n0 - (double)note[(t - 1) * kNdF + f], d2 = (double)n0 - (double)note[(t - 2) * kNdF + f];
+        const double d = d1 < d2 ? d1 : d2;
+        mfd = d > mfd ? d : mfd;
+      }
     }
   }
 #pragma unroll
@@ -70,7 +80,14 @@ __global__ __launch_bounds__(256) void nd_stats_kernel(const float* __restrict__
     mfd = b > mfd ? b : mfd;
     nan |= __shfl_xor(nan, o);
   }
-  if (lane == 0) {
+  if (lane == 0) s_mo[wave] = mo, s_fd[wave] = mfd, s_nan[wave] = nan;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      mo = s_mo[w] > mo ? s_mo[w] : mo;
+      mfd = s_fd[w] > mfd ? s_fd[w] : mfd;
+      nan |= s_nan[w];
+    }
     atomicMax(&st->max_on_ord, f2ord(mo));
     if (mfd > 0.0) atomicMax(&st->max_fd_bits, (unsigned long long)__double_as_longlong(mfd));
     if (nan) atomicOr(&st->nan, 1);
@@ -85,7 +102,7 @@ __device__ __forceinline__ double nd_np_maximum(double a, double b) {
 
 __global__ __launch_bounds__(256) void nd_candidates_kernel(const float* __restrict__ note, const float* __restrict__ onset,
                                                             int64_t T, int infer, double onset_thresh,
-                                                            const NdStats* __restrict__ st, uint8_t* __restrict__ bits) {
+                                                            const NdStats* __restrict__ st, uint32_t* __restrict__ bits) {
   const int lane = threadIdx.x & 63;
   const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= T) return;
@@ -115,35 +132,71 @@ __global__ __launch_bounds__(256) void nd_candidates_kernel(const float* __restr
     }
   }
   const unsigned long long b0 = __ballot(c[0]), b1 = __ballot(c[1]);
-  if (lane < 11) bits[t * 11 + lane] = (uint8_t)(lane < 8 ? (b0 >> (8 * lane)) : (b1 >> (8 * (lane - 8))));
+  if (lane < 3) bits[t * 3 + lane] = lane == 0 ? (uint32_t)b0 : (lane == 1 ? (uint32_t)(b0 >> 32) : (uint32_t)b1);
 }
 
+// One wave per frame: the contour row goes to LDS as float64 once (264 conversions instead of 88 x 51), lanes take bins
+// lane and lane + 64; the products and the running maximum in float64 like the host's loop.
 __global__ __launch_bounds__(256) void nd_bend_kernel(const float* __restrict__ contour, int64_t T, const int4* __restrict__ tab,
                                                       const double* __restrict__ gauss, int8_t* __restrict__ bend) {
-  const int lane = threadIdx.x & 63;
-  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= T) return;
-  const float* row = contour + t * kNdFC;
+  __shared__ double s_row[4][kNdFC];
+  __shared__ double s_g[51];
+  __shared__ int4 s_tab[kNdF];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 51) s_g[threadIdx.x] = gauss[threadIdx.x];
+  if (threadIdx.x < kNdF) s_tab[threadIdx.x] = tab[threadIdx.x];
+  for (int64_t t0 = (int64_t)blockIdx.x * 4; t0 < T; t0 += (int64_t)gridDim.x * 4) {
+    const int64_t t = t0 + wave;
+    __syncthreads();  // the tables (first pass) / the previous frame's row is read
+    if (t < T)
+      for (int i = lane; i < kNdFC; i += 64) s_row[wave][i] = (double)contour[t * kNdFC + i];
+    __syncthreads();
+    if (t >= T) continue;
+    const double* row = s_row[wave];
+    int8_t out[2] = {0, 0};
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int b = lane + 64 * h;
-    if (b >= kNdF) break;
-    const int4 w = tab[b];  // f0, n, g0, shift
-    int best = 0;
-    double bestv = (double)row[w.x] * gauss[w.z];
-    for (int j = 1; j < w.y; ++j) {
-      const double v = (double)row[w.x + j] * gauss[w.z + j];
-      if (v > bestv || (v != v && bestv == bestv)) {  // np.argmax: first maximum, NaN wins
-        bestv = v;
-        best = j;
+    for (int h = 0; h < 2; ++h) {
+      const int b = lane + 64 * h;
+      if (b >= kNdF) break;
+      const int4 w = s_tab[b];  // f0, n, g0, shift
+      int best = 0;
+      double bestv = row[w.x] * s_g[w.z];
+      for (int j = 1; j < w.y; ++j) {
+        const double v = row[w.x + j] * s_g[w.z + j];
+        if (v > bestv || (v != v && bestv == bestv)) {  // np.argmax: first maximum, NaN wins
+          bestv = v;
+          best = j;
+        }
       }
+      out[h] = (int8_t)(best - w.w);
     }
-    bend[t * kNdF + b] = (int8_t)(best - w.w);
+    bend[t * kNdF + lane] = out[0];
+    if (lane + 64 < kNdF) bend[t * kNdF + lane + 64] = out[1];
   }
 }
 
-// note / onset / contour: device maps of T frames.  Leaves the bitmap, the bend map (when `bend` != null) and the stats
-// on the device; `lo`, `hi`: the bins constrain_frequency keeps (0, 88: none to zero).
+// device -> page-locked host memory, by the compute queue: the note map, the bitmap and the bend map of a track in one
+// launch (4-byte words, a wave writes 256 contiguous bytes; the copy engine stays free for the next file's samples), the
+// stats record with them — and the device record back to its initial values for the next track (one launch and one
+// 16-byte copy fewer per track).
+__global__ __launch_bounds__(256) void nd_export_kernel(const uint32_t* __restrict__ s0, uint32_t* __restrict__ d0, int64_t n0,
+                                                        const uint32_t* __restrict__ s1, uint32_t* __restrict__ d1, int64_t n1,
+                                                        const uint32_t* __restrict__ s2, uint32_t* __restrict__ d2, int64_t n2,
+                                                        NdStats* __restrict__ st, NdStats* __restrict__ st_dst) {
+  const int64_t step = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n0; i += step) d0[i] = s0[i];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n1; i += step) d1[i] = s1[i];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += step) d2[i] = s2[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *st_dst = *st;
+    st->max_on_ord = f2ord(-__int_as_float(0x7f800000));
+    st->nan = 0;
+    st->max_fd_bits = 0ull;
+  }
+}
+
+// note / onset / contour: device maps of T frames.  Leaves the bitmap ([T][12] bytes), the bend map ([T][88] bytes, when
+// `bend` != null) and the stats on the device (the stats record must hold its initial values: launch_note_stats_init); `lo`, `hi`: the bins constrain_frequency keeps (0, 88: none to zero).
 void launch_note_candidates(float* note, float* onset, const float* contour, int64_t T, int lo, int hi, int infer,
                             double onset_thresh, const void* tab, const double* gauss, void* stats, uint8_t* bits,
                             int8_t* bend, hipStream_t s) {
@@ -152,11 +205,27 @@ void launch_note_candidates(float* note, float* onset, const float* contour, int
   const unsigned frames4 = (unsigned)((T + 3) / 4);
   if (lo > 0 || hi < kNdF)
     hipLaunchKernelGGL(nd_constrain_kernel, dim3((unsigned)((T * kNdF + 255) / 256)), dim3(256), 0, s, note, onset, T * kNdF, lo, hi);
-  hipLaunchKernelGGL(nd_stats_init_kernel, dim3(1), dim3(1), 0, s, st);
-  hipLaunchKernelGGL(nd_stats_kernel, dim3(frames4), dim3(256), 0, s, note, onset, T, infer, st);
-  hipLaunchKernelGGL(nd_candidates_kernel, dim3(frames4), dim3(256), 0, s, note, onset, T, infer, onset_thresh, st, bits);
+  hipLaunchKernelGGL(nd_stats_kernel, dim3(frames4 < 512u ? frames4 : 512u), dim3(256), 0, s, note, onset, T, infer, st);
+  hipLaunchKernelGGL(nd_candidates_kernel, dim3(frames4), dim3(256), 0, s, note, onset, T, infer, onset_thresh, st,
+                     reinterpret_cast<uint32_t*>(bits));
   if (bend)
-    hipLaunchKernelGGL(nd_bend_kernel, dim3(frames4), dim3(256), 0, s, contour, T, static_cast<const int4*>(tab), gauss, bend);
+    hipLaunchKernelGGL(nd_bend_kernel, dim3(frames4 < 1024u ? frames4 : 1024u), dim3(256), 0, s, contour, T,
+                       static_cast<const int4*>(tab), gauss, bend);
+}
+
+void launch_note_stats_init(void* stats, hipStream_t s) {
+  hipLaunchKernelGGL(nd_stats_init_kernel, dim3(1), dim3(64), 0, s, static_cast<NdStats*>(stats));
+}
+
+// the three results to device-visible host pointers (sizes in bytes, multiples of 4; a null destination is skipped)
+void launch_note_export(const void* note, void* note_dst, int64_t note_bytes, const void* bits, void* bits_dst,
+                        int64_t bits_bytes, const void* bend, void* bend_dst, int64_t bend_bytes, void* stats,
+                        void* stats_dst, hipStream_t s) {
+  hipLaunchKernelGGL(nd_export_kernel, dim3(64), dim3(256), 0, s, static_cast<const uint32_t*>(note),
+                     static_cast<uint32_t*>(note_dst), note_dst ? note_bytes / 4 : 0, static_cast<const uint32_t*>(bits),
+                     static_cast<uint32_t*>(bits_dst), bits_dst ? bits_bytes / 4 : 0, static_cast<const uint32_t*>(bend),
+                     static_cast<uint32_t*>(bend_dst), bend_dst ? bend_bytes / 4 : 0, static_cast<NdStats*>(stats),
+                     static_cast<NdStats*>(stats_dst));
 }
 
 }  // namespace bp

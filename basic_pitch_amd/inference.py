@@ -304,7 +304,7 @@ class Model:
     def note_candidates(self, output: Dict[str, Any], prm) -> Tuple[np.ndarray, np.ndarray, Optional[np.ndarray], int]:
         """The dense half of note decoding on the device (`bp_note_candidates`, csrc/note_device.hip) for the posteriorgrams
         `output` (numpy arrays or CUDA tensors of T frames): (note map after constrain_frequency, onset-peak bitmap
-        (T, 11) uint8, pitch-bend map (T, 88) int8 or None, status).  status 1: a NaN in the maps or an onset threshold
+        (T, 12) uint8, pitch-bend map (T, 88) int8 or None, status).  status 1: a NaN in the maps or an onset threshold
         <= 0 — decode the maps themselves (`note_creation.model_output_to_notes`).  `prm`: `note_creation._note_params`."""
         on_dev = _is_torch_cuda(output["note"])
         maps = {}
@@ -319,7 +319,7 @@ class Model:
             maps[k] = a
         T = int(maps["note"].shape[0])
         note = np.empty((T, N_FREQ_BINS_NOTES), np.float32)
-        bits = np.empty((T, 11), np.uint8)
+        bits = np.empty((T, 12), np.uint8)
         bend = np.empty((T, N_FREQ_BINS_NOTES), np.int8) if prm.include_pitch_bends else None
         status = C.c_int(0)
         ptr = (lambda a: a.data_ptr()) if on_dev else (lambda a: a.ctypes.data)

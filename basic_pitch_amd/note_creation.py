@@ -116,8 +116,8 @@ def decode_candidates(note: np.ndarray, cand_bits: np.ndarray, bend_map: Optiona
     note = np.require(note, np.float32, ["C"])
     cand_bits = np.require(cand_bits, np.uint8, ["C"])
     T = note.shape[0]
-    if note.ndim != 2 or note.shape[1] != N_FREQ_BINS_NOTES or cand_bits.shape != (T, 11):
-        raise ValueError("expected note (T, 88) float32 and cand_bits (T, 11) uint8")
+    if note.ndim != 2 or note.shape[1] != N_FREQ_BINS_NOTES or cand_bits.shape != (T, 12):
+        raise ValueError("expected note (T, 88) float32 and cand_bits (T, 12) uint8")
     if bend_map is not None:
         bend_map = np.require(bend_map, np.int8, ["C"])
         if bend_map.shape != (T, N_FREQ_BINS_NOTES):

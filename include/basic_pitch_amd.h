@@ -352,17 +352,20 @@ int bp_notes_decode(float* note, float* onset, const float* contour, int64_t n_f
 /* ---- Note decoding with the dense half on the device (round 5; SURVEY.md 8f rank 1: onset inference, peak picking and
  * thresholding note_creation.py:289-311, 394-402; the pitch bends of get_pitch_bends 182-219 for every (frame, bin)).
  * What the sequential note tracker needs of a track's posteriorgrams is the note map, WHERE the onset peaks are and the
- * pitch bend per (frame, note bin): 7.1 MB per 3-minute track instead of 27.6 MB across PCIe, and the three dense scans
+ * pitch bend per (frame, note bin): 7.0 MB per 3-minute track instead of 27.6 MB across PCIe, and the three dense scans
  * leave the host cores.  Same events as bp_notes_decode, bit for bit (tests/test_gpu_parity.py).
  *
  *   note_out  [n_frames][88] float32  the note map, frequency-constrained like constrain_frequency (314-343)
- *   cand_bits [n_frames][11] bytes    bit (f & 7) of byte f >> 3 in row t: (t, f) is an onset peak >= onset_threshold
+ *   cand_bits [n_frames][12] bytes    bit (f & 7) of byte f >> 3 in row t: (t, f) is an onset peak >= onset_threshold
+ *                                     (BP_NOTE_CAND_ROW_BYTES: 88 bits and a zero byte — rows of three 32-bit words)
  *   bend_map  [n_frames][88] int8     pitch bend of note bin f at frame t in 1/3 semitones; may be NULL without pitch bends
  *   *status   0: decode with bp_notes_decode_candidates;  1: the maps hold a NaN or onset_threshold <= 0 (numpy's
  *             propagation rules / every non-peak qualifies): decode the maps themselves with bp_notes_decode.
  * bp_note_candidates takes the three maps from host or device memory (mem_kind) and leaves them untouched;
  * bp_infer_pcm_raw_candidates is bp_infer_pcm_raw (inference.py:239 onwards) whose posteriorgrams stay on the device.
- * All outputs are host buffers (page-locked ones from bp_host_alloc make the copies asynchronous). */
+ * All outputs are host buffers; into page-locked ones (bp_host_alloc) a kernel writes them across PCIe itself, so that the
+ * copy engine — which serialises the copies of all handles, in both directions — is left to the inbound samples. */
+#define BP_NOTE_CAND_ROW_BYTES 12
 int bp_note_candidates(bp_handle h, const float* note, const float* onset, const float* contour, int64_t n_frames,
                        const bp_note_params* params, int mem_kind, float* note_out, uint8_t* cand_bits, int8_t* bend_map,
                        int* status);

@@ -236,8 +236,8 @@ def drop_overlapping_pitch_bends(events):
 
 def note_candidates(output, onset_thresh, infer_onsets=True, min_freq=None, max_freq=None, include_pitch_bends=True):
     """What the device extracts for the host's note tracker (csrc/note_device.hip, bp_note_candidates), restated with the
-    functions above: (note map after constrain_frequency, bitmap [T][11] uint8 of the onset peaks that reach the
-    threshold — bit f & 7 of byte f >> 3 —, pitch-bend map [T][88] int8 or None).  note_creation.py:289-311, 314-343,
+    functions above: (note map after constrain_frequency, bitmap [T][12] uint8 of the onset peaks that reach the
+    threshold — bit f & 7 of byte f >> 3, the twelfth byte zero —, pitch-bend map [T][88] int8 or None).  note_creation.py:289-311, 314-343,
     394-402, 182-219."""
     frames = np.array(output["note"], dtype=np.float32, copy=True)
     onsets = np.array(output["onset"], dtype=np.float32, copy=True)
@@ -250,8 +250,8 @@ def note_candidates(output, onset_thresh, infer_onsets=True, min_freq=None, max_
     peak_thresh_mat[peaks] = on[peaks]
     cand = peak_thresh_mat >= onset_thresh
     cand[-1:] = False  # a note cannot start in the last frame (note_creation.py:405-406); the device never marks it
-    bits = np.packbits(np.concatenate([cand, np.zeros((T, 0), bool)], axis=1), axis=1, bitorder="little")
-    assert bits.shape == (T, 11)
+    bits = np.packbits(np.concatenate([cand, np.zeros((T, 8), bool)], axis=1), axis=1, bitorder="little")
+    assert bits.shape == (T, 12)
     bend = None
     if include_pitch_bends:
         bend = np.zeros((T, 88), np.int8)

@@ -444,7 +444,7 @@ def test_candidate_decoder_refuses_what_needs_the_maps():
     lib = _native.load_library()
     prm = NC._note_params(0.0, 0.3, 11, True, None, None, True, NC.ENERGY_TOLERANCE, False)
     note = np.zeros((10, 88), np.float32)
-    bits = np.zeros((10, 11), np.uint8)
+    bits = np.zeros((10, 12), np.uint8)
     n_ev, n_b = C.c_int64(), C.c_int64()
     rc = lib.bp_notes_decode_candidates(note.ctypes.data, bits.ctypes.data, None, 10, C.byref(prm), None, 0, None, 0,
                                         C.byref(n_ev), C.byref(n_b))
