@@ -230,16 +230,21 @@ __global__ __launch_bounds__(256) void resample_tiled_kernel(const float* __rest
 // conversion for each.  Samples outside the signal and the steps that pad the tap count to a multiple of W contribute
 // x * 0 or 0 * tap = 0, which leaves a float64 accumulator as it is: the result is the kernels' above, bit for bit.
 // 3-minute track (1.54 G multiply-adds = 39 us at the fp64 vector rate): 303 us (tiled) -> 83 us with OUT = 4 -> 70 us with OUT = 8.
-constexpr int kHalfOut = 8, kHalfW = 2 * kHalfOut;
-// row length of a sub-sequence in LDS: 256 threads + 1024 / W tap blocks + 1, and = 2 (mod 32) so that the 32 lanes of a
-// fill pass (16 rows x 2 columns) hit 32 different banks
-constexpr int kHalfSub = 322;  // >= 256 + 64 + 1, = 2 (mod 32)
-static_assert(kHalfW == 16 && kHalfSub % 32 == 2 && kHalfSub >= 256 + kResTileTaps / kHalfW + 1, "fill pattern");
+// Round 5: OUT = 16 and the taps through the scalar cache (the tap index is the same for every lane: an s_load, not a
+// broadcast LDS read) — per 16 multiply-adds one ds_read_b32 and one conversion.
+#ifndef BP_HALF_OUT
+#define BP_HALF_OUT 16
+#endif
+constexpr int kHalfOut = BP_HALF_OUT, kHalfW = 2 * kHalfOut;
+// row length of a sub-sequence in LDS: 256 threads + 1024 / W tap blocks + 1, and = 1 (mod 32) (W = 32) or 2 (mod 32)
+// (W = 16), so that the 32 lanes of a fill pass hit 32 different banks
+constexpr int kHalfSub = kHalfW == 32 ? 289 : 322;
+static_assert((kHalfW == 16 && kHalfSub % 32 == 2) || (kHalfW == 32 && kHalfSub % 32 == 1), "fill pattern");
+static_assert(kHalfSub >= 256 + kResTileTaps / kHalfW + 1, "a block's slice fits");
 __global__ __launch_bounds__(256) void resample_half_kernel(const float* __restrict__ x, int64_t n_in,
                                                             const double* __restrict__ taps, ResamplePlan pl,
                                                             float* __restrict__ y, int64_t n_out) {
   __shared__ float sub[kHalfW][kHalfSub];
-  __shared__ double hs[kResTileTaps + kHalfW];
   const int M = (int)pl.n_taps, nb = (M + kHalfW - 1) / kHalfW, t = threadIdx.x;
   const int64_t K0 = (int64_t)blockIdx.x * (256 * kHalfOut);
   const int64_t X0 = 2 * K0 + pl.centre - (M - 1);  // x index behind sub[0][0]
@@ -248,8 +253,8 @@ __global__ __launch_bounds__(256) void resample_half_kernel(const float* __restr
     const int64_t X = X0 + e;
     sub[e % kHalfW][e / kHalfW] = (X >= 0 && X < n_in) ? x[X] : 0.0f;
   }
-  for (int s = t; s < kHalfW * nb; s += 256) hs[s] = s < M ? taps[M - 1 - s] : 0.0;
   __syncthreads();
+  const double* __restrict__ hr = taps + pl.rev_off;  // taps[M - 1 - s] at s, zeros from M to the end of its block of 32
   double r[kHalfW], acc[kHalfOut];
 #pragma unroll
   for (int i = 0; i < kHalfOut; ++i) acc[i] = 0.0;
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256) void resample_half_kernel(const float* __restr
   for (int b = 0; b < nb; ++b) {
 #pragma unroll
     for (int q = 0; q < kHalfW; ++q) {
-      const double h = hs[kHalfW * b + q];
+      const double h = hr[kHalfW * b + q];  // wave-uniform address: scalar loads, a block of taps at a time
 #pragma unroll
       for (int i = 0; i < kHalfOut; ++i) acc[i] = __builtin_fma(r[(q + 2 * i) % kHalfW], h, acc[i]);
       r[q] = (double)sub[q][t + b + 1];
@@ -334,7 +339,7 @@ void launch_resample(const float* x, int64_t n_in, const double* taps, const Res
   const dim3 per_output((unsigned)((n_out + 255) / 256));
   if (pl.direct)
     hipLaunchKernelGGL(resample_direct_kernel, per_output, dim3(256), 0, stream, x, n_in, taps, pl, y, n_out);
-  else if (mode == 0 && pl.up == 1 && pl.down == 2 && pl.n_taps <= kResTileTaps && (reinterpret_cast<uintptr_t>(y) & 15) == 0)
+  else if (mode == 0 && pl.up == 1 && pl.down == 2 && pl.rev_off > 0 && pl.n_taps <= kResTileTaps && (reinterpret_cast<uintptr_t>(y) & 15) == 0)
     hipLaunchKernelGGL(resample_half_kernel, dim3((unsigned)((n_out + 256 * kHalfOut - 1) / (256 * kHalfOut))), dim3(256), 0, stream, x, n_in, taps,
                        pl, y, n_out);
   else if (mode != 1 && span <= kResTileX && pl.n_taps <= kResTileTaps)

@@ -1638,7 +1638,16 @@ static int ingest(bp_handle h, const void* pcm, int format, int64_t n_frames, in
   }
   if (h->taps_rate != sample_rate) {
     std::vector<double> taps;
-    const ResamplePlan pl = make_resample_plan(sample_rate, h->rate, taps);
+    ResamplePlan pl = make_resample_plan(sample_rate, h->rate, taps);
+    pl.rev_off = 0;
+    if (!pl.direct && pl.up == 1 && pl.down == 2) {
+      // the 2 : 1 kernel walks the taps backwards, a block of 32 per scalar load: a reversed copy behind the table, padded
+      // with zeros to whole blocks (a zero tap adds x * 0 = 0 to a float64 sum)
+      const size_t M = taps.size(), base = (M + 31) / 32 * 32, padded = (M + 31) / 32 * 32;
+      taps.resize(base + padded, 0.0);
+      for (size_t i = 0; i < M; ++i) taps[base + i] = taps[M - 1 - i];
+      pl.rev_off = (int64_t)base;
+    }
     if (h->taps_dev) BP_HIP(hipFree(h->taps_dev));
     h->taps_dev = nullptr;
     h->taps_rate = 0;

@@ -238,6 +238,8 @@ struct ResamplePlan {
   double beta;      // Kaiser beta
   double inv_half;  // 1 / (centre + .5): window argument per tap
   double gain;      // up
+  int64_t rev_off;  // 2 : 1 plans: offset (in doubles) of the taps once more in reverse order, zero-padded to whole
+                    // blocks of 32 (resample_half_kernel reads them through the scalar cache); 0: absent
 };
 constexpr int64_t kMaxTableTaps = (int64_t)1 << 22;  // 32 MB of float64 taps; beyond it the direct kernel
 constexpr int kWindowTable = 1 << 16;

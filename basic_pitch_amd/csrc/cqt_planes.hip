@@ -1333,6 +1333,9 @@ bool launch_filterbank_planes(const uint16_t* pl, const float* audio, int64_t au
   float2* mm = reinterpret_cast<float2*>(scratch);
   const unsigned per_window = (unsigned)(g.n_levels * kPlTilesPerLevel);
   const unsigned magic = (unsigned)((0x100000000ull + per_window - 1) / per_window);
+  // one window per workgroup pays from half a window per CU on.  (A file job's 110-window tracks on three lanes, round 5:
+  // with the fused form from 32 windows on, 1,258 files/s against 1,460 — a third of the CUs for 60 us is worse than all
+  // of them for 29 + 15 us even when other lanes' kernels could fill the rest.)
   const bool fused = zp != nullptr && 2 * n_windows >= n_cu;
   constexpr int kThreads = 1024, kApf = 3;
   int grid;

@@ -135,43 +135,105 @@ __global__ __launch_bounds__(256) void nd_candidates_kernel(const float* __restr
   if (lane < 3) bits[t * 3 + lane] = lane == 0 ? (uint32_t)b0 : (lane == 1 ? (uint32_t)(b0 >> 32) : (uint32_t)b1);
 }
 
-// One wave per frame: the contour row goes to LDS as float64 once (264 conversions instead of 88 x 51), lanes take bins
-// lane and lane + 64; the products and the running maximum in float64 like the host's loop.
-__global__ __launch_bounds__(256) void nd_bend_kernel(const float* __restrict__ contour, int64_t T, const int4* __restrict__ tab,
-                                                      const double* __restrict__ gauss, int8_t* __restrict__ bend) {
-  __shared__ double s_row[4][kNdFC];
-  __shared__ double s_g[51];
-  __shared__ int4 s_tab[kNdF];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x < 51) s_g[threadIdx.x] = gauss[threadIdx.x];
-  if (threadIdx.x < kNdF) s_tab[threadIdx.x] = tab[threadIdx.x];
-  for (int64_t t0 = (int64_t)blockIdx.x * 4; t0 < T; t0 += (int64_t)gridDim.x * 4) {
-    const int64_t t = t0 + wave;
-    __syncthreads();  // the tables (first pass) / the previous frame's row is read
-    if (t < T)
-      for (int i = lane; i < kNdFC; i += 64) s_row[wave][i] = (double)contour[t * kNdFC + i];
-    __syncthreads();
-    if (t >= T) continue;
-    const double* row = s_row[wave];
-    int8_t out[2] = {0, 0};
+// Pitch bends.  A workgroup takes kNdBendFrames consecutive frames: their contour rows go to LDS as float64 once (264
+// conversions per frame instead of 88 x 51), each between two margins of -inf, so that every bin's window is the full 51
+// taps — a tap outside the row yields -inf x gauss = -inf, which never exceeds the running maximum and never comes
+// first (the running index starts at the first tap inside the row, where the host's loop starts).  An item is (frame,
+// bin): 16 x 88 = 1408 items over 256 threads, consecutive lanes consecutive bins (3 doubles apart: conflict-free
+// ds_read_b64), the Gaussian in registers, four vector operations per tap (multiply, compare, maximum, select) where the
+// wave-per-frame form with table-driven loop bounds issued twelve at 69 % lane use: 72 -> ~20 us per 3-minute track.
+// The products and comparisons are the host loop's float64 operations in the host loop's order: the same argmax.  A NaN
+// anywhere in the block's rows (np.argmax: the first NaN wins) sends the block through the comparison that handles it.
+constexpr int kNdBendFrames = 16, kNdBendPad = 26, kNdBendPitch = kNdFC + 2 * kNdBendPad;  // rows 16-byte aligned
+static_assert(kNdBendPad >= 25 && (kNdBendPad * 8) % 16 == 0 && (kNdBendPitch * 8) % 16 == 0, "aligned rows");
+
+__device__ __forceinline__ int nd_bend_argmax(const double* __restrict__ win, const double (&g)[26], int first) {
+  int best = first;
+  double bestv = -__longlong_as_double(0x7ff0000000000000ll);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int b = lane + 64 * h;
-      if (b >= kNdF) break;
-      const int4 w = s_tab[b];  // f0, n, g0, shift
-      int best = 0;
-      double bestv = row[w.x] * s_g[w.z];
-      for (int j = 1; j < w.y; ++j) {
-        const double v = row[w.x + j] * s_g[w.z + j];
-        if (v > bestv || (v != v && bestv == bestv)) {  // np.argmax: first maximum, NaN wins
-          bestv = v;
-          best = j;
-        }
-      }
-      out[h] = (int8_t)(best - w.w);
+  for (int j = 0; j < 51; ++j) {
+    const double v = win[j] * g[j <= 25 ? j : 50 - j];
+    best = v > bestv ? j : best;
+    bestv = __builtin_fmax(bestv, v);
+  }
+  return best;
+}
+
+// np.argmax over the taps [first, 50] with a NaN somewhere in the block: the first maximum, the first NaN wins (the margins
+// behind the row are -inf and never win).  A rolled loop with the Gaussian from LDS: this path is for broken inputs.
+__device__ __forceinline__ int nd_bend_argmax_nan(const double* __restrict__ win, const double* __restrict__ g, int first) {
+  int best = first;
+  double bestv = win[first] * g[first];
+#pragma unroll 1
+  for (int j = first + 1; j < 51; ++j) {
+    const double v = win[j] * g[j];
+    const bool take = (v > bestv) | ((v != v) & (bestv == bestv));
+    bestv = take ? v : bestv;
+    best = take ? j : best;
+  }
+  return best;
+}
+
+__global__ __launch_bounds__(256, 3) void nd_bend_kernel(const float* __restrict__ contour, int64_t T, const int4* __restrict__ tab,
+                                                      const double* __restrict__ gauss, int8_t* __restrict__ bend) {
+  __shared__ __attribute__((aligned(16))) double s_row[kNdBendFrames * kNdBendPitch];
+  __shared__ int s_start[kNdF], s_first[kNdF];
+  __shared__ double s_g[51];
+  __shared__ int s_nan;
+  const int tid = threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.x * kNdBendFrames;
+  const double ninf = -__longlong_as_double(0x7ff0000000000000ll);
+  if (tid == 0) s_nan = 0;
+  if (tid >= 128 && tid < 128 + 51) s_g[tid - 128] = gauss[tid - 128];
+  if (tid < kNdF) {
+    const int4 w = tab[tid];  // f0, n, g0, shift: tap j of the 51 reads row bin f0 - g0 + j; the first inside the row is g0
+    s_start[tid] = kNdBendPad + w.x - w.z;
+    s_first[tid] = w.z;
+  }
+  for (int i = tid; i < kNdBendFrames * 2 * kNdBendPad; i += 256) {
+    const int r = i / (2 * kNdBendPad), c = i - r * (2 * kNdBendPad);
+    s_row[r * kNdBendPitch + (c < kNdBendPad ? c : kNdFC + c)] = ninf;
+  }
+  // the Gaussian exp(-(j - 25)^2 / 50) is symmetric bit for bit (the host squares j - 25): 26 values, in vector registers
+  // (left to itself the compiler keeps the words in scalar registers it does not have)
+  double g[26];
+#pragma unroll
+  for (int j = 0; j < 26; ++j) {
+    g[j] = gauss[j];
+    asm volatile("" : "+v"(g[j]));
+  }
+  __syncthreads();
+  // the block's rows are contiguous in memory: 16 x 264 floats as float4s (264 = 4 x 66: no float4 straddles two rows)
+  int nan = 0;
+  const int64_t n_rows = T - t0 < kNdBendFrames ? T - t0 : kNdBendFrames;
+  const float4* src = reinterpret_cast<const float4*>(contour + t0 * kNdFC);
+  for (int e = tid; e < kNdBendFrames * (kNdFC / 4); e += 256) {
+    const int r = e / (kNdFC / 4), c4 = e - r * (kNdFC / 4);
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (r < n_rows) v = src[e];
+    nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+    double* d = &s_row[r * kNdBendPitch + kNdBendPad + 4 * c4];
+    *reinterpret_cast<double2*>(d) = double2{(double)v.x, (double)v.y};
+    *reinterpret_cast<double2*>(d + 2) = double2{(double)v.z, (double)v.w};
+  }
+  if (nan) s_nan = 1;
+  __syncthreads();
+  if (s_nan == 0) {  // block-uniform
+#pragma unroll 1
+    for (int item = tid; item < kNdBendFrames * kNdF; item += 256) {
+      const int r = item / kNdF, b = item - r * kNdF;
+      if (r >= n_rows) break;
+      const int best = nd_bend_argmax(&s_row[r * kNdBendPitch + s_start[b]], g, s_first[b]);
+      bend[t0 * kNdF + item] = (int8_t)(best - 25);  // = (best - g0) - shift, shift = 25 - g0
     }
-    bend[t * kNdF + lane] = out[0];
-    if (lane + 64 < kNdF) bend[t * kNdF + lane + 64] = out[1];
+  } else {
+#pragma unroll 1
+    for (int item = tid; item < kNdBendFrames * kNdF; item += 256) {
+      const int r = item / kNdF, b = item - r * kNdF;
+      if (r >= n_rows) break;
+      const int best = nd_bend_argmax_nan(&s_row[r * kNdBendPitch + s_start[b]], s_g, s_first[b]);
+      bend[t0 * kNdF + item] = (int8_t)(best - 25);
+    }
   }
 }
 
@@ -209,7 +271,7 @@ void launch_note_candidates(float* note, float* onset, const float* contour, int
   hipLaunchKernelGGL(nd_candidates_kernel, dim3(frames4), dim3(256), 0, s, note, onset, T, infer, onset_thresh, st,
                      reinterpret_cast<uint32_t*>(bits));
   if (bend)
-    hipLaunchKernelGGL(nd_bend_kernel, dim3(frames4 < 1024u ? frames4 : 1024u), dim3(256), 0, s, contour, T,
+    hipLaunchKernelGGL(nd_bend_kernel, dim3((unsigned)((T + kNdBendFrames - 1) / kNdBendFrames)), dim3(256), 0, s, contour, T,
                        static_cast<const int4*>(tab), gauss, bend);
 }
 
