@@ -122,6 +122,21 @@ __global__ __launch_bounds__(256) void contour_conv2_kernel(const float* __restr
       const int t = r - 2 + d;
       if (t < ta || t >= tb) continue;  // wave-uniform
       const float* __restrict__ wd = w2_ + (4 - d) * 40;
+#ifdef BP_D2_TWO_CHAINS
+      v2f side = {0.0f, 0.0f};  // second chain: a dependent v_pk_fma_f32 needs a wait state and the previous result
+#pragma unroll
+      for (int dw = 0; dw < 5; ++dw) {
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) {
+          const v2f wv2 = {wd[dw * 8 + 2 * c2], wd[dw * 8 + 2 * c2 + 1]};
+          if (c2 & 1)
+            side = __builtin_elementwise_fma(wv2, x[dw][c2], side);
+          else
+            acc[d] = __builtin_elementwise_fma(wv2, x[dw][c2], acc[d]);
+        }
+      }
+      acc[d] += side;
+#else
 #pragma unroll
       for (int dw = 0; dw < 5; ++dw) {
 #pragma unroll
@@ -130,6 +145,7 @@ __global__ __launch_bounds__(256) void contour_conv2_kernel(const float* __restr
           acc[d] = __builtin_elementwise_fma(wv2, x[dw][c2], acc[d]);
         }
       }
+#endif
     }
     const int t_out = r - 2;
     if (t_out >= ta && t_out < tb && wvalid) dst[(int64_t)t_out * kFreqC] = sigmoidf_fast((acc[0].x + acc[0].y) + p.bias);

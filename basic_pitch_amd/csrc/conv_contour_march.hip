@@ -98,6 +98,10 @@ __global__ __launch_bounds__(64 * kCmWaves, 2) void contour_conv1_march_kernel(C
   // workgroups of the same XCD, so a row is fetched from HBM by one L2 instead of by up to eight
   // (inside each half of the grid: a CU hosts workgroups p and p + gridDim.x / 2, and when the tasks per wave are not a whole
   // number the first half of the LOGICAL blocks carries the extra task — the pair of a CU must stay (first, second half))
+  // (Round 5 tried equal shares of the frames per WAVE instead — wave g of 2048 marching the g-th 2048th of all frames,
+  // 154 rows each instead of 4 x 45 for half the waves and 3 x 45 for the others: 0.228 ms against 0.2155.  The 3.5 tasks
+  // per wave are no imbalance — every SIMD hosts one wave of each kind and the matrix pipe is what they share — while
+  // consecutive tasks, the strips of one (window, chunk), read the same zp rows at the same time from the same CU.)
   const int half_n = (int)gridDim.x / 2, pq = (int)blockIdx.x % (half_n > 0 ? half_n : 1);
   const int lblock = (gridDim.x % 16 == 0) ? ((int)blockIdx.x / half_n) * half_n + (pq % 8) * (half_n / 8) + pq / 8 : (int)blockIdx.x;
 #pragma unroll 1

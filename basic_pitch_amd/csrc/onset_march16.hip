@@ -38,10 +38,6 @@ namespace bp {
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
 constexpr int kO16Waves = 4;  // independent waves per workgroup
-#ifndef BP_ONSET16_CHUNKS
-#define BP_ONSET16_CHUNKS 8
-#endif
-constexpr int kO16Chunks = BP_ONSET16_CHUNKS;  // time chunks per window
 constexpr int kO16Strips = 3;                  // 32-pixel strips of a row, 30 inner pixels each
 constexpr int kO16Ring = 6;                    // image rows a wave keeps: r - 2 .. r + 2 in use, r + 3 being written
 constexpr int kO16Slots = 98;                  // stack bins a strip's 32 pixels read: 3 * 31 + 5
@@ -61,8 +57,7 @@ struct Onset16Params {
   const uint32_t* zp;   // [n][kZRowsP][kZRow] packed (hi | lo << 16) words, zero padded (bp_common.h)
   const float* note;    // [n][172][88]
   float* out;           // [n][172][88]
-  int n_tasks;          // n_windows * chunks * kO16Strips
-  int chunks;           // time chunks per window: kO16Chunks at full batches, more when few windows must fill the chip
+  int n_ws;             // n_windows * kO16Strips (window, strip) pairs of 172 frames each
 };
 
 template <bool WLO>
@@ -122,19 +117,23 @@ __global__ __launch_bounds__(64 * kO16Waves, 2) void onset_march16_kernel(Onset1
   const int at56 = 3 * n + 2;
 
   const int total_waves = gridDim.x * kO16Waves;
-  // XCD-aware task order: workgroups go to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own L2; consecutive
-  // tasks — the strips and chunks of ONE window, which read overlapping parts of the same zp rows — are given to
+  // XCD-aware order: workgroups go to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own L2; consecutive
+  // pieces of work — the strips of ONE window, which read overlapping parts of the same zp rows — are given to
   // workgroups of the same XCD, so a row is fetched from HBM by one L2 instead of by up to eight
-  // (inside each half of the grid: a CU hosts workgroups p and p + gridDim.x / 2, and when the tasks per wave are not a whole
-  // number the first half of the LOGICAL blocks carries the extra task — the pair of a CU must stay (first, second half))
   const int half_n = (int)gridDim.x / 2, pq = (int)blockIdx.x % (half_n > 0 ? half_n : 1);
   const int lblock = (gridDim.x % 16 == 0) ? ((int)blockIdx.x / half_n) * half_n + (pq % 8) * (half_n / 8) + pq / 8 : (int)blockIdx.x;
+  // Work = the frames of all (window, strip) pairs laid end to end; wave g of G takes the g-th G-th of them: at most two
+  // marches (round 4: three tasks of an eighth of a window-strip each — three prologues and 3 x 2 warm-up rows per wave
+  // where 64.5 contiguous frames need 1.4 of each).
+  const int gw = lblock * kO16Waves + wave;
+  const int64_t total = (int64_t)p.n_ws * kFrames;
+  int64_t F0 = total * gw / total_waves;
+  const int64_t F1 = total * (gw + 1) / total_waves;
 #pragma unroll 1
-  for (int task = lblock * kO16Waves + wave; task < p.n_tasks; task += total_waves) {  // wave-uniform; no barriers
-    const int b = task / (p.chunks * kO16Strips);
-    const int rem = task - b * (p.chunks * kO16Strips);
-    const int ci = rem / kO16Strips, strip = rem - ci * kO16Strips;
-    const int T0 = (ci * kFrames) / p.chunks, T1 = ((ci + 1) * kFrames) / p.chunks;
+  for (int ws = (int)(F0 / kFrames); F0 < F1; ++ws, F0 = (int64_t)ws * kFrames) {  // wave-uniform; no barriers
+    const int b = ws / kO16Strips, strip = ws - b * kO16Strips;
+    const int T0 = (int)(F0 - (int64_t)ws * kFrames);
+    const int T1 = F1 - (int64_t)ws * kFrames < kFrames ? (int)(F1 - (int64_t)ws * kFrames) : kFrames;
 
     // this lane's two pixels of the strip (tile nt: strip pixel 16 nt + n), and the stack bin of image slot 0
     int w[2], wc[2];
@@ -358,12 +357,13 @@ __global__ __launch_bounds__(64 * kO16Waves, 2) void onset_march16_kernel(Onset1
 
 void launch_onset_march16(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, float* onset,
                           int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream) {
-  int chunks = kO16Chunks;  // small batches: shorter chunks until every resident wave has a task
-  while (chunks < 32 && (int64_t)n_windows * chunks * kO16Strips < (int64_t)2 * n_cu * kO16Waves) chunks *= 2;
-  Onset16Params p{static_cast<const uint4*>(wfrag), wf32, zp, note, onset, n_windows * chunks * kO16Strips, chunks};
-  if (p.n_tasks <= 0) return;
-  int grid = (p.n_tasks + kO16Waves - 1) / kO16Waves;
-  if (grid > 2 * n_cu) grid = 2 * n_cu;  // two resident workgroups per CU (LDS), persistent: the waves walk the tasks
+  // two resident workgroups per CU (LDS), persistent; small batches: fewer waves, at least kMinFrames frames each
+  Onset16Params p{static_cast<const uint4*>(wfrag), wf32, zp, note, onset, n_windows * kO16Strips};
+  if (p.n_ws <= 0) return;
+  constexpr int kMinFrames = 6;
+  const int64_t waves = ((int64_t)p.n_ws * kFrames + kMinFrames - 1) / kMinFrames;
+  int grid = (int)((waves + kO16Waves - 1) / kO16Waves);
+  if (grid > 2 * n_cu) grid = 2 * n_cu;
   if (weights_have_lo)
     hipLaunchKernelGGL(onset_march16_kernel<true>, dim3(grid), dim3(64 * kO16Waves), 0, stream, p);
   else
