@@ -122,30 +122,18 @@ __global__ __launch_bounds__(256) void contour_conv2_kernel(const float* __restr
       const int t = r - 2 + d;
       if (t < ta || t >= tb) continue;  // wave-uniform
       const float* __restrict__ wd = w2_ + (4 - d) * 40;
-#ifdef BP_D2_TWO_CHAINS
-      v2f side = {0.0f, 0.0f};  // second chain: a dependent v_pk_fma_f32 needs a wait state and the previous result
 #pragma unroll
       for (int dw = 0; dw < 5; ++dw) {
 #pragma unroll
         for (int c2 = 0; c2 < 4; ++c2) {
-          const v2f wv2 = {wd[dw * 8 + 2 * c2], wd[dw * 8 + 2 * c2 + 1]};
-          if (c2 & 1)
-            side = __builtin_elementwise_fma(wv2, x[dw][c2], side);
-          else
-            acc[d] = __builtin_elementwise_fma(wv2, x[dw][c2], acc[d]);
-        }
-      }
-      acc[d] += side;
-#else
-#pragma unroll
-      for (int dw = 0; dw < 5; ++dw) {
-#pragma unroll
-        for (int c2 = 0; c2 < 4; ++c2) {
+          // one chain of 20 dependent v_pk_fma_f32 (each behind a wait state): two interleaved chains per open row
+          // measured the same (round 5: 0.112 vs 0.112 ms) — other waves fill the slots; 200 plain v_fmac_f32 instead
+          // of the 100 packed ones: 0.132 ms; two rows of loads in flight instead of one: 0.118; six resident waves per
+          // SIMD instead of five (5 slabs of 35 frames): 0.103 - 0.107 against 0.106 - 0.109, seven or eight: 0.123
           const v2f wv2 = {wd[dw * 8 + 2 * c2], wd[dw * 8 + 2 * c2 + 1]};
           acc[d] = __builtin_elementwise_fma(wv2, x[dw][c2], acc[d]);
         }
       }
-#endif
     }
     const int t_out = r - 2;
     if (t_out >= ta && t_out < tb && wvalid) dst[(int64_t)t_out * kFreqC] = sigmoidf_fast((acc[0].x + acc[0].y) + p.bias);

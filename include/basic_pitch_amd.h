@@ -82,8 +82,11 @@ typedef enum bp_mem_kind {
                                  * Not available with BP_FLAG_F32_MFMA. */
 #define BP_FLAG_TIME_DOMINANT 16u /* record HIP events only around the dominant kernel (stage CONTOUR_CONV1: the folded
                                    * contour conv1, or CONTOUR for BP_CONTOUR_PATH=fused); bp_get_stage_ms then reports that
-                                   * stage alone.  Two event records per chunk instead of sixteen: the full set costs
-                                   * ~25 us (2.6 %) of a 256-window step.  Ignored with BP_FLAG_STAGE_TIMING / F32_MFMA. */
+                                   * stage alone.  Two event records on every FOURTH chunk (the first since creation or
+                                   * since the last bp_get_stage_ms included) instead of sixteen on every chunk: the full set costs ~25 us (2.6 %) of a
+                                   * 256-window step, and even one pair per chunk 0.04 ms of 0.75 (an event record between
+                                   * two kernels keeps the second from starting under the first's tail).
+                                   * Ignored with BP_FLAG_STAGE_TIMING / F32_MFMA. */
 
 #define BP_FLAG_F16_CORRECTIONS 32u /* Since round 3 this is the DEFAULT arithmetic and the flag is accepted as a no-op (it
                                     * wins over BP_FLAG_FP8_CORRECTIONS when both are set): every matrix product of the path

@@ -1108,6 +1108,18 @@ def test_device_note_candidates_give_the_host_decoders_events(tmp_path):
     assert s1 == s2 == 0 and np.array_equal(n1, n2) and np.array_equal(b1, b2) and np.array_equal(e1, e2)
     zero = {"note": np.zeros((50, 88), np.float32), "onset": np.zeros((50, 88), np.float32), "contour": np.zeros((50, 264), np.float32)}
     assert check(zero, dict(onset_thresh=0.5, frame_thresh=0.3)) == 0
+    # a contour map with NaN / +-inf entries (np.argmax: the first NaN wins, then the first maximum): the bend kernel's
+    # block-uniform slow path, at a frame count that is no multiple of its 16-frame blocks
+    odd = {"note": rng.random((203, 88), dtype=np.float32) ** 3, "onset": rng.random((203, 88), dtype=np.float32) ** 4,
+           "contour": rng.random((203, 264), dtype=np.float32)}
+    odd["contour"][5, 100] = np.nan
+    odd["contour"][5, 130] = np.nan
+    odd["contour"][40, 3] = np.nan
+    odd["contour"][41, 260] = np.inf
+    odd["contour"][60, :] = -np.inf
+    odd["contour"][61, 20:90] = np.inf
+    odd["contour"][202, 263] = np.nan
+    assert check(odd, dict(onset_thresh=0.5, frame_thresh=0.3, min_note_len=3)) == 0
     bad = {k: v.copy() for k, v in zero.items()}
     bad["onset"][7, 3] = np.nan
     assert check(bad, dict(onset_thresh=0.5, frame_thresh=0.3)) == 1
