@@ -563,6 +563,7 @@ def main() -> None:
     # sustained), so the W warm-up + K timed steps below start right behind two seconds of the same work, on a GPU in the
     # state a batch job keeps it in.
     extras = {}
+    sus_model = None
     if not args.exact_f32 and args.sustained_s > 0:
         sus_model = Model(device=local_rank, max_windows=B, bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k,
                           fp8_corrections=args.fp8_corrections)
@@ -591,7 +592,6 @@ def main() -> None:
             dist.barrier()
         t_sus = time.perf_counter() - t0
         t_sus = reduce_over_ranks(t_sus, dist.ReduceOp.MAX)
-        sus_model.close()
         extras["sustained"] = {"windows_per_s": B * n_sus * world / t_sus, "steps": n_sus, "seconds": t_sus,
                                "ms_per_step": t_sus / n_sus * 1e3,
                                "note": "same step, back to back, no event records, run directly before the W warm-up + K "
@@ -614,6 +614,8 @@ def main() -> None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     stage = model.stage_ms()  # mean per-launch ms over the timed steps (HIP events on the kernels' stream)
+    if sus_model is not None:
+        sus_model.close()  # after the timed steps: freeing a gigabyte of device buffers idles the GPU for milliseconds
     if not args.exact_f32 and rank == 0:
         # untimed second pass with events around every stage (same inputs, same kernels); the dominant kernel's entry
         # stays the one measured inside the timed region
@@ -666,6 +668,32 @@ def main() -> None:
         extras["fp8_corrections_note"] = ("BP_FLAG_FP8_CORRECTIONS, opt-in: contour / onset conv1 corrections on block-scaled fp8 "
                                           "MFMA — narrower than the config's fp32, reported beside `value`")
         fx_model.close()
+
+    if (not args.exact_f32 and not args.no_config_extras and rank == 0 and world == 1
+            and not (args.bf16_weights or args.ext_cqt_44k or args.fp8_corrections)):
+        # beside the headline: two handles on two streams taking alternate batches — what a service with two lanes gets
+        # (the kernels of one batch run under the launch gaps and tails of the other's; per-kernel times are no longer
+        # those of a kernel alone on the chip, which is why `value` and `roofline` stay on one stream)
+        lanes = [Model(device=local_rank, max_windows=B) for _ in range(2)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        outs = [out, {k: torch.empty_like(v) for k, v in out.items()}]
+
+        def lane_steps(n):
+            for i in range(n):
+                with torch.cuda.stream(streams[i & 1]):
+                    lanes[i & 1]._predict_device(audio, out=outs[i & 1], sync=False)
+
+        lane_steps(6)
+        torch.cuda.synchronize()
+        n_two = max(2 * args.steps, 200)
+        t0 = time.perf_counter()
+        lane_steps(n_two)
+        torch.cuda.synchronize()
+        t_two = time.perf_counter() - t0
+        extras["two_lanes"] = {"windows_per_s": B * n_two / t_two, "ms_per_step": t_two / n_two * 1e3, "steps": n_two,
+                               "note": "two handles, two streams, alternate batches of the same 256 windows; beside `value`"}
+        for m2 in lanes:
+            m2.close()
 
     if rank == 0:
         total_windows = B * args.steps * world
