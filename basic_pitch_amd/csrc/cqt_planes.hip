@@ -219,8 +219,19 @@ __global__ __launch_bounds__(256) void pl_unsplit_kernel(const uint16_t* __restr
 // 24 rows serve all 9 steps.  Re-loading the fragment every step would pull the tile through the texture path 9 times
 // (18 KB per tile, and a chain of dependent latencies); instead the 24 rows are fetched ONCE — lane (m, kg) row m, lanes
 // m >= 8 also row m + 8 —, parked in a wave-private LDS image, and the fragments are ds_read_b128 from there.
-constexpr int kPlRowU = 5;                      // 16-byte units per row in LDS (4 + 1 of skew)
-constexpr int kPlRowsU = 2 * 24 * kPlRowU;      // hi rows, then lo rows: 240 units = 3840 bytes per wave
+// LDS images whose 16-byte units are read as B fragments — the row images here, the resident planes of the per-window
+// kernel — are XOR-swizzled: unit u of an image (4 units = one row of 32 elements) sits at u ^ 2 when bit 4 of u is set,
+// i.e. the unit pairs (0, 2) and (1, 3) of rows 4 .. 7 (mod 8) are swapped.  ds_read_b128 is served in four groups of 16
+// lanes ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md): at the natural 64-byte row pitch rows rho and rho + 4 (+ 12) of
+// a group share banks — 8 LDS cycles per read instead of 4, with a padded pitch of 5 units (rounds 3 - 4: "4 + 1 of
+// skew") just the same, with 6 none but no LDS left for it; enumerated (round 5) for every k-step, tile offset and 16-byte
+// aligned base: 8 -> 4.  The decimator tiles' 18 signal-fragment reads were what the LDS pipe of a CU spent its time on
+// (a round of 16 tiles: 2,880 LDS cycles against 1,400 matrix-pipe cycles per SIMD).  A lane's unit at k-step s is row
+// m + s, unit kg: it reads unit kg ^ 2 p(s), p(s) = ((m + s) >> 2) & 1 — one select per k-step between two lane bases.
+constexpr int kPlRowU = 4;                      // 16-byte units per row in LDS
+constexpr int kPlRowsU = 2 * 24 * kPlRowU;      // hi rows, then lo rows: 192 units = 3072 bytes per wave
+__device__ __forceinline__ int pl_swz_units(int u) { return u ^ ((u >> 3) & 2); }     // 16-byte units
+__device__ __forceinline__ int pl_swz_elems(int e) { return e ^ ((e >> 3) & 16); }    // f16 elements (8 per unit)
 
 __device__ __forceinline__ uint4 pl_zero_outside(uint4 v, int idx, int L_in) {
   // keep elements whose sample index idx + e - kPlPad lies in [0, L_in): the reference zero-pads the decimator's input
@@ -328,7 +339,9 @@ __device__ __forceinline__ void pl_store16(void* p, uint4 v) {
 
 // TAIL = false: the level's reflect padding is written by somebody else (pl_reflect_pad_from_lds); the level's last,
 // partial group of four is stored here either way.
-template <bool TAIL = true>
+// SWZ: the LDS image is a swizzled resident region (per-window kernel): `mir_hi` = the REGION's element 0 (sample 0 sits
+// kPlPad elements behind it), elements at pl_swz_elems(region index).
+template <bool TAIL = true, bool SWZ = false>
 __device__ __forceinline__ void pl_tile_store(const f32x4& hh, const f32x4& xx, uint16_t* __restrict__ out_hi, int64_t stride,
                                               int L_out, int tile, int lane, uint16_t* mir_hi, int mir_stride) {
   const int m = lane & 15, kg = lane >> 4;
@@ -346,7 +359,7 @@ __device__ __forceinline__ void pl_tile_store(const f32x4& hh, const f32x4& xx, 
     pl_store8(oh + stride, l2);
   }
   if (mir_hi != nullptr) {  // wave-uniform
-    uint16_t* mh = mir_hi + n0;
+    uint16_t* mh = SWZ ? mir_hi + pl_swz_elems(kPlPad + n0) : mir_hi + n0;  // four elements: inside one half-row either way
     if (n0 + 3 < L_out) {
       *reinterpret_cast<uint2*>(mh) = h2;
       *reinterpret_cast<uint2*>(mh + mir_stride) = l2;
@@ -391,16 +404,19 @@ __device__ __forceinline__ void pl_tile_store(const f32x4& hh, const f32x4& xx, 
 // wave: out[kPlPad - n] = s[n], n = 1 .. 128, and out[kPlPad + L + j] = s[L - 2 - j], j = 0 .. 127 — two elements per
 // lane, end and plane.  The bits pl_tile_store<true> writes; off the tiles' critical path (below level 4 every tile of a
 // level holds padding samples, and the scattered 16-bit stores were a third of a one-tile level's time).
-__device__ __forceinline__ void pl_reflect_pad_from_lds(const uint16_t* img, int img_stride, int L, uint16_t* __restrict__ out_hi,
+// `region` = the swizzled resident region of the level (sample n at pl_swz_elems(kPlPad + n)).
+__device__ __forceinline__ void pl_reflect_pad_from_lds(const uint16_t* region, int img_stride, int L, uint16_t* __restrict__ out_hi,
                                                         int64_t stride, int lane) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int n = 2 * lane + 1 + e;  // 1 .. 128
-    out_hi[kPlPad - n] = img[n];
-    out_hi[stride + kPlPad - n] = img[img_stride + n];
+    const int a = pl_swz_elems(kPlPad + n);
+    out_hi[kPlPad - n] = region[a];
+    out_hi[stride + kPlPad - n] = region[img_stride + a];
     const int j = 2 * lane + e;      // 0 .. 127
-    out_hi[kPlPad + L + j] = img[L - 2 - j];
-    out_hi[stride + kPlPad + L + j] = img[img_stride + L - 2 - j];
+    const int b = pl_swz_elems(kPlPad + L - 2 - j);
+    out_hi[kPlPad + L + j] = region[b];
+    out_hi[stride + kPlPad + L + j] = region[img_stride + b];
   }
 }
 
@@ -413,7 +429,8 @@ __device__ __forceinline__ void pl_reflect_pad_from_lds(const uint16_t* img, int
 // PF:     k-steps of LDS fragment reads kept ahead of the matrix instructions (0 = the compiler's own order, which reads
 //         each fragment right in front of its use and waits: fine where four waves per SIMD and a prefetched next item
 //         cover it, 1.5 k cycles per tile where a tile's latency is the critical path — the per-window kernel).
-template <bool F32IN, bool MIRROR = false, int PF = 0>
+// SWZ_MIR: the mirror image is a swizzled resident region (see pl_tile_store).
+template <bool F32IN, bool MIRROR = false, int PF = 0, bool SWZ_MIR = false>
 __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, int64_t stride, int L_in, uint16_t* __restrict__ out_hi,
                                             int L_out, int tile, const uint4 (&th)[kPlDmSteps], const uint4* __restrict__ tlo,
                                             uint4* __restrict__ rows, int lane, uint16_t* mir_hi = nullptr, int mir_stride = 0) {
@@ -434,14 +451,19 @@ __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, int64_t str
       bl = pl_zero_outside(bl, base + 256, L_in);
     }
   }
-  uint4* rh = rows + m * kPlRowU + kg;
-  uint4* rl = rh + 24 * kPlRowU;
-  rh[0] = ah;
-  rl[0] = al;
-  if (m >= 8) {
-    rh[8 * kPlRowU] = bh;
-    rl[8 * kPlRowU] = bl;
+  // the swizzled row image: row rho's unit kg at 4 rho + (kg ^ 2 p), p = (rho >> 2) & 1
+  uint4* r0 = rows + m * kPlRowU + kg;
+  uint4* r1 = rows + m * kPlRowU + (kg ^ 2);
+  {
+    uint4* wr = (m & 4) ? r1 : r0;  // rows m and m + 8 have the same p
+    wr[0] = ah;
+    wr[24 * kPlRowU] = al;
+    if (m >= 8) {
+      wr[8 * kPlRowU] = bh;
+      wr[(24 + 8) * kPlRowU] = bl;
+    }
   }
+  auto row_at = [&](int s) { return ((m + s) & 4) ? r1 : r0; };  // the lane's unit of row m + s
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -453,7 +475,8 @@ __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, int64_t str
   if constexpr (PF == 0) {
 #pragma unroll
     for (int s = 0; s < kPlDmSteps; ++s) {
-      const uint4 xh = rh[s * kPlRowU], xl = rl[s * kPlRowU];
+      const uint4* rs = row_at(s);
+      const uint4 xh = rs[s * kPlRowU], xl = rs[(24 + s) * kPlRowU];
       const uint4 tls = tl[s * 64];
       hh = BP_PL_MFMA16(th[s], xh, hh);
       xa = BP_PL_MFMA16(tls, xh, xa);
@@ -462,8 +485,9 @@ __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, int64_t str
   } else {
     uint4 xh[PF + 1], xl[PF + 1], tls[PF + 1];
     auto rd = [&](int s) {
-      xh[s % (PF + 1)] = rh[s * kPlRowU];
-      xl[s % (PF + 1)] = rl[s * kPlRowU];
+      const uint4* rs = row_at(s);
+      xh[s % (PF + 1)] = rs[s * kPlRowU];
+      xl[s % (PF + 1)] = rs[(24 + s) * kPlRowU];
       tls[s % (PF + 1)] = tl[s * 64];
     };
 #pragma unroll
@@ -482,7 +506,7 @@ __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, int64_t str
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  pl_tile_store(hh, xa + xb, out_hi, stride, L_out, tile, lane, MIRROR ? mir_hi : nullptr, mir_stride);
+  pl_tile_store<true, SWZ_MIR>(hh, xa + xb, out_hi, stride, L_out, tile, lane, MIRROR ? mir_hi : nullptr, mir_stride);
 }
 
 // One tile whose input level is resident in LDS as contiguous hi / lo planes (round 5): the B fragment of lane (m, kg) at
@@ -500,15 +524,18 @@ __device__ __forceinline__ void pl_dec_tile_lds(const uint16_t* in_hi, int in_st
                                                 const uint4* __restrict__ tlo, int lane, uint16_t* mir_hi, int mir_stride) {
   asm volatile("" : "+v"(lane));  // keep the filter's lo fragments in LDS (see pl_dec_tile)
   const int m = lane & 15, kg = lane >> 4;
-  const int base = 2 * kPlTileOut * tile + 32 * m + 8 * kg;
-  const uint4* ph = reinterpret_cast<const uint4*>(in_hi + base);
-  const uint4* pw = reinterpret_cast<const uint4*>(in_hi + in_stride + base);
+  // the region is swizzled (see kPlRowU): the lane's unit of row 16 tile + m + s is kg ^ 2 p(s), p(s) = ((m + s) >> 2) & 1
+  const int base = 2 * kPlTileOut * tile + 32 * m;
+  const uint4* p0 = reinterpret_cast<const uint4*>(in_hi + base + 8 * kg);
+  const uint4* p1 = reinterpret_cast<const uint4*>(in_hi + base + 8 * (kg ^ 2));
+  static_assert((2 * kPlTileOut) % 256 == 0, "a tile starts on a swizzle period");
   const uint4* tl = tlo + lane;
   f32x4 hh = {0.f, 0.f, 0.f, 0.f}, xa = hh, xb = hh;
   uint4 xh[PF + 1], xl[PF + 1], tls[PF + 1];
   auto rd = [&](int s) {
-    xh[s % (PF + 1)] = ph[4 * s];
-    xl[s % (PF + 1)] = pw[4 * s];
+    const uint4* ps = ((m + s) & 4) ? p1 : p0;
+    xh[s % (PF + 1)] = ps[4 * s];
+    xl[s % (PF + 1)] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(ps + 4 * s) + in_stride);
     tls[s % (PF + 1)] = tl[s * 64];
   };
 #pragma unroll
@@ -522,7 +549,7 @@ __device__ __forceinline__ void pl_dec_tile_lds(const uint16_t* in_hi, int in_st
     xb = BP_PL_MFMA16(th[s], xl[s % (PF + 1)], xb);
     __builtin_amdgcn_sched_barrier(0);
   }
-  pl_tile_store<TAIL>(hh, xa + xb, out_hi, stride, L_out, tile, lane, mir_hi, mir_stride);
+  pl_tile_store<TAIL, true>(hh, xa + xb, out_hi, stride, L_out, tile, lane, mir_hi, mir_stride);
 }
 
 // The filter's hi fragments live in registers (36 VGPRs), its lo fragments in LDS (9 KB, one ds_read_b128 per k-step):
@@ -687,7 +714,8 @@ __global__ __launch_bounds__(kPlTailThreads) void pl_decimate_tail_kernel(const 
 constexpr int kPwThreads = 1024;
 constexpr int kPwGuard = kPlPad;   // zeros in front of a resident level (the decimator's zero padding; tile 0 reads them)
 constexpr int kPwTail = 768;       // zeros behind it (the last tile's fragments reach at most 767 elements past the samples)
-__host__ __device__ constexpr int pw_level_elems(int k) { return kPwGuard + ((level_len(k) + 7) & ~7) + kPwTail; }
+// (whole swizzle periods of 256 elements: a region's swizzle is then that of its plane, whatever its offset in it)
+__host__ __device__ constexpr int pw_level_elems(int k) { return (kPwGuard + ((level_len(k) + 7) & ~7) + kPwTail + 255) & ~255; }
 constexpr int kPwPlaneA = pw_level_elems(1);  // 22824 elements per plane: level 1; later levels 3 .. 7 back to back
 constexpr int kPwPlaneB = pw_level_elems(2);  // 11864: level 2, in the space of the row images
 static_assert(2 * kPwPlaneB * 2 <= (kPwThreads / 64) * kPlRowsU * 16, "level 2 fits the row images' space");
@@ -698,8 +726,9 @@ static_assert(kPlDmSteps * 64 * 16 + (kPwThreads / 64) * kPlRowsU * 16 + 2 * kPw
 // zero elements [from, to) of both planes of a resident region (from, to multiples of 4), all threads of the workgroup
 __device__ __forceinline__ void pw_zero(uint16_t* hi, int stride, int from, int to) {
   for (int i = from + 4 * (int)threadIdx.x; i < to; i += 4 * kPwThreads) {
-    *reinterpret_cast<uint2*>(hi + i) = uint2{0u, 0u};
-    *reinterpret_cast<uint2*>(hi + stride + i) = uint2{0u, 0u};
+    const int a = pl_swz_elems(i);  // region element i (a group of four stays inside its half-row)
+    *reinterpret_cast<uint2*>(hi + a) = uint2{0u, 0u};
+    *reinterpret_cast<uint2*>(hi + stride + a) = uint2{0u, 0u};
   }
 }
 
@@ -727,7 +756,7 @@ __device__ __forceinline__ void pw_level(uint16_t* reg_a, uint16_t* b16, uint16_
   // input: level K - 1 (region A for K = 2 and K >= 4, region B for K = 3); output image: B for K = 2, A otherwise
   const uint16_t* in_hi = (K == 3 ? b16 : reg_a) + GI::region_off();
   constexpr int in_stride = K == 3 ? kPwPlaneB : kPwPlaneA;
-  uint16_t* img = (K == 2 ? b16 : reg_a) + G::region_off() + kPwGuard;  // sample 0 of level K's image
+  uint16_t* img = (K == 2 ? b16 : reg_a) + G::region_off();  // level K's (swizzled) region: sample 0 kPwGuard elements in
   constexpr int img_stride = K == 2 ? kPwPlaneB : kPwPlaneA;
   if constexpr (K == 2) {  // level 2's zero surroundings in region B (the row images' space)
     pw_zero(b16, kPwPlaneB, 0, kPwGuard);
@@ -745,7 +774,7 @@ __device__ __forceinline__ void pw_level(uint16_t* reg_a, uint16_t* b16, uint16_
   // 2 .. 7; level 1 and level 8 (no image) write theirs from the tiles
   if constexpr (K >= 3)
     if (wave == kWaves - 1)
-      pl_reflect_pad_from_lds(in_hi + kPwGuard, in_stride, GI::kLen, w + off[K - 1], stride, lane);
+      pl_reflect_pad_from_lds(in_hi, in_stride, GI::kLen, w + off[K - 1], stride, lane);
   for (int tile = wave; tile < G::kTiles; tile += kWaves)
     pl_dec_tile_lds<3, !G::kKeep>(in_hi, in_stride, w + off[K], stride, G::kLen, tile, th, tlo, lane, G::kKeep ? img : nullptr,
                                   img_stride);
@@ -803,7 +832,7 @@ __global__ __launch_bounds__(kPwThreads) void pl_pyramid_window_kernel(const flo
     for (;;) {
       const int ntile = tile + kWaves;
       const PlRaw<true> nraw = pl_fetch_rows<true>(x, nullptr, 0, kL0, ntile < tiles1 ? ntile : tile, lane);
-      pl_dec_tile<true, true, 1>(raw, g.stride, kL0, w + off[1], kL1, tile, th, tlo, rows, lane, reg_a + kPwGuard, kPwPlaneA);
+      pl_dec_tile<true, true, 1, true>(raw, g.stride, kL0, w + off[1], kL1, tile, th, tlo, rows, lane, reg_a, kPwPlaneA);
       if (ntile >= tiles1) break;
       raw = nraw, tile = ntile;
     }
