@@ -518,14 +518,17 @@ __device__ __forceinline__ void pl_dec_tile(const PlRaw<F32IN>& raw, int64_t str
 // an edge tile, and below level 4 every tile is one) a one-tile level took 2.2 us, half of it the masks.
 // At the natural 64-byte row pitch lanes m and m + 4 share banks (2-way: 8 instead of 4 LDS cycles per read, ~70 cycles a
 // tile).  The same matrix instructions in the same order on the same operands as pl_dec_tile: the same bits.
+// `in_tile`: the tile's index inside the region `in_hi` starts (>= 0: a region that holds only part of the level — the
+// chunks of level 0 — starts at a multiple of 16 tiles).
 template <int PF, bool TAIL>
 __device__ __forceinline__ void pl_dec_tile_lds(const uint16_t* in_hi, int in_stride, uint16_t* __restrict__ out_hi,
                                                 int64_t stride, int L_out, int tile, const uint4 (&th)[kPlDmSteps],
-                                                const uint4* __restrict__ tlo, int lane, uint16_t* mir_hi, int mir_stride) {
+                                                const uint4* __restrict__ tlo, int lane, uint16_t* mir_hi, int mir_stride,
+                                                int in_tile = -1) {
   asm volatile("" : "+v"(lane));  // keep the filter's lo fragments in LDS (see pl_dec_tile)
   const int m = lane & 15, kg = lane >> 4;
   // the region is swizzled (see kPlRowU): the lane's unit of row 16 tile + m + s is kg ^ 2 p(s), p(s) = ((m + s) >> 2) & 1
-  const int base = 2 * kPlTileOut * tile + 32 * m;
+  const int base = 2 * kPlTileOut * (in_tile >= 0 ? in_tile : tile) + 32 * m;
   const uint4* p0 = reinterpret_cast<const uint4*>(in_hi + base + 8 * kg);
   const uint4* p1 = reinterpret_cast<const uint4*>(in_hi + base + 8 * (kg ^ 2));
   static_assert((2 * kPlTileOut) % 256 == 0, "a tile starts on a swizzle period");
@@ -800,10 +803,48 @@ __global__ __launch_bounds__(kPwThreads) void pl_pyramid_window_kernel(const flo
   PL_STAMP(0, 0);
   PL_STAMP_RT(0, 14);
   // The kernel's first memory round trips ALL AT ONCE (issued one behind the other they were 5.6 us of a 36 us kernel):
-  // the first tile's rows, the filter fragments (hi: registers, lo: one 16-byte piece per thread for LDS), the samples of
-  // this wave's two edge rows.
-  int tile = wave;
-  PlRaw<true> raw = pl_fetch_rows<true>(x, nullptr, 0, kL0, tile, lane);
+  // the first chunk of the signal, the filter fragments (hi: registers, lo: one 16-byte piece per thread for LDS), the
+  // samples of this wave's two edge rows.
+  //
+  // Level 0 -> 1 through resident CHUNKS (round 5, second half): 16 tiles' worth of the fp32 signal (8,192 samples + the
+  // 768 the last tile's fragments reach past them, zeros outside [0, L): nnaudio.py:269-279) are split to f16 hi + lo ONCE
+  // per sample by the whole workgroup — coalesced float4 loads, the next chunk's in flight during this chunk's tiles — and
+  // parked as swizzled planes in region B; the tiles then read their fragments straight from the planes like levels 2 .. 8
+  // do (~150 instructions a tile).  The wave-private row images before it fetched, split and parked every sample 1.5 times
+  // in per-lane code: ~350 instructions a tile, and instruction issue is what paces a round of 16 tiles.
+  constexpr int kChunkTiles = 16;
+  constexpr int kChunkSamples = 2 * kPlTileOut * kChunkTiles;        // 8192
+  constexpr int kChunkElems = kChunkSamples + kPwTail;               // 8960 region elements per plane
+  constexpr int kChunkGroups = kChunkElems / 4;                      // float4 groups: 2240
+  constexpr int kChunkPer = (kChunkGroups + kPwThreads - 1) / kPwThreads;
+  constexpr int kChunks = (tiles1 + kChunkTiles - 1) / kChunkTiles;
+  static_assert(kChunkElems % 256 == 0 && 2 * kChunkElems * 2 <= (kPwThreads / 64) * kPlRowsU * 16, "a chunk fits region B");
+  static_assert(kL0 % 4 == 0 && kPwGuard % 4 == 0, "a group of four samples lies inside the signal or outside it");
+  float4 cv[kChunkPer];
+  auto chunk_load = [&](int c) {
+#pragma unroll
+    for (int k = 0; k < kChunkPer; ++k) {
+      const int gq = (int)threadIdx.x + k * kPwThreads;
+      const int n = kChunkSamples * c + 4 * gq - kPwGuard;  // sample index of the group's first element
+      cv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gq < kChunkGroups && n >= 0 && n < kL0) cv[k] = *reinterpret_cast<const float4*>(x + n);
+    }
+  };
+  auto chunk_store = [&]() {
+#pragma unroll
+    for (int k = 0; k < kChunkPer; ++k) {
+      const int gq = (int)threadIdx.x + k * kPwThreads;
+      if (gq < kChunkGroups) {
+        uint2 h2, l2;
+        split_f16x2_rn(f32x2{cv[k].x, cv[k].y}, h2.x, l2.x);
+        split_f16x2_rn(f32x2{cv[k].z, cv[k].w}, h2.y, l2.y);
+        const int a = pl_swz_elems(4 * gq);
+        *reinterpret_cast<uint2*>(b16 + a) = h2;
+        *reinterpret_cast<uint2*>(b16 + kChunkElems + a) = l2;
+      }
+    }
+  };
+  chunk_load(0);
   uint4 th[kPlDmSteps];
 #pragma unroll
   for (int s = 0; s < kPlDmSteps; ++s) th[s] = tfrag[s * 64 + lane];
@@ -820,26 +861,22 @@ __global__ __launch_bounds__(kPwThreads) void pl_pyramid_window_kernel(const flo
   *reinterpret_cast<float4*>(edge_rows + wave * g.hop0 + 4 * lane) = er_a;
   *reinterpret_cast<float4*>(edge_rows + (16 + wave) * g.hop0 + 4 * lane) = er_b;
   PL_STAMP(0, 1);
-  lds_barrier();  // the lo fragments are in LDS
-  PL_STAMP(0, 2);
   int off[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) off[k] = g.off[k];
-  {
-    // level 0 -> 1: a wave walks tiles wave, wave + 16, ... (86 tiles: the six oldest waves have six, the others five),
-    // the next tile's rows in flight during the current one's matrix work
-    uint4* rows = reg_b + wave * kPlRowsU;
-    for (;;) {
-      const int ntile = tile + kWaves;
-      const PlRaw<true> nraw = pl_fetch_rows<true>(x, nullptr, 0, kL0, ntile < tiles1 ? ntile : tile, lane);
-      pl_dec_tile<true, true, 1, true>(raw, g.stride, kL0, w + off[1], kL1, tile, th, tlo, rows, lane, reg_a, kPwPlaneA);
-      if (ntile >= tiles1) break;
-      raw = nraw, tile = ntile;
-    }
+#pragma unroll 1
+  for (int c = 0; c < kChunks; ++c) {
+    chunk_store();                      // chunk c: split, into region B
+    if (c + 1 < kChunks) chunk_load(c + 1);
+    lds_barrier();                      // the chunk (and, the first time, the lo fragments) are in LDS
+    if (c == 0) PL_STAMP(0, 2);
+    const int tile = kChunkTiles * c + wave;
+    if (tile < tiles1)
+      pl_dec_tile_lds<3, true>(b16, kChunkElems, w + off[1], g.stride, kL1, tile, th, tlo, lane, reg_a, kPwPlaneA, wave);
+    lds_barrier();                      // every wave has read the chunk
   }
   PL_STAMP(0, 3);
-  lds_barrier();  // level 1 is complete in region A; the row images are dead
-  PL_STAMP(0, 4);
+  PL_STAMP(0, 4);  // (level 1 is complete in region A, the chunk buffer is dead: the loop's last barrier)
   pw_level<2>(reg_a, b16, w, off, g.stride, th, tlo, wave, lane);
   pw_level<3>(reg_a, b16, w, off, g.stride, th, tlo, wave, lane);
   pw_level<4>(reg_a, b16, w, off, g.stride, th, tlo, wave, lane);

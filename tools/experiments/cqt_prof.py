@@ -27,7 +27,7 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (2 * 2 * 16 * 16))()
 rc = lib.bp_debug_pl_prof(buf)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(2, 2, 16, 16).astype(np.int64)
-names = {0: ["entry", "edge rows", "tfrag", "L1 tiles", "L1 barrier"] + [f"L{k}" for k in range(2, 9)],
+names = {0: ["entry", "start-up", "chunk 0 in", "L1 chunks", "L1 end"] + [f"L{k}" for k in range(2, 9)],
          1: ["entry", "setup", "tasks", "barrier", "norm A", "norm B+C", "end barrier"]}
 print("rc", rc)
 for kern, kn in ((0, "pyramid"), (1, "filterbank")):
