@@ -130,6 +130,10 @@ __global__ __launch_bounds__(256) void contour_conv2_kernel(const float* __restr
           // measured the same (round 5: 0.112 vs 0.112 ms) — other waves fill the slots; 200 plain v_fmac_f32 instead
           // of the 100 packed ones: 0.132 ms; two rows of loads in flight instead of one: 0.118; six resident waves per
           // SIMD instead of five (5 slabs of 35 frames): 0.103 - 0.107 against 0.106 - 0.109, seven or eight: 0.123
+          // (profiles/r05_c_stalls.md: 58 % of the wave cycles sit in s_waitcnt, 11 % issue vector instructions.  TWO bins
+          // per lane — six pixel columns serve two outputs, every tap feeds two packed FMAs, 108 VGPRs, four waves per SIMD —
+          // measured 0.127 / 0.114 / 0.115 ms with 4 / 5 / 7 slabs against 0.112: what the shared taps save the lost
+          // occupancy costs.)
           const v2f wv2 = {wd[dw * 8 + 2 * c2], wd[dw * 8 + 2 * c2 + 1]};
           acc[d] = __builtin_elementwise_fma(wv2, x[dw][c2], acc[d]);
         }
