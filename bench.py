@@ -511,7 +511,18 @@ def main() -> None:
         if args.control_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group("gloo")
+            # gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to 1 peer ranks ..."): the contract is
+            # ONE JSON line there, so the group is brought up (first collective included) with fd 1 pointing at stderr
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo")
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
 
     from basic_pitch_amd.inference import Model
 
