@@ -23,6 +23,7 @@ SOURCES = [
     "cqt_planes.hip",
     "conv_contour1.hip",
     "conv_contour_rim.hip",
+    "conv_contour_rim_march.hip",
     "conv_contour_march.hip",
     "conv_contour2.hip",
     "conv_contour_fold_mx.hip",

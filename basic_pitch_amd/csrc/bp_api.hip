@@ -83,6 +83,8 @@ void launch_contour_conv1_march(const uint32_t* zp, const void* wfrag, const flo
                                 bool weights_have_lo, hipStream_t stream);
 void launch_contour_conv1_rim(const uint32_t* zp, const void* afrag, const float* bias, float* c1, int n_windows, int n_cu,
                               bool weights_have_lo, bool ext, hipStream_t stream);
+void launch_contour_conv1_rim_march(const uint32_t* zp, const void* afrag, const float* bias, float* c1, int n_windows, int n_cu,
+                                    bool weights_have_lo, hipStream_t stream);
 #ifdef BP_AB_KERNELS  // onset_march.hip: the 32x32x16 form of the onset march (A/B builds only)
 void launch_onset_march(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, float* onset,
                         int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
@@ -234,7 +236,7 @@ struct bp_context {
         *d_onset_wmx = nullptr, *d_onset_w16 = nullptr;
   float* zp = nullptr;  // uint32 [cap][kZRowsP][kZRow] pre-split z, zero padded (bp_common.h)
   // contour branch, two-kernel form (conv_contour_direct.hip): LDS weight image, bias[8], conv2 taps [5][5][8]
-  float *d_d1_wlds = nullptr, *d_d1_wfold = nullptr, *d_d1_wmarch = nullptr, *d_d1_wrim = nullptr, *d_d1_bias = nullptr,
+  float *d_d1_wlds = nullptr, *d_d1_wfold = nullptr, *d_d1_wmarch = nullptr, *d_d1_wrim = nullptr, *d_d1_wrimm = nullptr, *d_d1_bias = nullptr,
         *d_d2_w = nullptr;
   bool rim_exact = false, fold_mx = false;
   int resample_mode = 0;  // BP_RESAMPLE=plain|tiled: 1 | 2 (A/B runs of the resampling kernels)
@@ -526,6 +528,47 @@ void pack_contour_rim(const Tensor* w1, std::vector<uint16_t>& out, int n_bins =
   }
 }
 
+// The same dense per-side matrix for the register-resident rim kernel (conv_contour_rim_march.hip, 309-bin CQT): M blocks of
+// 16 rows = (2 bins x 8 channels), K = (dt, j) flattened = 432 -> 14 k-steps of 32 (zeros behind 432).  A fragments
+// [side][block 10][k-step 14][hi|lo][64 lanes][8]: lane (row i = lane & 15 = 8 (f % 2) + o, g = lane >> 4), element el:
+// k = 32 s + 8 g + el.
+void pack_contour_rim_march(const Tensor* w1, std::vector<uint16_t>& out) {
+  static const int shifts[8] = {-36, 0, 36, 57, 72, 84, 93, 101};
+  constexpr int kJ = 144, kSteps = (3 * kJ + 31) / 32, n_bins = 309;
+  out.assign((size_t)2 * 10 * kSteps * 2 * 64 * 8, 0);
+  for (int side = 0; side < 2; ++side) {
+    const int f0 = side ? 244 : 0, j0 = side ? 184 : 0;
+    std::vector<double> k((size_t)20 * 8 * 3 * kJ, 0.0);  // [f_local][o][dt][j], as pack_contour_rim
+    for (int fl = 0; fl < 20; ++fl)
+      for (int o = 0; o < 8; ++o)
+        for (int c = 0; c < 8; ++c)
+          for (int dt = 0; dt < 3; ++dt)
+            for (int df = 0; df < 39; ++df) {
+              const int sb = f0 + fl + df - 19;
+              if (sb < 0 || sb >= 264) continue;
+              const int zb = sb + shifts[c], j = zb - j0;
+              if (zb < 0 || zb >= n_bins) continue;
+              if (j < 0 || j >= kJ) {
+                std::fprintf(stderr, "pack_contour_rim_march: z bin %d outside the side's window\n", zb);
+                std::abort();
+              }
+              k[(((size_t)fl * 8 + o) * 3 + dt) * kJ + j] += (double)w1->data[((o * 8 + c) * 3 + dt) * 39 + df];
+            }
+    for (int mb = 0; mb < 10; ++mb)
+      for (int s = 0; s < kSteps; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int g = lane >> 4, i = lane & 15, fl = 2 * mb + (i >> 3), o = i & 7;
+          const size_t step = (size_t)(side * 10 + mb) * kSteps + s;
+          const size_t base_hi = ((step * 2 + 0) * 64 + lane) * 8, base_lo = ((step * 2 + 1) * 64 + lane) * 8;
+          for (int el = 0; el < 8; ++el) {
+            const int kk = 32 * s + 8 * g + el;
+            const float v = kk < 3 * kJ ? (float)k[(((size_t)fl * 8 + o) * 3 + kk / kJ) * kJ + kk % kJ] : 0.0f;
+            put_split(out, base_hi, base_lo, el, v, 2048.0f);
+          }
+        }
+  }
+}
+
 // ---- block-scaled fp8 (OCP e4m3fn, as gfx950's v_mfma_scale_f32_*_f8f6f4 reads it) for correction products ----
 // encode v / 2^e to e4m3fn, round to nearest even, saturating at +-448 (no infinities in the format)
 static uint8_t f32_to_e4m3(double v) {
@@ -785,7 +828,7 @@ void pack_filterbank_planes(const Tensor* re, const Tensor* im, std::vector<uint
 }
 
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->d_pl_bin_k, h->planes, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->d_onset_w16, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wmarch, h->d_d1_wrim, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->d_pl_bin_k, h->planes, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->d_onset_w16, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wmarch, h->d_d1_wrim, h->d_d1_wrimm, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->nd_buf, h->nd_tables, h->fb_scratch, h->pcm_dev, h->mono_dev, h->res_dev, reinterpret_cast<float*>(h->taps_dev)};
@@ -809,6 +852,19 @@ int ensure_fb_scratch(bp_handle h, int64_t n) {
   BP_HIP(hipMalloc(&h->fb_scratch, filterbank_scratch_floats((int)n) * sizeof(float)));
   h->fb_scratch_windows = n;
   return BP_OK;
+}
+
+// The rim of contour conv1: the register-resident march (309-bin CQT), the round-3 GEMM for the extended 44.1 kHz mode
+// (its 160 z bins per side would need 120 VGPRs of weights) and, in the A/B library, on BP_RIM=gemm.
+static void launch_rim(bp_handle h, const uint32_t* zp, float* c1, int n, bool wlo, hipStream_t s) {
+  static const bool gemm = [] {
+    const char* e = ab_env("BP_RIM");
+    return e && std::strcmp(e, "gemm") == 0;
+  }();
+  if (h->ext || gemm || !h->d_d1_wrimm)
+    launch_contour_conv1_rim(zp, h->d_d1_wrim, h->d_d1_bias, c1, n, h->n_cu, wlo, h->ext, s);
+  else
+    launch_contour_conv1_rim_march(zp, h->d_d1_wrimm, h->d_d1_bias, c1, n, h->n_cu, wlo, s);
 }
 
 // One chunk (n <= cap) of windows already resident at `audio_dev`; outputs to device pointers.
@@ -904,7 +960,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
         launch_contour_conv1_exact(zpp, h->d_d1_wlds, h->d_d1_bias, c1p, nw, h->n_cu, wlo, s);
       else
 #endif
-        launch_contour_conv1_rim(zpp, h->d_d1_wrim, h->d_d1_bias, c1p, nw, h->n_cu, wlo, h->ext, s);
+        launch_rim(h, zpp, c1p, nw, wlo, s);
       if (!contour_conv1_full()) {
         BP_MARK(BP_STAGE_CONTOUR_CONV1_EDGE);
         BP_DOM_BEGIN();
@@ -1118,6 +1174,10 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     else
       pack_contour_rim(c1w, frag);
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wrim))) return fail(rc);
+    if (!(flags & BP_FLAG_EXT_CQT_44K)) {  // the register-resident rim kernel serves the 309-bin CQT
+      pack_contour_rim_march(c1w, frag);
+      if ((rc = upload(h, raw_of(frag), &h->d_d1_wrimm))) return fail(rc);
+    }
     // folded conv1: all three split-precision products on f16 by default (fp32-class); BP_FLAG_FP8_CORRECTIONS opts into
     // the block-scaled fp8 corrections (conv_contour_fold_mx.hip; ~1e-5 on the contour map), BP_CONV1=f16 then keeps this
     // one layer on the three-product f16 kernel (A/B runs).
@@ -1960,7 +2020,7 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
             launch_contour_conv1_exact(bf->zp, h->d_d1_wlds, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
           else
 #endif
-            launch_contour_conv1_rim(bf->zp, h->d_d1_wrim, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, h->ext, s);
+            launch_rim(h, bf->zp, h->c1s, n, wlo, s);
           if (h->fold_mx && wlo) {
             const char* base = reinterpret_cast<const char*>(h->d_d1_wfold_mx);
             launch_contour_conv1_fold_mx(bf->zp, base, base + 36 * 64 * 16, base + 36 * 64 * 16 + 18 * 64 * 32, h->d_d1_bias,

@@ -1038,6 +1038,27 @@ def test_contour_march_equals_round_kernel(tmp_path):
     assert d <= 2e-6, d
 
 
+def test_rim_march_equals_rim_gemm(tmp_path):
+    """The rim of contour conv1 with the weights resident in registers (conv_contour_rim_march.hip, the default for the
+    309-bin CQT since round 5: 16-row blocks on 16x16x32, 14 k-steps of 32, z rows by LDS-DMA) and as the round-3 GEMM
+    (conv_contour_rim.hip, BP_RIM=gemm in the A/B library: 32-row blocks on 32x32x16, 27 k-steps of 16) multiply the same
+    per-side matrix with the same z rows: the contour maps agree to fp32 accumulation-order noise, on the rim bins and —
+    through conv2's 5 x 5 window — their neighbours.  Random z through the C ABI stage hook, one process per kernel."""
+    import subprocess
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "experiments", "contour_ab.py")
+    outs = {}
+    for name, env in (("march", {}), ("gemm", {"BP_RIM": "gemm"})):
+        out = str(tmp_path / f"{name}.npy")
+        subprocess.run([sys.executable, tool, out], check=True, env=_ab_env(**env), timeout=600)
+        outs[name] = np.load(out)
+    assert np.isfinite(outs["march"]).all()
+    d = np.abs(outs["march"] - outs["gemm"])
+    assert d.max() <= 2e-6, d.max()
+    assert d[..., 24:240].max() == 0.0  # away from the rim nothing changed
+
+
 def test_device_note_candidates_give_the_host_decoders_events(tmp_path):
     """The dense half of note decoding on the device (csrc/note_device.hip: constrain_frequency, inferred onsets, peak
     picking + threshold as a bitmap, the pitch bends of every (frame, bin); note_creation.py:289-343, 394-402, 182-219)
