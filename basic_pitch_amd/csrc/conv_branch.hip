@@ -211,9 +211,11 @@ __device__ __forceinline__ void raw_dma_issue(const BranchParams& p, int b, int 
 template <class Br, bool MX = false>
 __device__ __forceinline__ void raw_convert(int row_first, const uint4* raw_, uint4* __restrict__ img_hi,
                                             uint4* __restrict__ img_lo, int tid) {
-  // the DMA's LDS writes are invisible to the optimiser: read through a laundered pointer
-  const uint4* raw = raw_;
-  asm volatile("" : "+v"(raw)::"memory");
+  // the DMA's LDS writes are invisible to the optimiser: read behind a memory clobber, at a laundered OFFSET (laundering the
+  // pointer itself loses its address space: the reads became flat_load_dword — round 5, found in conv_contour_rim_march.hip)
+  int zoff = 0;
+  asm volatile("" : "+v"(zoff)::"memory");
+  const uint4* raw = raw_ + zoff;
   constexpr int PER_ROW = Br::kOnset ? kFreqC : kFreqN;
   constexpr int ntask = kBrRows * PER_ROW;
 #pragma unroll 1

@@ -265,7 +265,7 @@ def test_no_kernel_of_the_product_library_uses_scratch():
     assert len(rows) >= 40, len(rows)
     names = " ".join(r["name"] for r in rows)
     for must in ("pl_pyramid_window_kernel", "cqt_filterbank_planes_kernel", "contour_conv1_march_kernel",
-                 "contour_conv1_rim_kernel", "contour_conv2_kernel", "note_march_kernel", "onset_march16_kernel"):
+                 "contour_conv1_rim_kernel", "contour_conv1_rim_march_kernel", "contour_conv2_kernel", "note_march_kernel", "onset_march16_kernel"):
         assert must in names, must
     bad = [(r["name"], r["scratch"], r["vgpr_spill"], r["sgpr_spill"]) for r in rows
            if r["scratch"] or r["vgpr_spill"] or r["sgpr_spill"]]
