@@ -13,6 +13,9 @@ int bp_infer_pcm_raw(bp_handle, const void*, int, int64_t, int, int, float*, flo
 const char* bp_last_error(bp_handle) { return ""; }
 int64_t bp_handle_track_n_frames(bp_handle, int64_t) { return 0; }
 int64_t bp_handle_resampled_length(bp_handle, int64_t, int) { return 0; }
+int bp_handle_sample_rate(bp_handle) { return 22050; }
+int bp_infer_pcm_raw_candidates(bp_handle, const void*, int, int64_t, int, int, const bp_note_params*, float*, uint8_t*, int8_t*,
+                                int*) { return -1; }
 }
 static uint64_t s = 88172645463325252ull;
 static uint32_t rnd() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 11); }
@@ -45,7 +48,7 @@ int main(int argc, char** argv) {
   }
   printf("wav ok %ld bad %ld\n", ok, bad); fflush(stdout);
   // ---- note decoder + writers on random maps
-  long ev_total = 0;
+  long ev_total = 0, cand_total = 0;
   for (int it = 0; it < 300; ++it) {
     const int64_t T = 1 + rnd() % 300;
     std::vector<float> note((size_t)T * 88), onset((size_t)T * 88), contour((size_t)T * 264);
@@ -76,7 +79,25 @@ int main(int argc, char** argv) {
       }
       ev_total += ne;
     }
+    // the candidate-mode tracker (round 5) on an arbitrary peak bitmap and bend map: whatever the device could hand over
+    if (prm.onset_threshold > 0.0) {
+      std::vector<uint8_t> bits((size_t)T * BP_NOTE_CAND_ROW_BYTES);
+      std::vector<int8_t> bend((size_t)T * 88);
+      for (auto& b : bits) b = (rnd() % 6 == 0) ? (uint8_t)rnd() : 0;
+      for (auto& b : bend) b = (int8_t)((int)(rnd() % 51) - 25);
+      for (auto& v : note) if (std::isnan(v)) v = 0.5f;  // the device reports NaN maps back instead (status 1)
+      std::vector<bp_note_event> ev2(256); std::vector<int32_t> bends2(4096);
+      int64_t ne2 = 0, nb2 = 0;
+      int rc2 = bp_notes_decode_candidates(note.data(), bits.data(), (it & 1) ? bend.data() : nullptr, T, &prm, ev2.data(),
+                                           (int64_t)ev2.size(), bends2.data(), (int64_t)bends2.size(), &ne2, &nb2);
+      if (rc2 != 0 && (ne2 > (int64_t)ev2.size() || nb2 > (int64_t)bends2.size())) {
+        ev2.resize((size_t)ne2 + 1); bends2.resize((size_t)nb2 + 1);
+        rc2 = bp_notes_decode_candidates(note.data(), bits.data(), (it & 1) ? bend.data() : nullptr, T, &prm, ev2.data(),
+                                         (int64_t)ev2.size(), bends2.data(), (int64_t)bends2.size(), &ne2, &nb2);
+      }
+      if (rc2 == 0) cand_total += ne2;
+    }
   }
-  printf("note decode events %ld\n", ev_total);
+  printf("note decode events %ld, candidate-mode events %ld\n", ev_total, cand_total);
   return 0;
 }
