@@ -1146,3 +1146,15 @@ def test_device_note_candidates_give_the_host_decoders_events(tmp_path):
     assert check(bad, dict(onset_thresh=0.5, frame_thresh=0.3)) == 1
     assert check(zero, dict(onset_thresh=0.0, frame_thresh=0.3)) == 1
     m.close()
+
+
+def test_whole_path_is_run_to_run_deterministic():
+    """The same batch through the whole path 150 times at three batch sizes: every output bit-identical to the first pass.
+    The rim kernel of contour conv1 orders its LDS-DMA by hand (counted s_waitcnt vmcnt, one barrier per item): a missing
+    wait or a barrier one item early shows up as a run-to-run difference long before it shows up as a parity error."""
+    import subprocess
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "experiments", "determinism_stress.py")
+    res = subprocess.run([sys.executable, tool, "150"], capture_output=True, text=True, timeout=600, env=_ab_env())
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
