@@ -122,18 +122,42 @@ __global__ __launch_bounds__(64 * kO16Waves, 2) void onset_march16_kernel(Onset1
   // workgroups of the same XCD, so a row is fetched from HBM by one L2 instead of by up to eight
   const int half_n = (int)gridDim.x / 2, pq = (int)blockIdx.x % (half_n > 0 ? half_n : 1);
   const int lblock = (gridDim.x % 16 == 0) ? ((int)blockIdx.x / half_n) * half_n + (pq % 8) * (half_n / 8) + pq / 8 : (int)blockIdx.x;
-  // Work = the frames of all (window, strip) pairs laid end to end; wave g of G takes the g-th G-th of them: at most two
-  // marches (round 4: three tasks of an eighth of a window-strip each — three prologues and 3 x 2 warm-up rows per wave
-  // where 64.5 contiguous frames need 1.4 of each).
+  // Work = the frames of all (window, strip) pairs; every wave takes an equal share of them as at most two marches
+  // (round 4: three tasks of an eighth of a window-strip each — three prologues and 3 x 2 warm-up rows per wave).
+  //  * exactly 8 waves per window (full batches: 2048 waves, 256 windows; 3 strips x 172 frames = 8 x 64.5): waves 0-2
+  //    of a window march frames 0..63 of strips 0, 1, 2, waves 3-5 frames 64..128, wave 6 the rest of strip 0 and half the
+  //    rest of strip 1, wave 7 the other half and the rest of strip 2 — 1.25 pieces per wave, and the three strips of a
+  //    frame range, which gather from the SAME zp rows, are marched at the same time by neighbouring waves of one
+  //    workgroup (laid end to end instead, the strips of a window were marched at different times: 183 MB of HBM reads
+  //    per launch where this order needs 121 — the time is the same);
+  //  * any other wave count: the pairs laid end to end, wave g of G takes the g-th G-th.
   const int gw = lblock * kO16Waves + wave;
+  const bool aligned = total_waves == 8 * (p.n_ws / kO16Strips);  // wave-uniform
+  constexpr int kCut1 = 64, kCut2 = 129, kCut3 = 150;             // 64 | 65 | 43 = 21 + 22
+  const int b8 = gw >> 3, j8 = gw & 7;
   const int64_t total = (int64_t)p.n_ws * kFrames;
-  int64_t F0 = total * gw / total_waves;
+  int64_t F0 = total * gw / total_waves;  // the end-to-end order's share (a share may span several pairs)
   const int64_t F1 = total * (gw + 1) / total_waves;
 #pragma unroll 1
-  for (int ws = (int)(F0 / kFrames); F0 < F1; ++ws, F0 = (int64_t)ws * kFrames) {  // wave-uniform; no barriers
+  for (int pi = 0;; ++pi) {  // wave-uniform; no barriers
+    int ws, T0, T1;
+    if (aligned) {
+      if (pi >= (j8 < 6 ? 1 : 2)) break;
+      if (j8 < 6) {
+        ws = kO16Strips * b8 + (j8 < 3 ? j8 : j8 - 3), T0 = j8 < 3 ? 0 : kCut1, T1 = j8 < 3 ? kCut1 : kCut2;
+      } else if (pi == 0) {
+        ws = kO16Strips * b8 + (j8 - 6), T0 = j8 == 6 ? kCut2 : kCut3, T1 = kFrames;
+      } else {
+        ws = kO16Strips * b8 + (j8 - 5), T0 = kCut2, T1 = j8 == 6 ? kCut3 : kFrames;
+      }
+    } else {
+      if (F0 >= F1) break;
+      ws = (int)(F0 / kFrames);
+      T0 = (int)(F0 - (int64_t)ws * kFrames);
+      T1 = F1 - (int64_t)ws * kFrames < kFrames ? (int)(F1 - (int64_t)ws * kFrames) : kFrames;
+      F0 = (int64_t)(ws + 1) * kFrames;
+    }
     const int b = ws / kO16Strips, strip = ws - b * kO16Strips;
-    const int T0 = (int)(F0 - (int64_t)ws * kFrames);
-    const int T1 = F1 - (int64_t)ws * kFrames < kFrames ? (int)(F1 - (int64_t)ws * kFrames) : kFrames;
 
     // this lane's two pixels of the strip (tile nt: strip pixel 16 nt + n), and the stack bin of image slot 0
     int w[2], wc[2];
