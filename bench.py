@@ -62,7 +62,7 @@ DTYPE_DEFAULT = DTYPE_F16  # since round 3 the default IS the all-f16 split (fp3
 DTYPE_FP8 = ("f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands; OPT-IN reduced precision (--fp8-corrections): contour "
              "conv1 interior and onset conv1 issue hi*hi on f16 and the two correction products (<= 2^-11 of a product) on "
              "block-scaled fp8 MFMA")
-PMC_PROFILE = "r05_d"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
+PMC_PROFILE = "r05_e"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
 
 
 def pmc_traffic(kernel_key: str, batch: int):
