@@ -1403,6 +1403,7 @@ bool launch_filterbank_planes(const uint16_t* pl, const float* audio, int64_t au
   // with the fused form from 32 windows on, 1,258 files/s against 1,460 — a third of the CUs for 60 us is worse than all
   // of them for 29 + 15 us even when other lanes' kernels could fill the rest.)
   const bool fused = zp != nullptr && 2 * n_windows >= n_cu;
+  // (768 threads with 7 / 5 k-steps of A fragments ahead, 158 VGPRs: 0.070 - 0.074 / 0.069 ms against 0.069 - 0.070, round 5)
   constexpr int kThreads = 1024, kApf = 3;
   int grid;
   if (fused) {
