@@ -30,7 +30,7 @@ SOURCES = [
     "conv_stride3.hip",
     "conv_heads.hip",
     "conv_branch.hip",
-    "note_march.hip",
+    "note_march16.hip",
     "onset_march16.hip",
     "note_device.hip",
     "audio_ingest.hip",
@@ -44,6 +44,7 @@ SOURCES = [
 AB_SOURCES = [
     "conv_contour_direct.hip",  # exact 8-channel conv1 (BP_RIM=exact, BP_CONV1=full), round-2 folded conv1 (BP_CONV1=rounds)
     "onset_march.hip",          # onset march on 32x32x16 (BP_ONSET=march32)
+    "note_march.hip",           # note march on 32x32x16 (BP_NOTE=march32)
 ]
 AB_LIB_PATH = os.path.join(LIB_DIR, "libbasicpitch_amd_ab.so")
 

@@ -95,8 +95,12 @@ void launch_contour_conv1_fold_mx(const uint32_t* zp, const void* a16, const voi
                                   const float* bias, float* c1, int n_windows, int n_cu, hipStream_t stream);
 void launch_contour_conv2(const float* c1, const float* w2, float bias, float* contour, int n_windows, int n_cu,
                           hipStream_t stream);
+#ifdef BP_AB_KERNELS  // note_march.hip: the 32x32x16 form of the note march (A/B builds only)
 void launch_note_march(const float* contour, const void* wfrag, const float* wf32, float* note, int n_windows,
                        bool weights_have_lo, hipStream_t stream);
+#endif
+void launch_note_march16(const float* contour, const void* wfrag, const float* wf32, float* note, int n_windows, int n_cu,
+                         bool weights_have_lo, hipStream_t stream);
 void launch_note_candidates(float* note, float* onset, const float* contour, int64_t T, int lo, int hi, int infer,
                             double onset_thresh, const void* tab, const double* gauss, void* stats, uint8_t* bits,
                             int8_t* bend, hipStream_t s);
@@ -127,6 +131,22 @@ static void launch_onset(const uint32_t* zp, const float* note, const void* wfra
     launch_onset_branch(zp, note, wfrag, wf32, wmx, onset, n_windows, n_cu, weights_have_lo, stream);
   else
     launch_onset_march16(zp, note, w16, wf32, onset, n_windows, n_cu, weights_have_lo, stream);
+}
+// the note branch: the wave-private march on 16x16x32 (round 6).  A/B builds only: BP_NOTE=march32 selects the 32x32x16 form.
+static void launch_note(const float* contour, const void* wfrag, const void* w16, const float* wf32, float* note, int n_windows,
+                        int n_cu, bool weights_have_lo, hipStream_t stream) {
+#ifdef BP_AB_KERNELS
+  static const bool march32 = [] {
+    const char* e = ab_env("BP_NOTE");
+    return e && std::strcmp(e, "march32") == 0;
+  }();
+  if (march32) {
+    launch_note_march(contour, wfrag, wf32, note, n_windows, weights_have_lo, stream);
+    return;
+  }
+#endif
+  (void)wfrag;
+  launch_note_march16(contour, w16, wf32, note, n_windows, n_cu, weights_have_lo, stream);
 }
 }  // namespace bp
 
@@ -232,7 +252,7 @@ struct bp_context {
   float *d_lowpass = nullptr, *d_sqrt_len = nullptr, *d_fb_bfrag = nullptr;
   float* d_pl_bin_k = nullptr;  // cqt_planes.hip filterbank: per-bin eps / s^2, s = sqrt(len) 2^-12
   // fused branches (conv_branch.hip): f16 hi/lo A fragments (raw bytes) + {bias1[32], extra[9], bias2}
-  float *d_note_wfrag = nullptr, *d_note_wf32 = nullptr, *d_onset_wfrag = nullptr, *d_onset_wf32 = nullptr,
+  float *d_note_wfrag = nullptr, *d_note_w16 = nullptr, *d_note_wf32 = nullptr, *d_onset_wfrag = nullptr, *d_onset_wf32 = nullptr,
         *d_onset_wmx = nullptr, *d_onset_w16 = nullptr;
   float* zp = nullptr;  // uint32 [cap][kZRowsP][kZRow] pre-split z, zero padded (bp_common.h)
   // contour branch, two-kernel form (conv_contour_direct.hip): LDS weight image, bias[8], conv2 taps [5][5][8]
@@ -787,6 +807,45 @@ void pack_onset16(const Tensor* w1, const Tensor* w2, std::vector<uint16_t>& out
     }
 }
 
+// note_march16.hip: conv1 (1 -> 32, 7 x 7, stride (1, 3), models.py:270-278) and the (7, 3) head (282-289) as
+// v_mfma_f32_16x16x32_f16 A fragments, 18 x 64 lanes x (8 x f16): conv1 [kind][k-step s][block mb] at (4 kind + 2 s + mb),
+// conv2 [kind][block mb] at 12 + 2 kind + mb; kind 0 = hi 2^11, 1 = hi, 2 = lo 2^11 (the kernel adds all three products
+// into one accumulator at scale 2^11).  conv1: lane (m = lane & 15, g = lane >> 4), element e: out channel 16 mb + m, frame
+// tap dt = 4 s + g (7: zero), bin offset e (7: zero).  conv2: row rho = lane & 15 = 4 dw + i <-> tap (dt = 4 mb + i, dw)
+// (dw = 3, dt = 7: zero rows); K index 8 g + e <-> conv1 channel 4 g + e (e < 4) or 16 + 4 g + e - 4 — the order in which
+// conv1's C layout leaves a pixel's channels in a lane.  Returns false if a weight's hi part does not survive the 2^11.
+bool pack_note16(const Tensor* w1, const Tensor* w2, std::vector<uint16_t>& out) {
+  const size_t frag = 64 * 8;
+  out.assign(18 * frag, 0);
+  bool ok = true;
+  auto put3 = [&](size_t f_hi_scaled, size_t f_hi, size_t f_lo, size_t idx, float v) {
+    const uint16_t hi = f32_to_f16(v);
+    const float hif = f16_to_f32(hi);
+    if (!(std::fabs(hif) * 2048.0f < 65504.0f)) ok = false;
+    out[f_hi_scaled * frag + idx] = f32_to_f16(hif * 2048.0f);
+    out[f_hi * frag + idx] = hi;
+    out[f_lo * frag + idx] = f32_to_f16((v - hif) * 2048.0f);
+  };
+  for (int s = 0; s < 2; ++s)
+    for (int mb = 0; mb < 2; ++mb)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const int m = lane & 15, g = lane >> 4, dt = 4 * s + g;
+          const float v = (dt < 7 && e < 7) ? w1->data[((16 * mb + m) * 7 + dt) * 7 + e] : 0.f;
+          put3(0 + 2 * s + mb, 4 + 2 * s + mb, 8 + 2 * s + mb, (size_t)lane * 8 + e, v);
+        }
+  for (int mb = 0; mb < 2; ++mb)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int e = 0; e < 8; ++e) {
+        const int rho = lane & 15, g = lane >> 4;
+        const int dw = rho >> 2, dt = 4 * mb + (rho & 3);
+        const int ch = e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4);
+        const float v = (dw < 3 && dt < 7) ? w2->data[(ch * 7 + dt) * 3 + dw] : 0.f;
+        put3(12 + mb, 14 + mb, 16 + mb, (size_t)lane * 8 + e, v);
+      }
+  return ok;
+}
+
 // cqt_planes.hip decimator (transposed: the filter is the A operand): T[u][i] = h[i - 2u - 1] — the input window starts one
 // sample before the reference's (an 8-sample aligned element of the padded plane) — as [hi: 9 steps][lo: 9 steps] x 64
 // lanes x 8 f16; lane (u = lane & 15, kg = lane >> 4), element e: i = 32 s + 8 kg + e.
@@ -828,7 +887,7 @@ void pack_filterbank_planes(const Tensor* re, const Tensor* im, std::vector<uint
 }
 
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->d_pl_bin_k, h->planes, h->d_note_wfrag, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->d_onset_w16, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wmarch, h->d_d1_wrim, h->d_d1_wrimm, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->d_pl_bin_k, h->planes, h->d_note_wfrag, h->d_note_w16, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->d_onset_w16, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wmarch, h->d_d1_wrim, h->d_d1_wrimm, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->nd_buf, h->nd_tables, h->fb_scratch, h->pcm_dev, h->mono_dev, h->res_dev, reinterpret_cast<float*>(h->taps_dev)};
@@ -981,7 +1040,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
       launch_contour_conv2(c1p, h->d_d2_w, h->b_contour2, contour_dev + (int64_t)w0 * kPlaneC, nw, h->n_cu, s);
       BP_MARK(BP_STAGE_CONTOUR_CONV2);
     }
-    launch_note_march(contour_dev, h->d_note_wfrag, h->d_note_wf32, note_dev, n, wlo, s);
+    launch_note(contour_dev, h->d_note_wfrag, h->d_note_w16, h->d_note_wf32, note_dev, n, h->n_cu, wlo, s);
     BP_MARK(BP_STAGE_NOTE);
     launch_onset(reinterpret_cast<const uint32_t*>(h->zp), note_dev, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->d_onset_w16, onset_dev,
                  n, h->n_cu, wlo, s);
@@ -1216,6 +1275,13 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       if ((rc = upload(h, raw_of(frag), br ? &h->d_onset_wfrag : &h->d_note_wfrag)) ||
           (rc = upload(h, f32, br ? &h->d_onset_wf32 : &h->d_note_wf32)))
         return fail(rc);
+    }
+    {  // the note march on 16x16x32 (the default): its own fragment order, the hi parts also at scale 2^11
+      if (!pack_note16(n1w, n2w, frag)) {
+        h->err = "bp_create: a note-branch weight is too large for the scaled f16 operand (|w| >= 31.98)";
+        return fail(BP_ERR_BAD_WEIGHTS);
+      }
+      if ((rc = upload(h, raw_of(frag), &h->d_note_w16))) return fail(rc);
     }
     {  // the onset march on 16x16x32 (the default): its own fragment order
       pack_onset16(o1w, o2w, frag);
@@ -2038,7 +2104,7 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
       break;
     case BP_STAGE_NOTE:
       if ((ok = need(bf->contour) && need(bf->note)))
-        launch_note_march(bf->contour, h->d_note_wfrag, h->d_note_wf32, bf->note, n, wlo, s);
+        launch_note(bf->contour, h->d_note_wfrag, h->d_note_w16, h->d_note_wf32, bf->note, n, h->n_cu, wlo, s);
       break;
     case BP_STAGE_ONSET:
       if ((ok = need(bf->zp) && need(bf->note) && need(bf->onset)))

@@ -799,7 +799,7 @@ def _ab_env(**switches):
     only exist in the A/B library (build.py: build_library(ab=True), -DBP_AB_KERNELS), which is built here if the tree
     does not hold a current one; with no switches, the product library."""
     e = dict(os.environ)
-    for k in ("BASIC_PITCH_AMD_LIB", "BP_ONSET", "BP_CONV1", "BP_RIM", "BP_RESAMPLE", "BP_CONTOUR_PARTS"):
+    for k in ("BASIC_PITCH_AMD_LIB", "BP_ONSET", "BP_NOTE", "BP_CONV1", "BP_RIM", "BP_RESAMPLE", "BP_CONTOUR_PARTS"):
         e.pop(k, None)
     if switches:
         from basic_pitch_amd import build as B
@@ -1057,6 +1057,28 @@ def test_rim_march_equals_rim_gemm(tmp_path):
     d = np.abs(outs["march"] - outs["gemm"])
     assert d.max() <= 2e-6, d.max()
     assert d[..., 24:240].max() == 0.0  # away from the rim nothing changed
+
+
+def test_note_march16_equals_note_march32(tmp_path):
+    """The note branch on 16x16x32 (note_march16.hip, the default since round 6: one accumulator at scale 2^11, the
+    activations' lo parts from a residual matrix instruction, conv2's vertical sum in lane) and the round-2 march on 32x32x16
+    (note_march.hip, BP_NOTE=march32 in the A/B library) evaluate the same split-precision products of the same operands in
+    another fp32 order: the note maps agree to accumulation-order noise, at the map's rims and at every cut of the frames
+    into wave shares (5 windows: the end-to-end cut; 256 windows would take the aligned cut — covered by
+    test_batch_invariance_and_chunking, which compares a 256-window launch with 7-window launches bit for bit).  Random
+    contour maps through the C ABI stage hook, one process per kernel."""
+    import subprocess
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "experiments", "note_ab.py")
+    outs = {}
+    for name, env in (("march16", {}), ("march32", {"BP_NOTE": "march32"})):
+        out = str(tmp_path / f"{name}.npy")
+        subprocess.run([sys.executable, tool, out], check=True, env=_ab_env(**env), timeout=600)
+        outs[name] = np.load(out)
+    assert np.isfinite(outs["march16"]).all()
+    d = np.abs(outs["march16"] - outs["march32"]).max()
+    assert d <= 2e-6, d
 
 
 def test_device_note_candidates_give_the_host_decoders_events(tmp_path):
