@@ -32,6 +32,7 @@
 //     march's cut): 8 % halo rows instead of 28 %.
 // Roofline: f16 MFMA issue; 20 16x16x32 per 16 pixels (12 conv1 + 2 residual + 6 projection); HBM 182 KB read (through L2:
 // the three strips of a window overlap by 2 pixels, shares by 6 rows) and 61 KB written per window.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "bp_common.h"
@@ -47,6 +48,10 @@ constexpr int kN16Ring = 8;     // image rows a wave keeps: r - 3 .. r + 3 in us
 constexpr int kN16Row = 64;     // ring row stride in 16-byte units: hi plane (32 pixels), lo plane at kN16Lo
 constexpr int kN16Lo = 32;
 constexpr int kN16Frags = 18;   // pack_note16
+#ifndef N16_OCC
+#define N16_OCC 2
+#endif
+constexpr int kN16Occ = N16_OCC;  // resident workgroups per CU (x 4 waves: waves per SIMD)
 static_assert(kN16Strips * 30 >= kFreqN, "strips cover a row");
 static_assert(kN16Row % 16 == 0, "conflict-free ds_read_b128: rows differ by a multiple of 16 units");
 
@@ -64,7 +69,7 @@ struct N16Phase {
 };
 
 template <bool WLO>
-__global__ __launch_bounds__(64 * kN16Waves, 2) void note_march16_kernel(Note16Params p) {
+__global__ __launch_bounds__(64 * kN16Waves, kN16Occ) void note_march16_kernel(Note16Params p) {
   __shared__ __attribute__((aligned(16))) uint4 lds[kN16Waves][kN16Ring * kN16Row];  // [wave][row slot][hi | lo][pixel]
 
   const int lane = threadIdx.x & 63;
@@ -72,6 +77,11 @@ __global__ __launch_bounds__(64 * kN16Waves, 2) void note_march16_kernel(Note16P
   const int g = lane >> 4, n = lane & 15;
   uint4* ring = lds[wave];
   uint2* ring2 = reinterpret_cast<uint2*>(ring);
+#ifdef N16_PROF  // tools only: 100 MHz stamps of a few waves (entry, set-up done, per share: prologue done, march done)
+  unsigned long long pt[8];
+  int npt = 0;
+  pt[npt++] = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // resident A operands (pack_note16): conv1 [kind H = hi 2^11, h = hi, L = lo 2^11][k-step][block], conv2 [kind][block]
   uint4 a1H[2][2], a1h[2][2], a1L[2][2], a2H[2], a2h[2], a2L[2];
@@ -117,6 +127,10 @@ __global__ __launch_bounds__(64 * kN16Waves, 2) void note_march16_kernel(Note16P
   const int src_l4 = ((n + 15) & 15) * 4;         // ds_bpermute: pixel n - 1 of lane group 0
   const int src_r4 = (32 + ((n + 1) & 15)) * 4;   // pixel n + 1 of lane group 2
 
+#ifdef N16_PROF
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  pt[npt++] = __builtin_amdgcn_s_memrealtime();
+#endif
   // work distribution: onset_march16.hip's (XCD-aware order; equal contiguous shares of the frames of all (window, strip)
   // pairs; at exactly 8 waves per window the three strips of a frame range are marched by neighbouring waves)
   const int total_waves = gridDim.x * kN16Waves;
@@ -124,7 +138,10 @@ __global__ __launch_bounds__(64 * kN16Waves, 2) void note_march16_kernel(Note16P
   const int lblock = (gridDim.x % 16 == 0) ? ((int)blockIdx.x / half_n) * half_n + (pq % 8) * (half_n / 8) + pq / 8 : (int)blockIdx.x;
   const int gw = lblock * kN16Waves + wave;
   const bool aligned = total_waves == 8 * (p.n_ws / kN16Strips);  // wave-uniform
-  constexpr int kCut1 = 64, kCut2 = 129, kCut3 = 150;             // 64 | 65 | 43 = 21 + 22
+  // cuts by COST, not by frames: a share costs its frames + 3 rows of halo per cut end (rows outside the window are skipped) and
+  // ~2.3 rows per prologue: 68 + 3 | 65 + 6 | 39 + 3 + (18 + 6) + prologue | (21 + 3) + (39 + 3) + prologue = 71, 71, 68.3, 68.3
+  // (profiles/r06_note_phases.md: with the onset march's cuts 64 | 65 | 43 the two-share waves ran 75 rows against 67)
+  constexpr int kCut1 = 68, kCut2 = 133, kCut3 = 151;
   const int b8 = gw >> 3, j8 = gw & 7;
   const int64_t total = (int64_t)p.n_ws * kFrames;
   int64_t F0 = total * gw / total_waves;
@@ -234,6 +251,10 @@ __global__ __launch_bounds__(64 * kN16Waves, 2) void note_march16_kernel(Note16P
       }
     };
     read_k(0, bh0, bl0);
+#ifdef N16_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (npt < 7) pt[npt++] = __builtin_amdgcn_s_memrealtime();
+#endif
     const float sig_k = -1.44269504088896341f * kLoUnscale;  // sigmoid((y + b) 2^-11) = 1 / (1 + exp2((y + b) sig_k))
     const int st_w0 = w[0], st_w1 = w[1];
 
@@ -284,36 +305,70 @@ __global__ __launch_bounds__(64 * kN16Waves, 2) void note_march16_kernel(Note16P
         pend = stage_issue(r + 5);
         conv1_kstep(1, bh1, bl1);
         read_k(ph + 1, bh0, bl0);  // rows r - 2 .. r + 1: the next step's k-step 0
-        // ReLU, split, tap projection
+        // ReLU, split, tap projection — written tile-interleaved, stage by stage: the hi parts of both tiles, their residual
+        // matrix instructions, the projection's two hi products (which need no lo part) while the residuals complete, the
+        // lo parts, the third product
         f32x4 P[2][2];  // [tile][block]: row i = frame tap 4 mb + i of dw = g, at scale 2^11
+        f32x4 v[2][2];
+        f16x8 b2h[2], b2l[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          uint32_t hw[4], lw[4];
-          f32x4 v[2];
+          uint32_t hw[4];
 #pragma unroll
           for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[mb][i] = relu_f32(acc[nt][mb][i]);
-            hw[2 * mb] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(v[mb][0] * kLoUnscale, v[mb][1] * kLoUnscale));
-            hw[2 * mb + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(v[mb][2] * kLoUnscale, v[mb][3] * kLoUnscale));
+            for (int i = 0; i < 4; ++i) v[nt][mb][i] = relu_f32(acc[nt][mb][i]);
+            hw[2 * mb] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(v[nt][mb][0] * kLoUnscale, v[nt][mb][1] * kLoUnscale));
+            hw[2 * mb + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(v[nt][mb][2] * kLoUnscale, v[nt][mb][3] * kLoUnscale));
           }
-          const f16x8 b2h = __builtin_bit_cast(f16x8, uint4{hw[0], hw[1], hw[2], hw[3]});
+          b2h[nt] = __builtin_bit_cast(f16x8, uint4{hw[0], hw[1], hw[2], hw[3]});
+        }
+#ifndef N16_RESID_VALU
+        f32x4 d[2][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+            d[nt][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sel[mb]), b2h[nt], v[nt][mb], 0, 0, 0);
+#endif
+        const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+            P[nt][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a2H[mb]), b2h[nt], zero4, 0, 0, 0);
+        if (WLO) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+              P[nt][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a2L[mb]), b2h[nt], P[nt][mb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          uint32_t lw[4];
 #pragma unroll
           for (int mb = 0; mb < 2; ++mb) {
-            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sel[mb]), b2h, v[mb], 0, 0, 0);
-            const f16x2 d01 = {(_Float16)d[0], (_Float16)d[1]}, d23 = {(_Float16)d[2], (_Float16)d[3]};
+#ifdef N16_RESID_VALU
+            // the residual on the vector pipe (A/B): v - 2^11 float(hi), exact
+            const f16x8 hh = b2h[nt];
+            f32x4 dd;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dd[i] = __builtin_fmaf((float)hh[4 * mb + i], -kLoScale, v[nt][mb][i]);
+            const f16x2 d01 = {(_Float16)dd[0], (_Float16)dd[1]}, d23 = {(_Float16)dd[2], (_Float16)dd[3]};
+#else
+            const f16x2 d01 = {(_Float16)d[nt][mb][0], (_Float16)d[nt][mb][1]}, d23 = {(_Float16)d[nt][mb][2], (_Float16)d[nt][mb][3]};
+#endif
             lw[2 * mb] = __builtin_bit_cast(uint32_t, d01);
             lw[2 * mb + 1] = __builtin_bit_cast(uint32_t, d23);
           }
-          const f16x8 b2l = __builtin_bit_cast(f16x8, uint4{lw[0], lw[1], lw[2], lw[3]});
-          const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-          for (int mb = 0; mb < 2; ++mb) {
-            f32x4 pp = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a2H[mb]), b2h, zero4, 0, 0, 0);
-            if (WLO) pp = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a2L[mb]), b2h, pp, 0, 0, 0);
-            P[nt][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a2h[mb]), b2l, pp, 0, 0, 0);
-          }
+          b2l[nt] = __builtin_bit_cast(f16x8, uint4{lw[0], lw[1], lw[2], lw[3]});
         }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+            P[nt][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a2h[mb]), b2l[nt], P[nt][mb], 0, 0, 0);
         // conv2's vertical sum: frame tap dt of conv1 row r belongs to output row r + 3 - dt
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -361,7 +416,16 @@ __global__ __launch_bounds__(64 * kN16Waves, 2) void note_march16_kernel(Note16P
       if (++r > r_last) break;
     }
     ring_fence();  // the next piece's prologue overwrites the ring
+#ifdef N16_PROF
+    if (npt < 7) pt[npt++] = __builtin_amdgcn_s_memrealtime();
+#endif
   }
+#ifdef N16_PROF
+  pt[npt++] = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0 && p.n_ws >= 768 && (gw < 8 || gw == 1003 || gw == 1006 || gw == 2040 || gw == 2047))
+    printf("N16P gw %d block %d t0 %llu setup %llu | %llu %llu %llu %llu | end %llu\n", gw, (int)blockIdx.x, pt[0] % 100000000ull, pt[1] - pt[0],
+           npt > 3 ? pt[2] - pt[0] : 0ull, npt > 3 ? pt[3] - pt[0] : 0ull, npt > 5 ? pt[4] - pt[0] : 0ull, npt > 5 ? pt[5] - pt[0] : 0ull, pt[npt - 1] - pt[0]);
+#endif
 }
 
 void launch_note_march16(const float* contour, const void* wfrag, const float* wf32, float* note, int n_windows, int n_cu,
@@ -372,7 +436,7 @@ void launch_note_march16(const float* contour, const void* wfrag, const float* w
   constexpr int kMinFrames = 12;
   const int64_t waves = ((int64_t)p.n_ws * kFrames + kMinFrames - 1) / kMinFrames;
   int grid = (int)((waves + kN16Waves - 1) / kN16Waves);
-  if (grid > 2 * n_cu) grid = 2 * n_cu;
+  if (grid > kN16Occ * n_cu) grid = kN16Occ * n_cu;
   if (weights_have_lo)
     hipLaunchKernelGGL(note_march16_kernel<true>, dim3(grid), dim3(64 * kN16Waves), 0, stream, p);
   else
