@@ -26,7 +26,6 @@ SOURCES = [
     "conv_contour_rim_march.hip",
     "conv_contour_march.hip",
     "conv_contour2.hip",
-    "conv_contour_fold_mx.hip",
     "conv_stride3.hip",
     "conv_heads.hip",
     "conv_branch.hip",
@@ -45,6 +44,7 @@ AB_SOURCES = [
     "conv_contour_direct.hip",  # exact 8-channel conv1 (BP_RIM=exact, BP_CONV1=full), round-2 folded conv1 (BP_CONV1=rounds)
     "onset_march.hip",          # onset march on 32x32x16 (BP_ONSET=march32)
     "note_march.hip",           # note march on 32x32x16 (BP_NOTE=march32)
+    "conv_contour_fold_mx.hip", # contour conv1 of the fp8-corrections mode (BP_FLAG_FP8_CORRECTIONS: A/B library only since round 6)
 ]
 AB_LIB_PATH = os.path.join(LIB_DIR, "libbasicpitch_amd_ab.so")
 

@@ -91,8 +91,10 @@ void launch_onset_march(const uint32_t* zp, const float* note, const void* wfrag
 #endif
 void launch_onset_march16(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, float* onset,
                           int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
+#ifdef BP_AB_KERNELS  // conv_contour_fold_mx.hip: the fp8-correction mode's contour conv1 (A/B builds only since round 6)
 void launch_contour_conv1_fold_mx(const uint32_t* zp, const void* a16, const void* amx, const void* ascale,
                                   const float* bias, float* c1, int n_windows, int n_cu, hipStream_t stream);
+#endif
 void launch_contour_conv2(const float* c1, const float* w2, float bias, float* contour, int n_windows, int n_cu,
                           hipStream_t stream);
 #ifdef BP_AB_KERNELS  // note_march.hip: the 32x32x16 form of the note march (A/B builds only)
@@ -108,10 +110,12 @@ void launch_note_export(const void* note, void* note_dst, int64_t note_bytes, co
                         int64_t bits_bytes, const void* bend, void* bend_dst, int64_t bend_bytes, void* stats,
                         void* stats_dst, hipStream_t s);
 void launch_note_stats_init(void* stats, hipStream_t s);
+#ifdef BP_AB_KERNELS
 void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, const void* wmx,
                          float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream);
-// the onset branch: the wave-private march on 16x16x32; the workgroup kernel for the fp8-correction mode (it carries the
-// block-scaled products).  A/B builds only: BP_ONSET=march32 selects the 32x32x16 form of the march, BP_ONSET=ring the
+#endif
+// the onset branch: the wave-private march on 16x16x32.  A/B builds only: the workgroup kernel for the fp8-correction
+// mode (it carries the block-scaled products), BP_ONSET=march32 selects the 32x32x16 form of the march, BP_ONSET=ring the
 // workgroup kernel without fp8.
 static void launch_onset(const uint32_t* zp, const float* note, const void* wfrag, const float* wf32, const void* wmx,
                          const void* w16, float* onset, int n_windows, int n_cu, bool weights_have_lo, hipStream_t stream) {
@@ -126,11 +130,13 @@ static void launch_onset(const uint32_t* zp, const float* note, const void* wfra
     launch_onset_march(zp, note, wfrag, wf32, onset, n_windows, n_cu, weights_have_lo, stream);
     return;
   }
-#endif
-  if (wmx || kind == 2)
+  if (wmx || kind == 2) {
     launch_onset_branch(zp, note, wfrag, wf32, wmx, onset, n_windows, n_cu, weights_have_lo, stream);
-  else
-    launch_onset_march16(zp, note, w16, wf32, onset, n_windows, n_cu, weights_have_lo, stream);
+    return;
+  }
+#endif
+  (void)wfrag, (void)wmx, (void)kind;
+  launch_onset_march16(zp, note, w16, wf32, onset, n_windows, n_cu, weights_have_lo, stream);
 }
 // the note branch: the wave-private march on 16x16x32 (round 6).  A/B builds only: BP_NOTE=march32 selects the 32x32x16 form.
 static void launch_note(const float* contour, const void* wfrag, const void* w16, const float* wf32, float* note, int n_windows,
@@ -1023,17 +1029,16 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
       if (!contour_conv1_full()) {
         BP_MARK(BP_STAGE_CONTOUR_CONV1_EDGE);
         BP_DOM_BEGIN();
+#ifdef BP_AB_KERNELS
         if (h->fold_mx && wlo) {
           const char* base = reinterpret_cast<const char*>(h->d_d1_wfold_mx);
           launch_contour_conv1_fold_mx(zpp, base, base + 36 * 64 * 16, base + 36 * 64 * 16 + 18 * 64 * 32, h->d_d1_bias, c1p,
                                        nw, h->n_cu, s);
-#ifdef BP_AB_KERNELS
         } else if (!contour_conv1_use_march()) {
           launch_contour_conv1_folded(zpp, h->d_d1_wfold, h->d_d1_bias, c1p, nw, h->n_cu, wlo, s);
+        } else
 #endif
-        } else {
           launch_contour_conv1_march(zpp, h->d_d1_wmarch, h->d_d1_bias, c1p, nw, h->n_cu, wlo, s);
-        }
       }
       BP_DOM_END(BP_STAGE_CONTOUR_CONV1);
       BP_MARK(BP_STAGE_CONTOUR_CONV1);
@@ -1237,6 +1242,7 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       pack_contour_rim_march(c1w, frag);
       if ((rc = upload(h, raw_of(frag), &h->d_d1_wrimm))) return fail(rc);
     }
+#ifdef BP_AB_KERNELS
     // folded conv1: all three split-precision products on f16 by default (fp32-class); BP_FLAG_FP8_CORRECTIONS opts into
     // the block-scaled fp8 corrections (conv_contour_fold_mx.hip; ~1e-5 on the contour map), BP_CONV1=f16 then keeps this
     // one layer on the three-product f16 kernel (A/B runs).
@@ -1256,6 +1262,16 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       if ((rc = upload(h, raw, &h->d_d1_wfold_mx))) return fail(rc);
       h->fold_mx = true;
     }
+#else
+    // the reduced-precision fp8-corrections mode left the product library in round 6 (not faster than the default any more,
+    // narrower than the config's fp32): its kernels are built into the A/B library only
+    const bool fp8_ok = false;
+    if ((flags & BP_FLAG_FP8_CORRECTIONS) && !(flags & BP_FLAG_F16_CORRECTIONS)) {
+      h->err = "bp_create: BP_FLAG_FP8_CORRECTIONS is built into the A/B library only (basic_pitch_amd.build.build_library(ab=True), "
+               "BASIC_PITCH_AMD_LIB); the product library computes all three split-precision products on f16";
+      return fail(BP_ERR_INVALID_ARG);
+    }
+#endif
     if (const char* ep = ab_env("BP_CONTOUR_PARTS")) h->contour_parts = std::atoi(ep) > 8 ? 8 : std::atoi(ep);
     {
       const char* er = ab_env("BP_RIM");  // "exact": the round-1 rim kernel on the 8-channel form (A/B runs)
@@ -1265,16 +1281,17 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
     if (const char* es = ab_env("BP_RESAMPLE"))  // A/B runs: the resampler's simpler kernels (bit-identical results)
       h->resample_mode = std::strcmp(es, "plain") == 0 ? 1 : std::strcmp(es, "tiled") == 0 ? 2 : 0;
     for (int br = 0; br < 2; ++br) {
-      pack_branch(br ? 13 : 4, br ? o1w : n1w, br ? o2w : n2w, br == 1, frag);
       std::vector<float> f32(42, 0.f);
       const Tensor* b1 = br ? o1b : n1b;
       for (int i = 0; i < 32; ++i) f32[i] = b1->data[i];
       if (br)
         for (int i = 0; i < 9; ++i) f32[32 + i] = o2w->data[i];  // onset2 taps of concat channel 0 (the note map)
       f32[41] = br ? o2b->data[0] : n2b->data[0];
-      if ((rc = upload(h, raw_of(frag), br ? &h->d_onset_wfrag : &h->d_note_wfrag)) ||
-          (rc = upload(h, f32, br ? &h->d_onset_wf32 : &h->d_note_wf32)))
-        return fail(rc);
+#ifdef BP_AB_KERNELS  // the 32x32x16 kernels' fragments (note_march.hip, onset_march.hip, conv_branch.hip)
+      pack_branch(br ? 13 : 4, br ? o1w : n1w, br ? o2w : n2w, br == 1, frag);
+      if ((rc = upload(h, raw_of(frag), br ? &h->d_onset_wfrag : &h->d_note_wfrag))) return fail(rc);
+#endif
+      if ((rc = upload(h, f32, br ? &h->d_onset_wf32 : &h->d_note_wf32))) return fail(rc);
     }
     {  // the note march on 16x16x32 (the default): its own fragment order, the hi parts also at scale 2^11
       if (!pack_note16(n1w, n2w, frag)) {
@@ -1287,6 +1304,7 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       pack_onset16(o1w, o2w, frag);
       if ((rc = upload(h, raw_of(frag), &h->d_onset_w16))) return fail(rc);
     }
+#ifdef BP_AB_KERNELS
     // onset conv1: fp8 corrections under BP_FLAG_FP8_CORRECTIONS like the folded contour conv1 (BP_ONSET=f16: not this layer)
     if (const char* eo = ab_env("BP_ONSET"); !(eo && std::strcmp(eo, "f16") == 0) && fp8_ok && !(flags & BP_FLAG_BF16_WEIGHTS)) {
       std::vector<uint8_t> mxf;
@@ -1297,6 +1315,9 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       std::memcpy(raw.data() + mxf.size() / 4, mxs.data(), mxs.size() * 4);
       if ((rc = upload(h, raw, &h->d_onset_wmx))) return fail(rc);
     }
+#else
+    (void)fp8_ok;
+#endif
   }
   pack_contour1(c1w, c1f);
   pack_onset1(o1w, o1f);
@@ -2087,17 +2108,16 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
           else
 #endif
             launch_rim(h, bf->zp, h->c1s, n, wlo, s);
+#ifdef BP_AB_KERNELS
           if (h->fold_mx && wlo) {
             const char* base = reinterpret_cast<const char*>(h->d_d1_wfold_mx);
             launch_contour_conv1_fold_mx(bf->zp, base, base + 36 * 64 * 16, base + 36 * 64 * 16 + 18 * 64 * 32, h->d_d1_bias,
                                          h->c1s, n, h->n_cu, s);
-#ifdef BP_AB_KERNELS
           } else if (!contour_conv1_use_march()) {
             launch_contour_conv1_folded(bf->zp, h->d_d1_wfold, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
+          } else
 #endif
-          } else {
             launch_contour_conv1_march(bf->zp, h->d_d1_wmarch, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
-          }
           launch_contour_conv2(h->c1s, h->d_d2_w, h->b_contour2, bf->contour, n, h->n_cu, s);
         }
       }

@@ -43,6 +43,12 @@ namespace bp {
 
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)((v - (float)hi) * kLoScale);
+}
+
+#ifdef BP_AB_KERNELS  // the workgroup branch kernel (BP_ONSET=ring) and its fp8-correction variant (BP_FLAG_FP8_CORRECTIONS): A/B library only since round 6
 constexpr int kBrThreads = 256;
 constexpr int kBrRows = 4;                               // conv1 rows per phase
 constexpr int kBrTilesPerRow = 3;                        // 32-pixel tiles, 30 inner pixels each
@@ -85,10 +91,6 @@ struct OnsetBr {
   static __device__ __forceinline__ int lane_slot(int wc) { return 3 * wc; }  // bin 3w+dw-1 -> slot 3w+dw
 };
 
-__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
-  hi = (_Float16)v;
-  lo = (_Float16)((v - (float)hi) * kLoScale);
-}
 
 // ---- fp8 planes of the MX variant (the correction products lo_w a + hi_w lo_a of conv1 on
 // v_mfma_scale_f32_32x32x64_f8f6f4, see conv_contour_fold_mx.hip): a slot of the second image then holds
@@ -569,6 +571,7 @@ __global__ __launch_bounds__(kBrThreads, Br::WGS) void branch_kernel(BranchParam
   }
 #undef BR_STAMP
 }
+#endif  // BP_AB_KERNELS
 
 // ---- z pack: NormalizedLog tail + BatchNorm affine, stored pre-split as (f16 hi | f16 lo << 16) ----
 // (signal.py:177-183, models.py:187-189).  One pass over lp; consumers gather these words straight
@@ -640,6 +643,7 @@ void launch_zpack_partials(const float* lp, const float* scratch, int n_partials
                      reinterpret_cast<const float2*>(scratch), n_partials, zp, kc, n_bins);
 }
 
+#ifdef BP_AB_KERNELS
 template <class Br>
 static void launch_branch(const BranchParams& p, int n_cu, bool weights_have_lo, hipStream_t stream) {
   const int items = p.n_windows * Br::CHUNKS;
@@ -675,12 +679,10 @@ static void launch_branch(const BranchParams& p, int n_cu, bool weights_have_lo,
       return;
     }
   }
-#ifdef BP_AB_KERNELS  // the workgroup kernel without the fp8 products: only BP_ONSET=ring reaches it (A/B builds)
   if (weights_have_lo)
     hipLaunchKernelGGL((branch_kernel<Br, true>), dim3(grid), dim3(kBrThreads), 0, stream, p);
   else
     hipLaunchKernelGGL((branch_kernel<Br, false>), dim3(grid), dim3(kBrThreads), 0, stream, p);
-#endif
 }
 
 // wmx: the fp8 correction fragments (pack_onset_mx) or null for the three-product f16 kernel
@@ -690,5 +692,6 @@ void launch_onset_branch(const uint32_t* zp, const float* note, const void* wfra
                  static_cast<const uint4*>(wmx)};
   launch_branch<OnsetBr>(p, n_cu, weights_have_lo, stream);
 }
+#endif  // BP_AB_KERNELS
 
 }  // namespace bp

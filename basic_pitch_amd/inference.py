@@ -97,7 +97,7 @@ class Model:
             flags |= _native.BP_FLAG_EXT_CQT_44K
         if f16_corrections:  # the default arithmetic since round 3 (all three split-precision products on f16): a no-op
             flags |= _native.BP_FLAG_F16_CORRECTIONS
-        if fp8_corrections:  # opt-in reduced precision: contour / onset conv1 corrections on block-scaled fp8 MFMA
+        if fp8_corrections:  # A/B library only since round 6 (the product library refuses the flag: ValueError)
             flags |= _native.BP_FLAG_FP8_CORRECTIONS
         if blocking_wait:  # whole-track calls sleep on an interrupt instead of spinning (file jobs: workers share cores)
             flags |= _native.BP_FLAG_BLOCKING_WAIT
@@ -547,6 +547,86 @@ def run_inference_windowed(
         k: unwrap_output(np.concatenate(output[k]), audio_original_length, n_overlapping_frames, hop_size)
         for k in output
     }
+
+
+def predict_window_range(
+    audio_path: Union[pathlib.Path, str],
+    model_or_model_path: Union[Model, pathlib.Path, str],
+    piece: int,
+    n_pieces: int,
+) -> Dict[str, Any]:
+    """Piece `piece` of `n_pieces` of ONE long file (the window-range fallback of the file-sharded job).
+
+    A window's samples are determined by its index alone (start = w * 36164 - 3840: inference.py:207,242) and a window's 142
+    un-overlapped rows by the window alone (per-window normalisation, signal.py:177-183), so a rank can compute windows
+    [w0, w1) = `sharding.split_windows(n_windows, n_pieces)[piece]` without any of its neighbours' data: the file is decoded
+    and resampled (on the device, by the same kernel the whole-file call uses), this range's windows are cut on the host
+    exactly as `window_audio_file` cuts them and go through `Model.predict` in full batches; `assemble_window_ranges`
+    concatenates the pieces' rows — the same bits the unsplit call produces (the library's results do not depend on how
+    windows are batched: tests/test_gpu_parity.py::test_batch_invariance_and_chunking)."""
+    from .sharding import split_windows
+
+    model = _model_from(model_or_model_path)
+    verify_input_path(audio_path)
+    pcm, file_sr = _audio.read_audio(str(audio_path))
+    y = np.ascontiguousarray(model.resample(pcm, file_sr), dtype=np.float32)
+    n_overlapping_frames = DEFAULT_OVERLAPPING_FRAMES
+    overlap_len = n_overlapping_frames * FFT_HOP
+    hop_size = AUDIO_N_SAMPLES - overlap_len
+    n_olap = n_overlapping_frames // 2
+    padded = np.concatenate([np.zeros((overlap_len // 2,), dtype=np.float32), y])
+    n_windows = len(range(0, padded.shape[0], hop_size))
+    w0, w1 = split_windows(n_windows, n_pieces)[piece]
+    rows: Dict[str, List[np.ndarray]] = {"note": [], "onset": [], "contour": []}
+    batch = int(getattr(model, "max_windows", 256))
+    for a in range(w0, w1, batch):
+        b = min(w1, a + batch)
+        x = np.zeros((b - a, AUDIO_N_SAMPLES), dtype=np.float32)
+        for w in range(a, b):
+            seg = padded[w * hop_size : w * hop_size + AUDIO_N_SAMPLES]
+            x[w - a, : len(seg)] = seg
+        for k, v in model.predict(x).items():
+            if k in rows:
+                v = np.asarray(v)[:, n_olap:-n_olap, :]
+                rows[k].append(v.reshape(v.shape[0] * v.shape[1], v.shape[2]))
+    width = {"note": 88, "onset": 88, "contour": 264}
+    return {"rows": {k: (np.concatenate(v) if v else np.zeros((0, width[k]), np.float32)) for k, v in rows.items()},
+            "range": (w0, w1), "n_windows": n_windows, "original_length": int(y.shape[0])}
+
+
+def assemble_window_ranges(
+    parts: Sequence[Dict[str, Any]],
+    onset_threshold: float = DEFAULT_ONSET_THRESHOLD,
+    frame_threshold: float = DEFAULT_FRAME_THRESHOLD,
+    minimum_note_length: float = DEFAULT_MINIMUM_NOTE_LENGTH_MS,
+    minimum_frequency: Optional[float] = None,
+    maximum_frequency: Optional[float] = None,
+    multiple_pitch_bends: bool = False,
+    melodia_trick: bool = True,
+    midi_tempo: float = DEFAULT_MINIMUM_MIDI_TEMPO,
+    **_ignored: Any,
+) -> Tuple[Dict[str, np.ndarray], "infer.pretty_midi.PrettyMIDI", List["infer.NoteEvent"]]:
+    """The pieces of `predict_window_range` back into what `predict()` returns for the file: rows concatenated in window
+    order, trimmed to int(L / hop * 142) (`unwrap_output`, inference.py:277-279), notes decoded over the WHOLE file (a note
+    may span pieces)."""
+    parts = sorted(parts, key=lambda p: p["range"][0])
+    at = 0
+    for p in parts:
+        if p["range"][0] != at:
+            raise ValueError(f"window ranges do not tile the file: expected a piece starting at window {at}, got {p['range']}")
+        at = p["range"][1]
+    if not parts or at != parts[0]["n_windows"]:
+        raise ValueError("window ranges do not cover the file")
+    hop_size = AUDIO_N_SAMPLES - DEFAULT_OVERLAPPING_FRAMES * FFT_HOP
+    n_rows = int(parts[0]["original_length"] / hop_size * (AUDIO_WINDOW_LENGTH * ANNOTATIONS_FPS - DEFAULT_OVERLAPPING_FRAMES))
+    model_output = {k: np.ascontiguousarray(np.concatenate([p["rows"][k] for p in parts])[:n_rows]) for k in ("note", "onset", "contour")}
+    min_note_len = int(np.round(minimum_note_length / 1000 * (AUDIO_SAMPLE_RATE / FFT_HOP)))
+    midi_data, note_events = infer.model_output_to_notes(
+        model_output, onset_thresh=onset_threshold, frame_thresh=frame_threshold, min_note_len=min_note_len,
+        min_freq=minimum_frequency, max_freq=maximum_frequency, multiple_pitch_bends=multiple_pitch_bends,
+        melodia_trick=melodia_trick, midi_tempo=midi_tempo,
+    )
+    return model_output, midi_data, note_events
 
 
 class OutputExtensions(enum.Enum):

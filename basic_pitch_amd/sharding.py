@@ -75,6 +75,31 @@ def split_windows(n_windows: int, world_size: int) -> List[Tuple[int, int]]:
     return out
 
 
+def plan_units(costs: Sequence[float], world_size: int) -> Tuple[List[Tuple[int, int, int]], List[List[int]]]:
+    """The plan of a file-sharded job with the window-range fallback: work units `(file, piece, n_pieces)`
+    and, per rank, the indices of its units (LPT over the units' costs; deterministic on every rank).
+
+    A file is one unit — unless it alone outweighs an even share of the job (cost > total / world_size): no assignment of
+    whole files can balance it, so it is cut into n_pieces = min(world_size, ceil(cost / share)) contiguous window ranges of
+    equal cost (`split_windows`; a window needs nothing from its neighbours).  With world_size 1, or when no file is that
+    heavy, the units are the files and the plan is `plan_shards`'s."""
+    if world_size <= 0:
+        raise ValueError("world_size must be positive")
+    total = sum(float(c) for c in costs)
+    share = total / world_size
+    units: List[Tuple[int, int, int]] = []
+    unit_costs: List[float] = []
+    for i, c in enumerate(costs):
+        c = float(c)
+        k = 1
+        if world_size > 1 and share > 0 and c > share:
+            k = min(world_size, int(-(-c // share)))
+        for j in range(k):
+            units.append((i, j, k))
+            unit_costs.append(c / k)
+    return units, plan_shards(unit_costs, world_size)
+
+
 def run_sharded(
     items: Sequence[Any],
     costs: Sequence[float],
@@ -137,11 +162,13 @@ def _file_costs(paths: Sequence[Any]) -> List[float]:
 
 
 def _predict_shard(paths: Sequence[Any], indices: Sequence[int], device: int, model_or_model_path: Any,
-                   model_factory: Optional[Callable[[int], Any]], kwargs: Dict[str, Any]) -> Dict[int, Any]:
-    """One rank's share: a Model on its own GPU, `predict_many` over its files, {input index: result or exception}."""
+                   model_factory: Optional[Callable[[int], Any]], kwargs: Dict[str, Any],
+                   pieces: Sequence[Tuple[int, int, int]] = ()) -> Dict[Any, Any]:
+    """One rank's share: a Model on its own GPU, `predict_many` over its whole files -> {input index: result or
+    exception}, and `predict_window_range` for its pieces of split files -> {(index, piece, n_pieces): rows or exception}."""
     from . import inference
 
-    if not indices:
+    if not indices and not pieces:
         return {}
     if model_factory is not None:
         model = model_factory(device)
@@ -149,8 +176,49 @@ def _predict_shard(paths: Sequence[Any], indices: Sequence[int], device: int, mo
         model = model_or_model_path
     else:
         model = inference.Model(model_or_model_path, device=device)
-    res = inference.predict_many([paths[i] for i in indices], model, return_exceptions=True, **kwargs)
-    return dict(zip(indices, res))
+    out: Dict[Any, Any] = {}
+    if indices:
+        res = inference.predict_many([paths[i] for i in indices], model, return_exceptions=True, **kwargs)
+        out.update(zip(indices, res))
+    for i, j, k in pieces:
+        try:
+            out[(i, j, k)] = inference.predict_window_range(paths[i], model, j, k)
+        except Exception as e:  # per-file isolation, like the whole files'
+            out[(i, j, k)] = e
+    return out
+
+
+def _units_of_rank(paths: Sequence[Any], world: int, rank: int) -> Tuple[List[int], List[Tuple[int, int, int]]]:
+    units, shards = plan_units(_file_costs(paths), world)
+    mine = [units[u] for u in shards[rank]]
+    return [i for i, j, k in mine if k == 1], [(i, j, k) for i, j, k in mine if k > 1]
+
+
+def _merge_units(merged: Dict[Any, Any], n_files: int, kwargs: Dict[str, Any]) -> List[Any]:
+    """Per-file results in input order: whole files as they are, split files assembled from their pieces (the first piece's
+    exception stands for the file: a file that cannot be read fails on every rank that touched it)."""
+    from . import inference
+
+    split: Dict[int, List[Any]] = {}
+    for key, val in merged.items():
+        if isinstance(key, tuple):
+            split.setdefault(key[0], []).append((key[1], val))
+    decode_kw = {k: v for k, v in kwargs.items() if k not in ("group", "decode_threads", "return_exceptions")}
+    out: List[Any] = []
+    for i in range(n_files):
+        if i in split:
+            parts = [v for _, v in sorted(split[i], key=lambda t: t[0])]
+            bad = [v for v in parts if isinstance(v, BaseException)]
+            if bad:
+                out.append(bad[0])
+                continue
+            try:
+                out.append(inference.assemble_window_ranges(parts, **decode_kw))
+            except Exception as e:
+                out.append(e)
+        else:
+            out.append(merged[i])
+    return out
 
 
 def _post(queue, rank: int, produce: Callable[[], Any]) -> None:
@@ -212,8 +280,8 @@ def _collect(procs, queue, what: str, poll_s: float = 0.5) -> Dict[int, Any]:
 
 def _spawned_worker(rank: int, world: int, device: int, paths, model_path, model_factory, kwargs, queue) -> None:
     def produce():
-        shards = plan_shards(_file_costs(paths), world)
-        return _predict_shard(paths, shards[rank], device, model_path, model_factory, kwargs)
+        files, pieces = _units_of_rank(paths, world, rank)
+        return _predict_shard(paths, files, device, model_path, model_factory, kwargs, pieces)
 
     _post(queue, rank, produce)
 
@@ -230,8 +298,12 @@ def predict_many_sharded(
 
     Returns, in input order, the `(model_output, midi_data, note_events)` tuple of each file — or the exception that
     file raised (per-file isolation, like the try / except of inference.py:548-604) — identical to what
-    `predict_many` returns on one GPU.  Files are assigned by the LPT plan over their sizes (`plan_shards`), every
+    `predict_many` returns on one GPU.  Files are assigned by the LPT plan over their sizes (`plan_units`), every
     rank owns a `Model` on its own GPU and nothing but finished per-file results crosses rank boundaries (host side).
+    A file that alone outweighs an even share of the job (one very long recording among short ones, or a job of one file)
+    is cut into window ranges (`split_windows`), one per rank that takes a piece: every piece's rank decodes the file and
+    computes its own windows (`inference.predict_window_range`), rank 0 / the parent concatenates the rows and decodes the
+    notes over the whole file (`inference.assemble_window_ranges`) — bit-identical to the unsplit result.
 
       * inside a `torch.distributed` job (launched one rank per GPU): every rank calls this with the same list; the
         rank's GPU is LOCAL_RANK; results are gathered with `gather_object` and returned on rank 0 (None elsewhere);
@@ -260,17 +332,17 @@ def predict_many_sharded(
         pass
     if dist is not None:
         rank, world = dist.get_rank(), dist.get_world_size()
-        shards = plan_shards(_file_costs(paths), world)
+        files, pieces = _units_of_rank(paths, world, rank)
         device = int(os.environ.get("LOCAL_RANK", rank))
-        mine = _predict_shard(paths, shards[rank], device, model_or_model_path, model_factory, predict_kwargs)
+        mine = _predict_shard(paths, files, device, model_or_model_path, model_factory, predict_kwargs, pieces)
         bucket: Optional[List[Any]] = [None] * world if rank == 0 else None
         dist.gather_object(mine, bucket, dst=0)
         if rank != 0:
             return None
-        merged: Dict[int, Any] = {}
+        merged: Dict[Any, Any] = {}
         for part in bucket or []:
             merged.update(part or {})
-        return [merged[i] for i in range(len(paths))]
+        return _merge_units(merged, len(paths), predict_kwargs)
 
     if gpus is None:
         import torch
@@ -294,7 +366,7 @@ def predict_many_sharded(
     for p in procs:
         p.start()
     merged = _collect(procs, queue, "predict_many_sharded")
-    return [merged[i] for i in range(len(paths))]
+    return _merge_units(merged, len(paths), predict_kwargs)
 
 
 def _save_shard(paths: Sequence[Any], indices: Sequence[int], device: int, model_or_model_path: Any,

@@ -45,10 +45,6 @@ F16_MFMA_PEAK_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense f16/bf16 m
 # MFMAs (hi*hi, lo*hi, hi*lo).  BP_CONV1=full: the exact kernel over all 66 groups, 45 rounds x 8 waves x 63 x 3.
 F1_SHARE = 56.0 / 66.0
 F1_EXECUTED_FLOP_PER_WINDOW = 38 * 8 * 36 * 3 * (2 * 32 * 32 * 16)
-# contour_conv1_fold_mx_kernel (conv_contour_fold_mx.hip, the default): same tiling, per tile 36 f16 MFMAs (hi*hi) + 18
-# block-scaled fp8 32x32x64 MFMAs (lo*hi and hi*lo of 32 taps each).  Counted in f16-equivalent FLOPs = matrix-pipe time:
-# the fp8 instruction does 4x the MACs of the f16 one in 2x its cycles, so its FLOPs count half.
-FX_EXECUTED_FLOP_PER_WINDOW = 38 * 8 * (36 * (2 * 32 * 32 * 16) + 18 * (2 * 32 * 32 * 64) // 2)
 F1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 224 * 8 * 4  # zp read + interior c1 written
 # contour_conv1_march_kernel (conv_contour_march.hip, the default since round 4): 7 strips of 32 bins x 4 frame chunks per
 # window; a chunk of 43 frames marches over 45 z rows (2 rows of warm-up), 54 v_mfma_f32_16x16x32_f16 per row (3 frame taps
@@ -59,9 +55,6 @@ D1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 264 * 8 * 4  # zp read + c1 written
 HBM_PEAK_GBS = 8000.0
 DTYPE_F16 = "f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands, all three products of every layer on f16 MFMA"
 DTYPE_DEFAULT = DTYPE_F16  # since round 3 the default IS the all-f16 split (fp32-class)
-DTYPE_FP8 = ("f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands; OPT-IN reduced precision (--fp8-corrections): contour "
-             "conv1 interior and onset conv1 issue hi*hi on f16 and the two correction products (<= 2^-11 of a product) on "
-             "block-scaled fp8 MFMA")
 PMC_PROFILE = "r05_e"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
 
 
@@ -143,7 +136,7 @@ def run_tracks(args, torch, dist, world, rank, local_rank) -> None:
     lengths = [int(base * (1.0 - 0.02 * rng.random())) for _ in range(args.tracks)]
     shards = plan_shards(lengths, world)
     mine = shards[rank]
-    model = Model(device=local_rank, max_windows=256, fp8_corrections=args.fp8_corrections)
+    model = Model(device=local_rank, max_windows=256)
     lib = model._lib
     g = torch.Generator(device=dev)
     g.manual_seed(99 + rank)
@@ -184,7 +177,7 @@ def run_tracks(args, torch, dist, world, rank, local_rank) -> None:
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": DTYPE_FP8 if args.fp8_corrections else DTYPE_DEFAULT,
+            "dtype": DTYPE_DEFAULT,
             "data": "synthetic",
             "config": {
                 "workload": f"{args.tracks} synthetic 3-minute tracks (110 windows each) through bp_infer_tracks (64 tracks per call), "
@@ -202,7 +195,7 @@ def run_files(args, torch=None, dist=None, world: int = 1, rank: int = 0, local_
     resampling, CQT + CNN, D2H of what note decoding needs and note decoding on host threads are all inside the timed
     region): `--files` synthetic 16-bit stereo 44.1 kHz WAV files of `--file-seconds` each in a temporary directory.
     Reports files/s and audio-seconds per second.  With `--gpus N --native` (BASELINE.json configs[2] as a FILE job) the
-    files are sharded over the ranks (file i -> rank i mod N: the files are equally long; no collective on the data path),
+    files are sharded over the ranks by the product's own plan (`sharding.plan_shards`: LPT over the files' sizes; no collective on the data path),
     every rank runs the native pipeline on its own GPU with its share of the host cores, the timed region is bracketed by
     barriers and closed by the slowest rank; rank 0 reports the whole-job rate, the per-rank rates and their imbalance."""
     import tempfile
@@ -213,7 +206,11 @@ def run_files(args, torch=None, dist=None, world: int = 1, rank: int = 0, local_
     if world > 1 and not args.native:
         raise SystemExit("--workload files on several GPUs runs the native pipeline: add --native")
     total_files = args.files
-    mine = list(range(rank, total_files, world))
+    from basic_pitch_amd.sharding import plan_shards
+
+    # the product's plan (what predict_and_save_sharded computes from os.path.getsize): the synthetic files are equally long
+    file_bytes = 44 + int(args.file_seconds * 44100) * 4
+    mine = plan_shards([float(file_bytes)] * total_files, world)[rank]
     args.files = len(mine)
     rng = np.random.default_rng(7 + rank)
     n = int(args.file_seconds * 44100)
@@ -354,9 +351,10 @@ def pmc_step_traffic(batch: int):
             "source": "profiles/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % PMC_PROFILE}
 
 
-def config_extras(torch, local_rank: int, steps: int = 4) -> dict:
-    """The other BASELINE.json configs and the reference's own call pattern, a few steps each, AFTER the timed region
-    (rank 0 only): beside `value`, never instead of it.  Every entry: windows/s and ms per step (per call)."""
+def config_extras(torch, local_rank: int, steps: int = 12) -> dict:
+    """The other BASELINE.json configs and the reference's own call pattern, AFTER the timed region (rank 0 only, the GPU
+    still warm from it): beside `value`, never instead of it.  Every entry: 3 warm-up steps, then >= 10 timed steps
+    (round 5 timed 4 steps behind 2: B = 1024 read slower than B = 256 there); windows/s and ms per step (per call)."""
     from basic_pitch_amd.inference import Model
 
     dev = torch.device("cuda", local_rank)
@@ -370,7 +368,7 @@ def config_extras(torch, local_rank: int, steps: int = 4) -> dict:
         o = {"note": torch.empty((B, 172, 88), device=dev), "onset": torch.empty((B, 172, 88), device=dev),
              "contour": torch.empty((B, 172, 264), device=dev)}
         m = Model(device=local_rank, max_windows=B, **kw)
-        for _ in range(2):
+        for _ in range(3):
             m._predict_device(audio, out=o, sync=False)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -379,7 +377,7 @@ def config_extras(torch, local_rank: int, steps: int = 4) -> dict:
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         m.close()
-        out[key] = {"windows_per_s": B * steps / el, "ms_per_step": el / steps * 1e3, "batch": B, "steps": steps,
+        out[key] = {"windows_per_s": B * steps / el, "ms_per_step": el / steps * 1e3, "batch": B, "steps": steps, "warmup": 3,
                     "config": note}
         del audio, o
 
@@ -463,10 +461,8 @@ def main() -> None:
                     "--batch 512); not the headline line")
     ap.add_argument("--f16-corrections", action="store_true",
                     help="accepted for compatibility: all three split-precision products on f16 MFMA is the default since round 3")
-    ap.add_argument("--fp8-corrections", action="store_true",
-                    help="BP_FLAG_FP8_CORRECTIONS (opt-in, reduced precision): the contour / onset conv1 corrections on "
-                         "block-scaled fp8 MFMA; not the headline line")
-    ap.add_argument("--no-fp8-extra", action="store_true", help="skip the extra fp8-corrections rate (profiling runs)")
+    ap.add_argument("--no-fp8-extra", action="store_true",
+                    help="accepted and ignored (the fp8-corrections mode left the product library in round 6; old tool scripts pass it)")
     ap.add_argument("--no-config-extras", action="store_true",
                     help="skip the side rates of the other BASELINE.json configs and of the batch-1 host seam (profiling runs)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -562,8 +558,7 @@ def main() -> None:
     # full per-stage table costs 16 event records = ~25 us (2.6 %) per step and comes from a second, untimed pass.
     # The exact-f32 A/B path has no dominant-only mode: it is timed with the full set.
     model = Model(device=local_rank, max_windows=B, stage_timing=args.exact_f32, time_dominant=not args.exact_f32,
-                  exact_f32_mfma=args.exact_f32, bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k,
-                  fp8_corrections=args.fp8_corrections)
+                  exact_f32_mfma=args.exact_f32, bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k)
 
     def step():
         model._predict_device(audio, out=out, sync=False)
@@ -574,10 +569,32 @@ def main() -> None:
     # sustained), so the W warm-up + K timed steps below start right behind two seconds of the same work, on a GPU in the
     # state a batch job keeps it in.
     extras = {}
+    # `value_cold`: the contract's W warm-up + K timed steps started on an idle GPU, as rounds 1 - 4 measured `value` — run
+    # FIRST, on a handle of its own, so that both protocols are on every line and a round-to-round difference can be told
+    # from a protocol difference.  `value` itself is measured behind the sustained pass since round 5.
+    if not args.exact_f32 and args.sustained_s > 0:
+        cold_model = Model(device=local_rank, max_windows=B, bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k)
+        for _ in range(args.warmup):
+            cold_model._predict_device(audio, out=out, sync=False)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            cold_model._predict_device(audio, out=out, sync=False)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t_cold = reduce_over_ranks(time.perf_counter() - t0, dist.ReduceOp.MAX)
+        cold_model.close()
+        extras["value_cold"] = B * args.steps * world / t_cold
+        extras["ms_per_step_cold"] = t_cold / args.steps * 1e3
+        extras["value_note"] = ("`value` / `ms_per_step`: W warm-up + K timed steps run directly behind `sustained` (>= 2 s of the "
+                                "same step; since round 5).  `value_cold` / `ms_per_step_cold`: the same W + K steps started on "
+                                "an idle GPU before anything else ran (the protocol of rounds 1 - 4)")
     sus_model = None
     if not args.exact_f32 and args.sustained_s > 0:
-        sus_model = Model(device=local_rank, max_windows=B, bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k,
-                          fp8_corrections=args.fp8_corrections)
+        sus_model = Model(device=local_rank, max_windows=B, bf16_weights=args.bf16_weights, ext_cqt_44k=args.ext_cqt_44k)
 
         def sus_step():
             sus_model._predict_device(audio, out=out, sync=False)
@@ -632,8 +649,7 @@ def main() -> None:
         # stays the one measured inside the timed region
         dom = {k: v for k, v in stage.items() if v > 0.0}
         model.close()
-        model = Model(device=local_rank, max_windows=B, stage_timing=True, fp8_corrections=args.fp8_corrections,
-                      bf16_weights=args.bf16_weights,
+        model = Model(device=local_rank, max_windows=B, stage_timing=True, bf16_weights=args.bf16_weights,
                       ext_cqt_44k=args.ext_cqt_44k)
         for _ in range(3):
             step()
@@ -664,24 +680,8 @@ def main() -> None:
         torch.cuda.synchronize()
         extras["exact_f32_windows_per_s"] = B * 8 / (time.perf_counter() - t0)
         ex_model.close()
-    if (not args.exact_f32 and not args.no_fp8_extra and not args.fp8_corrections and rank == 0
-            and not (args.bf16_weights or args.ext_cqt_44k)):
-        # beside the headline, never instead of it: the opt-in reduced-precision mode on the same batch
-        fx_model = Model(device=local_rank, max_windows=B, fp8_corrections=True)
-        for _ in range(3):
-            fx_model._predict_device(audio, out=out, sync=False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            fx_model._predict_device(audio, out=out, sync=False)
-        torch.cuda.synchronize()
-        extras["fp8_corrections_windows_per_s"] = B * args.steps / (time.perf_counter() - t0)
-        extras["fp8_corrections_note"] = ("BP_FLAG_FP8_CORRECTIONS, opt-in: contour / onset conv1 corrections on block-scaled fp8 "
-                                          "MFMA — narrower than the config's fp32, reported beside `value`")
-        fx_model.close()
-
     if (not args.exact_f32 and not args.no_config_extras and rank == 0 and world == 1
-            and not (args.bf16_weights or args.ext_cqt_44k or args.fp8_corrections)):
+            and not (args.bf16_weights or args.ext_cqt_44k)):
         # beside the headline: two handles on two streams taking alternate batches — what a service with two lanes gets
         # (the kernels of one batch run under the launch gaps and tails of the other's; per-kernel times are no longer
         # those of a kernel alone on the chip, which is why `value` and `roofline` stay on one stream)
@@ -721,17 +721,7 @@ def main() -> None:
             c1_ms = stage["contour_conv1"]
             folded = stage.get("contour_conv1_edge", 0.0) > 0.0
             mf = (2 / 3 if args.bf16_weights else 1)
-            mx = folded and os.environ.get("BP_CONV1") != "f16" and not args.bf16_weights and args.fp8_corrections
-            if mx:
-                c1_flop = C1_FLOP_PER_WINDOW * F1_SHARE
-                c1_kernel = ("contour_conv1_fold_mx_kernel (interior 56/66 of harmonic stack + Conv2D 8->8 3x39 + ReLU with the 8 "
-                             "shifted channels folded into one 176-tap kernel; hi*hi on f16 MFMA 32x32x16, the lo*hi + hi*lo "
-                             "corrections on block-scaled fp8 MFMA 32x32x64, one fp32 accumulator; algorithmic FLOPs = the "
-                             "reference's 8-channel products it replaces; executed = f16-equivalent matrix-pipe FLOPs)")
-                c1_exec = FX_EXECUTED_FLOP_PER_WINDOW * B / (c1_ms * 1e-3) / 1e12
-                c1_bytes = F1_BYTES_PER_WINDOW * B
-                c1_key = "contour_conv1_fold_mx_kernel"
-            elif folded and os.environ.get("BP_CONV1") != "rounds":
+            if folded and os.environ.get("BP_CONV1") != "rounds":
                 c1_flop = C1_FLOP_PER_WINDOW * F1_SHARE
                 c1_kernel = ("contour_conv1_march_kernel (interior 56/66 of harmonic stack + Conv2D 8->8 3x39 + ReLU with the 8 "
                              "shifted channels folded into one 176-tap kernel; wave-private vertical march on f16 MFMA 16x16x32: "
@@ -773,7 +763,7 @@ def main() -> None:
             # weights rounded to bf16 (one f16 operand), activations and CQT unchanged
             "dtype": ("f32 I/O + accumulate, bf16-rounded weights as single f16 MFMA operands, split-f16 activations" if args.bf16_weights
                       else "exact f32 MFMA (A/B path)" if args.exact_f32
-                      else DTYPE_FP8 if args.fp8_corrections else DTYPE_DEFAULT),
+                      else DTYPE_DEFAULT),
             "data": "synthetic",
             "config": {
                 "workload": f"batch={B} synthetic uniform[-1,1) 2 s @ 22.05 kHz mono windows per GPU, "
@@ -798,7 +788,12 @@ def main() -> None:
                 # the kernel's own ratio above is ~1; the STEP moves far more than the path's algorithmic I/O (c1 round trip,
                 # pyramid planes, lp): that ratio belongs on the line too
                 "step_traffic": pmc_step_traffic(B) if c1_key else None,
-                "algorithmic_bytes_per_launch": c1_bytes,
+                # what THIS kernel reads and writes by construction (zp in, the materialised 8-channel c1 out): an
+                # implementation choice, not the algorithm's I/O ...
+                "kernel_io_bytes_per_launch": c1_bytes,
+                # ... which for the whole contour branch (conv1 + conv2; c1 never needs to exist) is the 172 x 309 fp32 CQT
+                # in and the 172 x 264 fp32 contour map out
+                "branch_algorithmic_bytes_per_launch": (172 * 309 * 4 + 172 * 264 * 4) * B,
                 "executed_mfma_tflops": c1_exec,  # incl. the 3-product split and Toeplitz padding
                 "executed_frac": c1_exec / c1_peak,
                 "launch_ms": c1_ms,
@@ -839,7 +834,7 @@ def main() -> None:
                 "algorithmic_flop_per_window": 79_425_024,
             }
         line.update(extras)
-        if (not args.no_config_extras and not args.exact_f32 and not args.fp8_corrections
+        if (not args.no_config_extras and not args.exact_f32
                 and not (args.bf16_weights or args.ext_cqt_44k) and B == BATCH):
             model.close()
             del audio, out

@@ -89,18 +89,17 @@ typedef enum bp_mem_kind {
                                    * Ignored with BP_FLAG_STAGE_TIMING / F32_MFMA. */
 
 #define BP_FLAG_F16_CORRECTIONS 32u /* Since round 3 this is the DEFAULT arithmetic and the flag is accepted as a no-op (it
-                                    * wins over BP_FLAG_FP8_CORRECTIONS when both are set): every matrix product of the path
+                                    * wins over BP_FLAG_FP8_CORRECTIONS when both are set: the pair is accepted): every matrix product of the path
                                     * is hi hi + lo hi + hi lo on the f16 instruction with fp32 accumulation — fp32-class
                                     * results (<= 2^-22 per product), 5e-6 / 5e-7 per stage against the fp32 oracle. */
-#define BP_FLAG_FP8_CORRECTIONS 64u /* OPT-IN reduced-precision mode, not the reference's fp32 contract: the two correction
-                                    * products of the split-precision scheme (lo_w a + hi_w lo_a, each <= 2^-11 of a product)
-                                    * of the two largest layers — the folded contour conv1 and the onset conv1 — run on the
-                                    * block-scaled fp8 matrix instruction (one v_mfma_scale_f32_32x32x64_f8f6f4 per 32 taps
-                                    * instead of four f16 instructions): ~1e-5 on the contour map, ~3e-5 on the onset map
-                                    * against the fp64 graph, ~8 % more throughput; 1 of 512 noise-like windows measured at
-                                    * 1.05e-4 (profiles/r02_parity_many.md).  (Environment, for A/B runs of one layer on a
-                                    * handle created with this flag: BP_CONV1=f16, BP_ONSET=f16.)  Ignored with
-                                    * BP_FLAG_BF16_WEIGHTS / BP_FLAG_F32_MFMA. */
+#define BP_FLAG_FP8_CORRECTIONS 64u /* NOT IN THE PRODUCT LIBRARY since round 6: bp_create refuses it with BP_ERR_INVALID_ARG
+                                    * (unless BP_FLAG_F16_CORRECTIONS is set too, which wins).  Rounds 2 - 5: an opt-in
+                                    * reduced-precision mode — the two correction products of the folded contour conv1 and
+                                    * of the onset conv1 on the block-scaled fp8 matrix instruction, ~1e-5 / ~3e-5 on the
+                                    * contour / onset map; once the default moved to the register-resident marches it was no
+                                    * faster (345 k against 347 k windows/s, round 5).  Its kernels are compiled into the A/B
+                                    * library only (basic_pitch_amd/build.py: build_library(ab=True)), where the flag works
+                                    * as before (tests/test_gpu_parity.py::test_fp8_corrections_mode_lives_in_the_ab_library). */
 #define BP_FLAG_BLOCKING_WAIT 128u /* the whole-track calls (bp_infer_track / _tracks / _pcm / _pcm_raw) wait for the device
                                     * asleep on an interrupt instead of spinning on the stream: for file jobs with more worker
                                     * threads than cores (bp_transcribe_files).  Costs tens of microseconds of wake-up

@@ -53,13 +53,17 @@ def test_bench_single_rank_line_has_the_contract_keys():
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in line, k
     assert line["n_gpus"] == 1 and "workload" in line["config"] and "fp8" not in line["dtype"]
-    # the opt-in reduced-precision rate and the exact-f32 A/B rate are reported BESIDE the headline
-    assert line["fp8_corrections_windows_per_s"] > 0 and line["exact_f32_windows_per_s"] > 0
+    # the exact-f32 A/B rate is reported BESIDE the headline; the fp8-corrections mode left the product in round 6
+    assert "fp8_corrections_windows_per_s" not in line and line["exact_f32_windows_per_s"] > 0
     r = line["roofline"]
     assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # the kernel's own I/O (c1 materialised: an implementation choice) is not called algorithmic; the branch's is beside it
+    assert "algorithmic_bytes_per_launch" not in r
+    assert r["kernel_io_bytes_per_launch"] > 3 * r["branch_algorithmic_bytes_per_launch"] > 0
     # every BASELINE.json config and the reference's batch-1 host call pattern are in the driver's record (round 4)
     for k in ("b1024", "bf16_b1024", "ext44k_b512", "tracks_256x3min", "b16"):
         assert line["configs"][k]["windows_per_s"] > 0, k
+        assert k == "tracks_256x3min" or (line["configs"][k]["steps"] >= 10 and line["configs"][k]["warmup"] == 3), k
     assert line["seam_b1_host"]["windows_per_s"] > 0 and line["seam_b1_host"]["ms_per_call"] > 0
     st = r["step_traffic"]
     assert st is None or (st["ratio"] > 1.0 and st["bytes_per_step"] > st["algorithmic_bytes_per_step"])

@@ -347,3 +347,128 @@ def test_save_shard_native_routes_through_transcribe_files(tmp_path, monkeypatch
     with pytest.raises(ValueError, match="native=True"):
         sharding._save_shard(paths, [0], 0, None, fake_factory, out,
                              {"save_midi": True, "sonify_midi": True, "save_model_outputs": False, "save_notes": True}, {"native": True})
+
+
+# ---- the window-range fallback: one long file among short ones is cut into pieces ------------------------
+class WindowFake(FakeModel):
+    """A stand-in whose posteriorgrams are a function of each WINDOW's samples (as the real graph's are), with both entry
+    points `predict_many_sharded` drives: `predict_tracks` (whole files: host windowing -> predict -> unwrap, the
+    reference's structure) and `predict` (a piece's windows).  Split and unsplit results can then be compared bit for bit."""
+
+    max_windows = 4
+
+    def predict(self, x):
+        x = np.asarray(x, np.float32).reshape(len(x), -1)
+        note = np.zeros((len(x), 172, 88), np.float32)
+        onset = np.zeros((len(x), 172, 88), np.float32)
+        contour = np.zeros((len(x), 172, 264), np.float32)
+        for i, w in enumerate(x):
+            rng = np.random.default_rng(int(np.abs(w[4000:9000]).sum() * 1e5) % (2**31))
+            note[i] = rng.uniform(0, 0.2, (172, 88))
+            onset[i] = rng.uniform(0, 0.2, (172, 88))
+            contour[i] = rng.uniform(0, 0.2, (172, 264))
+            f, t0 = int(rng.integers(5, 80)), int(rng.integers(20, 100))
+            note[i, t0 : t0 + 40, f] = 0.8
+            onset[i, t0, f] = 0.9
+        return {"note": note, "onset": onset, "contour": contour}
+
+    def predict_tracks(self, signals):
+        from basic_pitch_amd import inference as inf
+
+        outs = []
+        for y in signals:
+            padded = np.concatenate([np.zeros(3840, np.float32), np.asarray(y, np.float32)])
+            wins = [w[:, 0] for w, _ in inf.window_audio_file(padded, 36164)]
+            parts = {"note": [], "onset": [], "contour": []}
+            for a in range(0, len(wins), 3):  # another batching than predict_window_range's
+                for k, v in self.predict(np.stack(wins[a : a + 3])).items():
+                    parts[k].append(v)
+            outs.append({k: inf.unwrap_output(np.concatenate(v), len(y), 30, 36164) for k, v in parts.items()})
+        return outs
+
+
+def window_fake_factory(device):
+    return WindowFake(device)
+
+
+def _write_long_and_short(tmp_path):
+    import wave
+
+    paths = []
+    for i, seconds in enumerate((2, 61, 3, 2)):
+        rng = np.random.default_rng(70 + i)
+        x = (rng.uniform(-0.5, 0.5, 22050 * seconds) * 32767).astype("<i2")
+        p = tmp_path / f"take_{i}.wav"
+        with wave.open(str(p), "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(22050)
+            w.writeframes(x.tobytes())
+        paths.append(str(p))
+    return paths
+
+
+def _digest(results):
+    import hashlib
+
+    out = []
+    for r in results:
+        if isinstance(r, Exception):
+            out.append(("error", type(r).__name__, str(r)[:40]))
+        else:
+            mo, midi, ev = r
+            out.append((mo["note"].shape, hashlib.sha256(b"".join(np.ascontiguousarray(mo[k]).tobytes() for k in ("note", "onset", "contour"))).hexdigest(),
+                        [(float(e[0]), float(e[1]), int(e[2]), float(e[3])) for e in ev]))
+    return out
+
+
+def _split_worker(rank, world, port, paths, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = str(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from basic_pitch_amd import predict_many_sharded
+
+    res = predict_many_sharded(paths, model_factory=window_fake_factory, group=2, decode_threads=2)
+    if rank == 0:
+        torch.save(_digest(res), out_path)
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_long_file_is_split_by_window_range_over_two_ranks(tmp_path):
+    """SURVEY.md 8e / VERDICT r5 missing #3: `split_windows` is part of the product's plan.  A 61-second take among three
+    short ones outweighs an even share of a 2-rank job, so `plan_units` cuts it into two window ranges; each rank decodes the
+    file, computes its own windows (`predict_window_range`), rank 0 concatenates the rows and decodes the notes over the whole
+    file.  Inside a 2-rank gloo job and as 2 spawned workers the result is BIT-EQUAL to the unsplit single-process result
+    (posteriorgram bytes and note events) — windows are independent — and a long file that cannot be read is reported in
+    place."""
+    from basic_pitch_amd import predict_many_sharded
+    from basic_pitch_amd.sharding import _file_costs, plan_units, split_windows
+
+    paths = _write_long_and_short(tmp_path)
+    units, shards = plan_units(_file_costs(paths), 2)
+    assert (1, 0, 2) in units and (1, 1, 2) in units and len(units) == 5
+    owners = {units[u]: r for r, sh in enumerate(shards) for u in sh}
+    assert owners[(1, 0, 2)] != owners[(1, 1, 2)]  # the two halves of the long file run on different ranks
+    single = _digest(predict_many_sharded(paths, gpus=1, model_factory=window_fake_factory, group=2, decode_threads=2))
+    assert single[1][0][0] == int(61 * 22050 / 36164 * 142) and len(single[1][2]) > 10
+    out_path = str(tmp_path / "split.pt")
+    mp.spawn(_split_worker, args=(2, _free_port(), paths, out_path), nprocs=2, join=True)
+    ranked = torch.load(out_path)
+    spawned = _digest(predict_many_sharded(paths, gpus=2, model_factory=window_fake_factory, group=2, decode_threads=2))
+    assert ranked == single and spawned == single
+    # a job of ONE file: every rank takes a window range of it
+    solo = _digest(predict_many_sharded(paths[1:2], gpus=2, model_factory=window_fake_factory, decode_threads=1))
+    assert solo == single[1:2]
+    n_win = len(range(0, 61 * 22050 + 3840, 36164))
+    assert split_windows(n_win, 2) == [(0, 19), (19, 38)] and n_win == 38
+    # a long file that is not audio: its pieces fail on both ranks, the file's entry is the exception, the others are there
+    bad = tmp_path / "long_bad.wav"
+    bad.write_bytes(b"RIFF" + bytes(3_000_000))
+    res = predict_many_sharded([paths[0], str(bad), paths[2]], gpus=2, model_factory=window_fake_factory, decode_threads=1)
+    assert isinstance(res[1], Exception) and not isinstance(res[0], Exception) and not isinstance(res[2], Exception)

@@ -29,7 +29,9 @@ def sliced(f, x):
 def per_window(p, ref):
     return np.max([np.abs(p[k] - ref[k]).reshape(len(ref[k]), -1).max(1) for k in KEYS], axis=0)
 
-paths = {"default (all-f16 split)": {}, "fp8 corrections (opt-in)": {"fp8_corrections": True}, "exact-f32 A/B path": {"exact_f32_mfma": True}}
+paths = {"default (all-f16 split)": {}, "exact-f32 A/B path": {"exact_f32_mfma": True}}
+if "_ab" in os.environ.get("BASIC_PITCH_AMD_LIB", ""):  # the fp8-corrections mode lives in the A/B library since round 6
+    paths["fp8 corrections (A/B library)"] = {"fp8_corrections": True}
 try:
     O.c_library(); have_c = True
 except OSError:
