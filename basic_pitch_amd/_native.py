@@ -101,7 +101,8 @@ class bp_transcribe_params(C.Structure):
         ("save_notes", C.c_int32),
         ("threads", C.c_int32),
         ("host_decode", C.c_int32),
-        ("reserved", C.c_int32 * 3),
+        ("direct_io", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -149,6 +150,8 @@ EXPORTED_SYMBOLS = [
     "bp_host_alloc",
     "bp_host_free",
     "bp_files_release_buffers",
+    "bp_files_direct_reads",
+    "bp_files_read_probe",
     "bp_track_n_windows",
     "bp_handle_track_n_windows",
     "bp_handle_track_n_frames",
@@ -239,6 +242,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bp_host_free.restype = None
     lib.bp_files_release_buffers.argtypes = []
     lib.bp_files_release_buffers.restype = None
+    lib.bp_files_direct_reads.argtypes = []
+    lib.bp_files_direct_reads.restype = C.c_int64
+    lib.bp_files_read_probe.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    lib.bp_files_read_probe.restype = C.c_int64
     lib.bp_handle_track_n_windows.argtypes = [vp, i64]
     lib.bp_handle_track_n_windows.restype = i64
     lib.bp_handle_track_n_frames.argtypes = [vp, i64]

@@ -409,9 +409,24 @@ struct Pinned {
   Pinned& operator=(const Pinned&) = delete;
 };
 
-bool read_file_pinned(const std::string& path, Pinned& buf, size_t& n) {
+std::atomic<int64_t> g_direct_reads{0};  // files whose bytes came in by O_DIRECT since the library was loaded
+
+// A file's bytes into a page-locked buffer.  `direct`: O_DIRECT — the storage device's DMA writes straight into the
+// page-locked buffer the GPU's copy engine reads from; the page cache is bypassed, so a file crosses host DRAM twice (device
+// write, PCIe read) instead of four times (page-cache fill, the copy out of it: read + write, PCIe read) and no core copies
+// it (host DRAM bandwidth is the first resource an 8-GPU file job runs out of).  O_DIRECT wants the buffer, the
+// offset and the length aligned to the logical block size: the pooled buffers are page-aligned, the length is rounded up
+// to 4 KiB (the read stops at the end of the file).  A file system that refuses O_DIRECT (tmpfs, some overlays: EINVAL at
+// open or at the first read) is read through the page cache as before.
+template <class Ensure>  // ensure(bytes) -> page-aligned buffer of at least that many bytes, or null (g_file_error set)
+bool read_file_into(const std::string& path, Ensure&& ensure, size_t& n, bool direct, bool* was_direct = nullptr) {
   n = 0;
-  const int fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+  int fd = -1;
+#ifdef O_DIRECT
+  if (direct) fd = open(path.c_str(), O_RDONLY | O_CLOEXEC | O_DIRECT);
+#endif
+  bool is_direct = fd >= 0;
+  if (fd < 0) fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
   if (fd < 0) {
     g_file_error = path + " is not a file path.";
     return false;
@@ -423,13 +438,27 @@ bool read_file_pinned(const std::string& path, Pinned& buf, size_t& n) {
     return false;
   }
   const size_t size = (size_t)st.st_size;
-  if (!buf.ensure(size ? size : 1)) {
+  constexpr size_t kBlock = 4096;
+  const size_t want = is_direct ? ((size + kBlock - 1) / kBlock) * kBlock : size;
+  uint8_t* dst = static_cast<uint8_t*>(ensure(want ? want : 1));
+  if (!dst) {
     close(fd);
     return false;
   }
   while (n < size) {
-    const ssize_t got = read(fd, static_cast<uint8_t*>(buf.p) + n, size - n);
+    // direct: n stays a multiple of the block size until the file's end (a short read ends the loop or the file)
+    const ssize_t got = read(fd, dst + n, want - n);
     if (got < 0 && errno == EINTR) continue;
+    if (got < 0 && is_direct && errno == EINVAL && n == 0) {  // the file system takes the flag at open and refuses the read
+      close(fd);
+      fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+      is_direct = false;
+      if (fd < 0) {
+        g_file_error = path + " is not a file path.";
+        return false;
+      }
+      continue;
+    }
     if (got < 0) {
       g_file_error = path + ": " + std::strerror(errno);
       close(fd);
@@ -437,9 +466,17 @@ bool read_file_pinned(const std::string& path, Pinned& buf, size_t& n) {
     }
     if (got == 0) break;  // shorter than fstat said: what is there
     n += (size_t)got;
+    if (is_direct && (n % kBlock) != 0) break;  // the file's tail
   }
+  if (n > size) n = size;
   close(fd);
+  if (is_direct) g_direct_reads.fetch_add(1, std::memory_order_relaxed);
+  if (was_direct) *was_direct = is_direct;
   return true;
+}
+
+bool read_file_pinned(const std::string& path, Pinned& buf, size_t& n, bool direct = false) {
+  return read_file_into(path, [&](size_t bytes) -> void* { return buf.ensure(bytes) ? buf.p : nullptr; }, n, direct);
 }
 
 int wav_pcm_format(const WavInfo& w) {
@@ -512,6 +549,38 @@ void set_report(bp_file_report* r, int status, const std::string& msg) {
 extern "C" {
 
 const char* bp_files_last_error(void) { return g_file_error.c_str(); }
+
+int64_t bp_files_direct_reads(void) { return g_direct_reads.load(std::memory_order_relaxed); }
+
+// The pipeline's file reader on its own, into ordinary page-aligned host memory (no device needed): the file's length, a
+// 64-bit FNV-1a of its bytes and whether O_DIRECT was really used — what the CPU tests compare with Python's read.
+int64_t bp_files_read_probe(const char* path, int direct_io, uint64_t* fnv1a, int* used_direct) {
+  if (!path) {
+    g_file_error = "bp_files_read_probe: null path";
+    return BP_ERR_INVALID_ARG;
+  }
+  void* mem = nullptr;
+  size_t n = 0;
+  bool was = false;
+  const bool ok = read_file_into(std::string(path), [&](size_t bytes) -> void* {
+    if (posix_memalign(&mem, 4096, bytes) != 0) {
+      mem = nullptr;
+      g_file_error = "bp_files_read_probe: out of memory";
+    }
+    return mem;
+  }, n, direct_io != 0, &was);
+  if (!ok) {
+    std::free(mem);
+    return BP_ERR_BAD_AUDIO;
+  }
+  uint64_t h = 1469598103934665603ull;
+  const uint8_t* p = static_cast<const uint8_t*>(mem);
+  for (size_t i = 0; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+  std::free(mem);
+  if (fnv1a) *fnv1a = h;
+  if (used_direct) *used_direct = was ? 1 : 0;
+  return (int64_t)n;
+}
 
 void bp_files_release_buffers(void) {
   std::vector<std::pair<void*, size_t>> all;
@@ -678,7 +747,7 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
         continue;
       }
       size_t n_bytes = 0;
-      if (!read_file_pinned(path, file, n_bytes)) {
+      if (!read_file_pinned(path, file, n_bytes, prm.direct_io != 0)) {
         set_report(rep, BP_ERR_BAD_AUDIO, g_file_error);
         continue;
       }

@@ -943,6 +943,7 @@ def transcribe_files(
     threads: int = 0,
     devices: Optional[Sequence[int]] = None,
     host_decode: bool = False,
+    direct_io: bool = False,
 ) -> List[Dict[str, Any]]:
     """The batch job of `predict_and_save` (inference.py:509-604) for WAV / FLAC input and MIDI / note-event output, run
     natively: ONE call into the library (`bp_transcribe_files`, csrc/file_pipeline.cpp), C++ worker threads from the
@@ -954,7 +955,8 @@ def transcribe_files(
     milliseconds of the worker}}`; per-file
     failures are reported, not raised (the reference's per-file try / except).  By default the dense half of note
     decoding runs on the device and 7 MB per 3-minute track come back instead of 27.6 (`host_decode=True`: the round-4
-    path, all three posteriorgrams decoded on the host; same bytes)."""
+    path, all three posteriorgrams decoded on the host; same bytes).  `direct_io=True` reads the files with O_DIRECT straight
+    into the page-locked buffers the GPU copies from (no page-cache copy; for corpora larger than the page cache)."""
     own: List[Model] = []
     if models is None:
         if isinstance(model_or_model_path, Model):
@@ -978,6 +980,7 @@ def transcribe_files(
         prm.multiple_pitch_bends = int(bool(multiple_pitch_bends))
         prm.save_midi, prm.save_notes, prm.threads = int(bool(save_midi)), int(bool(save_notes)), int(threads)
         prm.host_decode = int(bool(host_decode))
+        prm.direct_io = int(bool(direct_io))
         handles = (C.c_void_p * len(models))(*[m._handle for m in models])
         cpaths = (C.c_char_p * max(1, n))(*paths)
         reports = (_native.bp_file_report * max(1, n))()

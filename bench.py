@@ -247,8 +247,23 @@ def run_files(args, torch=None, dist=None, world: int = 1, rank: int = 0, local_
             out_dir, warm_dir = os.path.join(d, "out"), os.path.join(d, "warm")
             os.mkdir(out_dir)
             os.mkdir(warm_dir)
-            kw = dict(models=lanes, threads=threads, host_decode=args.host_decode)
+            kw = dict(models=lanes, threads=threads, host_decode=args.host_decode, direct_io=args.direct_io)
             transcribe_files(paths[: min(8, len(paths))], warm_dir, **kw)  # warm-up
+            if args.cold_files:
+                # the corpus does not sit in the page cache: written back, then dropped from it (the distinct files; the rest
+                # are hard links to them).  Buffered reads then come from the storage device THROUGH the page cache,
+                # O_DIRECT reads from the device straight into the page-locked buffers.
+                os.sync()
+                for pth in paths[:distinct]:
+                    fd = os.open(pth, os.O_RDONLY)
+                    try:
+                        os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+                    finally:
+                        os.close(fd)
+            direct_before = int(lanes[0]._lib.bp_files_direct_reads())
+            import resource
+
+            ru0 = resource.getrusage(resource.RUSAGE_SELF)
             if world > 1:
                 dist.barrier()
             t0 = time.perf_counter()
@@ -266,6 +281,12 @@ def run_files(args, torch=None, dist=None, world: int = 1, rank: int = 0, local_
                 raise SystemExit(f"native pipeline: {len(bad)} files failed: {bad[0]}")
             n_events = sum(r["n_note_events"] for r in rep)
             stage_ms = {k: float(np.mean([r["ms"][k] for r in rep])) for k in rep[0]["ms"]}
+            ru1 = resource.getrusage(resource.RUSAGE_SELF)
+            io_note = {"host_cpu_ms_per_file": {"user": (ru1.ru_utime - ru0.ru_utime) * 1e3 / max(1, len(paths)),
+                                                "system": (ru1.ru_stime - ru0.ru_stime) * 1e3 / max(1, len(paths))},
+                       "direct_io_requested": bool(args.direct_io),
+                       "files_read_with_o_direct": int(lanes[0]._lib.bp_files_direct_reads()) - direct_before,
+                       "cold_files": bool(args.cold_files), "distinct_files": distinct, "tmp_dir": d}
             for m in lanes:
                 m.close()
             back = ("all three posteriorgrams back (27.6 MB per file), note decoding on the host" if args.host_decode else
@@ -327,9 +348,9 @@ def run_files(args, torch=None, dist=None, world: int = 1, rank: int = 0, local_
         "audio_seconds_per_s": n_all * args.file_seconds / el, "windows_per_s": windows / el,
         "config": {"workload": f"{n_all} synthetic 16-bit stereo 44.1 kHz WAV files ({min(len(paths), 32)} distinct signals per rank) of {args.file_seconds:g} s through "
                    + how, "host_threads": min(16, os.cpu_count() or 1), "note_events": n_events,
-                   "sharding": "file i -> rank i mod N, no collective on the data path"},
+                   "sharding": "sharding.plan_shards (LPT over the files' sizes), no collective on the data path"},
         **extra,
-        **({"worker_ms_per_file": stage_ms} if args.native else {}),
+        **({"worker_ms_per_file": stage_ms, "file_io": io_note} if args.native else {}),
     }), flush=True)
 
 STEP_ALGORITHMIC_BYTES_PER_WINDOW = BYTES_PER_WINDOW  # fp32 audio in + three fp32 posteriorgrams out
@@ -446,6 +467,10 @@ def main() -> None:
     ap.add_argument("--native", action="store_true",
                     help="--workload files: the native pipeline (bp_transcribe_files: C++ worker threads, no Python in the loop)")
     ap.add_argument("--lanes", type=int, default=3, help="--native: GPU lanes (handles) the workers queue for")
+    ap.add_argument("--direct-io", action="store_true",
+                    help="--native: read the files with O_DIRECT straight into the page-locked buffers (no page-cache copy)")
+    ap.add_argument("--cold-files", action="store_true",
+                    help="--native: drop the files from the page cache before the timed job (a corpus larger than host memory)")
     ap.add_argument("--host-decode", action="store_true",
                     help="--native: bring all three posteriorgrams back and decode on the host (the round-4 path) instead of "
                          "extracting the onset peaks and pitch bends on the device")

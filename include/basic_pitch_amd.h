@@ -403,7 +403,12 @@ typedef struct bp_transcribe_params {
                                    onset-peak bitmap and the pitch-bend map come back (bp_infer_pcm_raw_candidates: 7 MB per
                                    3-minute track); 1: all three posteriorgrams come back (27.6 MB) and the host decodes
                                    them (bp_notes_decode) — the round-4 path, same events */
-  int32_t reserved[3];
+  int32_t direct_io;            /* 0 (default): files are read through the page cache; 1: with O_DIRECT, the storage device's
+                                   DMA landing in the page-locked buffer the GPU copies from (no page-cache copy: half the
+                                   host-DRAM traffic per file and no core-ms for it; a file system that refuses O_DIRECT is
+                                   read buffered).  For corpora that do NOT fit the page cache — a file that is already
+                                   cached is read faster from there */
+  int32_t reserved[2];
 } bp_transcribe_params;
 
 typedef struct bp_file_report {
@@ -433,6 +438,12 @@ const char* bp_files_last_error(void); /* thread-local */
 /* bp_transcribe_files keeps its workers' page-locked buffers (a file's bytes, its posteriorgrams) in a process-wide pool
  * between calls; this releases the pooled ones (a long-lived service calls it when a burst of jobs is over). */
 void bp_files_release_buffers(void);
+/* files whose bytes bp_transcribe_files read with O_DIRECT since the library was loaded (params.direct_io; 0 when the file
+ * system refused the flag) */
+int64_t bp_files_direct_reads(void);
+/* bp_transcribe_files' file reader on its own, into ordinary host memory (test hook, no device): returns the number of bytes
+ * read (or a negative bp_status), a 64-bit FNV-1a of them and whether O_DIRECT was really used. */
+int64_t bp_files_read_probe(const char* path, int direct_io, uint64_t* fnv1a, int* used_direct);
 
 #ifdef __cplusplus
 }

@@ -293,3 +293,45 @@ def test_product_library_reads_no_behaviour_switch_from_the_environment():
     assert n <= 2, n
     for src in build.AB_SOURCES:
         assert src not in build.SOURCES
+
+
+def test_native_file_reader_direct_io_reads_the_same_bytes(tmp_path):
+    """bp_transcribe_files' reader (csrc/file_pipeline.cpp read_file_into) with and without O_DIRECT: the same bytes as
+    Python's read for lengths around the 4 KiB block size (an O_DIRECT read is issued in whole blocks and stops at the end of
+    the file), an empty file included; a file system that refuses O_DIRECT is read through the page cache and says so; a missing file is an error, not a crash."""
+    import ctypes as C
+
+    from basic_pitch_amd import _native
+
+    lib = _native.load_library()
+
+    def fnv(b):
+        h = 1469598103934665603
+        for x in b:
+            h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    rng = np.random.default_rng(3)
+    used_any = False
+    for n in (0, 1, 4095, 4096, 4097, 8192, 100_000, 1_048_576 + 17):
+        p = tmp_path / f"f{n}.bin"
+        data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        p.write_bytes(data)
+        for direct in (0, 1):
+            h, used = C.c_uint64(), C.c_int(-1)
+            got = lib.bp_files_read_probe(os.fsencode(str(p)), direct, C.byref(h), C.byref(used))
+            assert got == n and h.value == fnv(data), (n, direct, got)
+            assert used.value in (0, 1) and (direct or used.value == 0)
+            used_any = used_any or used.value == 1
+    before = lib.bp_files_direct_reads()
+    h, used = C.c_uint64(), C.c_int(-1)
+    assert lib.bp_files_read_probe(os.fsencode(str(tmp_path / "missing.bin")), 1, C.byref(h), C.byref(used)) < 0
+    assert lib.bp_files_direct_reads() == before
+    if os.path.isdir("/dev/shm"):  # tmpfs: refuses O_DIRECT before Linux 6.6 (buffered fallback), takes it as a no-op since
+        q = "/dev/shm/bp_direct_probe_%d.bin" % os.getpid()
+        try:
+            open(q, "wb").write(b"x" * 5000)
+            assert lib.bp_files_read_probe(os.fsencode(q), 1, C.byref(h), C.byref(used)) == 5000 and h.value == fnv(b"x" * 5000)
+        finally:
+            os.unlink(q)
+    print("O_DIRECT used on", tmp_path, ":", used_any)
