@@ -95,8 +95,12 @@ void launch_onset_march16(const uint32_t* zp, const float* note, const void* wfr
 void launch_contour_conv1_fold_mx(const uint32_t* zp, const void* a16, const void* amx, const void* ascale,
                                   const float* bias, float* c1, int n_windows, int n_cu, hipStream_t stream);
 #endif
+#ifdef BP_AB_KERNELS  // conv_contour2.hip: the round-2 vector kernel (BP_CONV2=valu; A/B builds only)
 void launch_contour_conv2(const float* c1, const float* w2, float bias, float* contour, int n_windows, int n_cu,
                           hipStream_t stream);
+#endif
+void launch_contour_conv2_proj(const float* c1, const void* wfrag, float bias, float* contour, int n_windows, int n_cu,
+                               bool weights_have_lo, hipStream_t stream);
 #ifdef BP_AB_KERNELS  // note_march.hip: the 32x32x16 form of the note march (A/B builds only)
 void launch_note_march(const float* contour, const void* wfrag, const float* wf32, float* note, int n_windows,
                        bool weights_have_lo, hipStream_t stream);
@@ -137,6 +141,22 @@ static void launch_onset(const uint32_t* zp, const float* note, const void* wfra
 #endif
   (void)wfrag, (void)wmx, (void)kind;
   launch_onset_march16(zp, note, w16, wf32, onset, n_windows, n_cu, weights_have_lo, stream);
+}
+// contour conv2: the tap projection on the matrix cores (round 6).  A/B builds only: BP_CONV2=valu selects the round-2 kernel.
+static void launch_conv2(const float* c1, const float* w2, const void* wproj, float bias, float* contour, int n_windows,
+                         int n_cu, bool weights_have_lo, hipStream_t stream) {
+#ifdef BP_AB_KERNELS
+  static const bool valu = [] {
+    const char* e = ab_env("BP_CONV2");
+    return e && std::strcmp(e, "valu") == 0;
+  }();
+  if (valu) {
+    launch_contour_conv2(c1, w2, bias, contour, n_windows, n_cu, stream);
+    return;
+  }
+#endif
+  (void)w2;
+  launch_contour_conv2_proj(c1, wproj, bias, contour, n_windows, n_cu, weights_have_lo, stream);
 }
 // the note branch: the wave-private march on 16x16x32 (round 6).  A/B builds only: BP_NOTE=march32 selects the 32x32x16 form.
 static void launch_note(const float* contour, const void* wfrag, const void* w16, const float* wf32, float* note, int n_windows,
@@ -263,7 +283,7 @@ struct bp_context {
   float* zp = nullptr;  // uint32 [cap][kZRowsP][kZRow] pre-split z, zero padded (bp_common.h)
   // contour branch, two-kernel form (conv_contour_direct.hip): LDS weight image, bias[8], conv2 taps [5][5][8]
   float *d_d1_wlds = nullptr, *d_d1_wfold = nullptr, *d_d1_wmarch = nullptr, *d_d1_wrim = nullptr, *d_d1_wrimm = nullptr, *d_d1_bias = nullptr,
-        *d_d2_w = nullptr;
+        *d_d2_w = nullptr, *d_d2_wproj = nullptr;
   bool rim_exact = false, fold_mx = false;
   int resample_mode = 0;  // BP_RESAMPLE=plain|tiled: 1 | 2 (A/B runs of the resampling kernels)
   int contour_parts = 0;  // BP_CONTOUR_PARTS (0: automatic)
@@ -813,6 +833,34 @@ void pack_onset16(const Tensor* w1, const Tensor* w2, std::vector<uint16_t>& out
     }
 }
 
+// conv_contour2.hip contour_conv2_proj_kernel: Conv2D 8 -> 1, 5 x 5 (models.py:254-263; w2 is OIHW (1, 8, 5, 5)) as the A operand
+// of v_mfma_f32_32x32x16_f16 with the three split-precision products packed along K: two fragments x 64 lanes x (8 x f16),
+// A1 = [hi 2^11 | hi], A2 = [lo 2^11 | 0] against the B operand [hi(c1) | lo(c1) 2^11] of four channels.  Lane (m = lane & 31,
+// hk = lane >> 5), elements j < 4 / j >= 4: channel 4 hk + (j & 3); row m <-> C register r = (m & 3) + 4 (m >> 3) of lane half
+// (m >> 2) & 1; half 0 holds frame taps dt = 0, 1, 2 (r = 5 dt + df, r = 15 unused), half 1 dt = 3, 4 (r = 5 (dt - 3) + df,
+// r >= 10 unused).
+bool pack_conv2_proj(const Tensor* w2, std::vector<uint16_t>& out) {
+  const size_t frag = 64 * 8;
+  out.assign(2 * frag, 0);
+  bool ok = true;
+  for (int lane = 0; lane < 64; ++lane)
+    for (int j = 0; j < 4; ++j) {
+      const int m = lane & 31, hk = lane >> 5;
+      const int r = (m & 3) + 4 * (m >> 3), half = (m >> 2) & 1;
+      const int dt = (half ? 3 : 0) + r / 5, df = r % 5, ch = 4 * hk + j;
+      const bool used = half ? r < 10 : r < 15;
+      const float v = used ? w2->data[(ch * 5 + dt) * 5 + df] : 0.f;
+      const uint16_t hi = f32_to_f16(v);
+      const float hif = f16_to_f32(hi);
+      if (!(std::fabs(hif) * 2048.0f < 65504.0f)) ok = false;
+      const size_t idx = (size_t)lane * 8 + j;
+      out[idx] = f32_to_f16(hif * 2048.0f);                 // x hi(c1)
+      out[idx + 4] = hi;                                    // x lo(c1) 2^11
+      out[frag + idx] = f32_to_f16((v - hif) * 2048.0f);    // x hi(c1); elements 4..7 stay zero
+    }
+  return ok;
+}
+
 // note_march16.hip: conv1 (1 -> 32, 7 x 7, stride (1, 3), models.py:270-278) and the (7, 3) head (282-289) as
 // v_mfma_f32_16x16x32_f16 A fragments, 18 x 64 lanes x (8 x f16): conv1 [kind][k-step s][block mb] at (4 kind + 2 s + mb),
 // conv2 [kind][block mb] at 12 + 2 kind + mb; kind 0 = hi 2^11, 1 = hi, 2 = lo 2^11 (the kernel adds all three products
@@ -893,7 +941,7 @@ void pack_filterbank_planes(const Tensor* re, const Tensor* im, std::vector<uint
 }
 
 int free_all(bp_handle h) {
-  float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->d_pl_bin_k, h->planes, h->d_note_wfrag, h->d_note_w16, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->d_onset_w16, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wmarch, h->d_d1_wrim, h->d_d1_wrimm, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
+  float* ptrs[] = {h->d_pl_tfrag, h->d_pl_bfrag, h->d_pl_bin_k, h->planes, h->d_note_wfrag, h->d_note_w16, h->d_note_wf32, h->d_onset_wfrag, h->d_onset_wf32, h->d_onset_wmx, h->d_onset_w16, h->zp, h->c1s, h->d_d1_wlds, h->d_d1_wfold, h->d_d1_wmarch, h->d_d1_wrim, h->d_d1_wrimm, h->d_d1_wfold_mx, h->d_d1_bias, h->d_d2_w, h->d_d2_wproj, h->d_lowpass, h->d_sqrt_len, h->d_fb_bfrag, h->d_c1_bfrag, h->d_c1_bias, h->d_o1_bfrag,
                    h->d_o1_bias, h->d_n1_bfrag, h->d_n1_bias, h->d_w_contour2, h->d_w_note2, h->d_w_onset2,
                    h->audio, h->pyr, h->lp, h->c1, h->contour, h->n1, h->note, h->o1, h->onset, h->track,
                    h->track_out, h->nd_buf, h->nd_tables, h->fb_scratch, h->pcm_dev, h->mono_dev, h->res_dev, reinterpret_cast<float*>(h->taps_dev)};
@@ -1042,7 +1090,7 @@ int run_chunk(bp_handle h, const float* audio_dev, int n, float* note_dev, float
       }
       BP_DOM_END(BP_STAGE_CONTOUR_CONV1);
       BP_MARK(BP_STAGE_CONTOUR_CONV1);
-      launch_contour_conv2(c1p, h->d_d2_w, h->b_contour2, contour_dev + (int64_t)w0 * kPlaneC, nw, h->n_cu, s);
+      launch_conv2(c1p, h->d_d2_w, h->d_d2_wproj, h->b_contour2, contour_dev + (int64_t)w0 * kPlaneC, nw, h->n_cu, wlo, s);
       BP_MARK(BP_STAGE_CONTOUR_CONV2);
     }
     launch_note(contour_dev, h->d_note_wfrag, h->d_note_w16, h->d_note_wf32, note_dev, n, h->n_cu, wlo, s);
@@ -1225,6 +1273,11 @@ int bp_create(const void* weights, size_t nbytes, int device_ordinal, unsigned f
       for (int dw = 0; dw < 5; ++dw)
         for (int c = 0; c < 8; ++c) w2t[(dt * 5 + dw) * 8 + c] = c2w->data[(c * 5 + dt) * 5 + dw];
     if ((rc = upload(h, vec(c1b), &h->d_d1_bias)) || (rc = upload(h, w2t, &h->d_d2_w))) return fail(rc);
+    if (!pack_conv2_proj(c2w, frag)) {
+      h->err = "bp_create: a contour conv2 weight is too large for the scaled f16 operand (|w| >= 31.98)";
+      return fail(BP_ERR_BAD_WEIGHTS);
+    }
+    if ((rc = upload(h, raw_of(frag), &h->d_d2_wproj))) return fail(rc);
 #ifdef BP_AB_KERNELS  // operand tables of the A/B conv1 kernels (conv_contour_direct.hip)
     pack_contour_direct(c1w, frag);
     if ((rc = upload(h, raw_of(frag), &h->d_d1_wlds))) return fail(rc);
@@ -2118,7 +2171,7 @@ int bp_run_stage(bp_handle h, int stage, const bp_stage_buffers* bf, int64_t n_w
           } else
 #endif
             launch_contour_conv1_march(bf->zp, h->d_d1_wmarch, h->d_d1_bias, h->c1s, n, h->n_cu, wlo, s);
-          launch_contour_conv2(h->c1s, h->d_d2_w, h->b_contour2, bf->contour, n, h->n_cu, s);
+          launch_conv2(h->c1s, h->d_d2_w, h->d_d2_wproj, h->b_contour2, bf->contour, n, h->n_cu, wlo, s);
         }
       }
       break;

@@ -1,9 +1,259 @@
 // Contour branch, second layer: Conv2D 8->1, 5x5, "same", sigmoid, FlattenFreqCh (basic_pitch/models.py:254-263,
 // nn.py:105-119), c1 -> contour.  conv1 leaves relu(conv1) channel-last in HBM (conv_contour_march.hip + conv_contour_rim.hip);
-// this kernel is HBM-paced: 1.48 MB read, 181,632 B written per window, 18.2 MFLOP on the f32 VALU.
+// the layer is HBM-paced: 1.48 MB read, 181,632 B written per window, 18.2 MFLOP.
+//
+// Round 6: `contour_conv2_proj_kernel` (the default) puts the channel contraction on the matrix cores; the round-2 vector
+// kernel `contour_conv2_kernel` (200 FMAs per output behind scalar tap loads: 58 % of its wave cycles in s_waitcnt, neither at
+// the HBM rate nor at the vector rate) stays in the A/B library behind BP_CONV2=valu.
+#include <stdlib.h>
+
 #include "bp_common.h"
 
 namespace bp {
+
+// ---------------------------------------------------------------------------------------------------------
+// conv2 as a TAP PROJECTION on the matrix cores (the decomposition of the note / onset heads): for every INPUT pixel
+//   P[tap (dt, df)][pixel] = sum_c W[dt][df][c] c1[pixel][c]        M = 25 taps (32 rows), K = 8 channels, N = 32 pixels
+// — K is the 8 channels: no Toeplitz padding, no im2col, no LDS staging.  out[t][f] = sum_taps P[dt, df][t + dt - 2][f + df - 2] is then 25 additions per output on the vector pipe
+// (the round-2 kernel: 200 FMAs).
+//   * B operand: lane (n = lane & 31, h = lane >> 5) holds channels 4 h .. 4 h + 3 of pixel n = the 16 bytes one
+//     global_load_dwordx4 brings (a wave-row of 32 pixels is 1 KB contiguous), split to f16 hi / lo in registers — every c1
+//     value is loaded and split exactly once per strip; A operand: the taps as two resident fragments (8 VGPRs), all three
+//     products into ONE accumulator at scale 2^11 (note_march16.hip) — packed along K, see the kernel.
+//   * C layout: lane half h = 0 holds frame taps dt = 0, 1, 2 (rows 5 dt + df), half 1 dt = 3, 4: marching down the frames a
+//     lane adds its taps into a chain of open output rows — X0 = P[dt0] + IN, X1 = X0' + P[dt1], X2 = X1' + P[dt2] —, half 0's
+//     finished three-tap sum crosses to half 1 (ds_bpermute lane ^ 32) as the IN of its two-tap chain, and the finished row
+//     leaves half 1 two frames later; the five frequency taps are four more ds_bpermute (lanes n - 2 .. n + 2; the two tiles of
+//     a strip hand over their edge pixels through the source lanes' select).
+//   * a work item is (16 windows, frame slab, strip of 64 columns of the flat (window, padded bin) index, 60 of them stored):
+//     the zero padding of "same" is c1's own pad columns, which sit between the windows in the flat index — no masks; rows
+//     outside the window contribute P = 0.
+// Roofline: HBM (1.48 MB in + 7 % strip overlap + 9 % slab halo, 182 KB out per window); matrix 4 instructions per 64 pixels.
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+constexpr int kP2Group = 16;                         // windows per flat index group
+constexpr int kP2Cols = kP2Group * kC1Row;           // 4288 flat columns per group
+constexpr int kP2Strip = 64, kP2Stride = 60;         // columns a wave reads / stores per row
+constexpr int kP2Strips = (kP2Cols + kP2Stride - 1) / kP2Stride;  // 72
+static_assert(kC1Pad == 2, "the pad columns of c1 are the zero padding of the 5-tap rows");
+
+struct Conv2ProjParams {
+  const float* c1;      // [n][172][kC1Row][8]
+  const uint4* wfrag;   // pack_conv2_proj: [A1 = hi 2^11 | hi][A2 = lo 2^11 | 0] x 64 lanes x (8 x f16)
+  float bias;
+  float* out;           // [n][172][264]
+  int n_windows;
+  int slab_rows;        // frames per slab
+  int n_slabs;          // slabs per window
+};
+
+#ifndef P2_OCC
+#define P2_OCC 4
+#endif
+constexpr int kP2Occ = P2_OCC;  // resident waves per SIMD the launch is cut for (and the register budget allows)
+
+// The instruction is v_mfma_f32_32x32x16_f16 with the three split-precision products packed along K: a lane's B operand is
+// [hi(c1[pixel][4 h .. 4 h + 3]) | lo 2^11 of the same four channels] — the 8 halves its own split leaves —, A1 = [w_hi 2^11 |
+// w_hi] gives hi_w hi_a + hi_w lo_a in ONE instruction, A2 = [w_lo 2^11 | 0] the third product against the same B: two
+// instructions of 32 cycles per 32 pixels (three v_mfma_f32_32x32x8_f16, the shape whose K is the 8 channels, cost 96).
+template <int V>
+struct P2Phase {
+  static constexpr int v = V;
+};
+
+template <bool WLO>
+__global__ __launch_bounds__(256, kP2Occ) void contour_conv2_proj_kernel(Conv2ProjParams p) {
+  const int lane = threadIdx.x & 63;
+  const int n = lane & 31, h = lane >> 5;
+  // XCD-aware order: workgroups go to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own L2.  Neighbouring
+  // strips read 4 columns in common and neighbouring slabs 4 rows: a contiguous run of work items (whole windows) goes to ONE
+  // XCD, so what two items share is fetched from HBM once, by one L2, instead of once per XCD that touches it.
+#ifdef P2_NO_XCD
+  const int lblock = (int)blockIdx.x;
+#else
+  const int lblock = (gridDim.x % 8 == 0) ? ((int)blockIdx.x % 8) * ((int)gridDim.x / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+#endif
+  const int64_t wg = (int64_t)lblock * 4 + wave_id();  // wave-uniform work item; whole waves only, no barrier
+  const int n_groups = (p.n_windows + kP2Group - 1) / kP2Group;
+  if (wg >= (int64_t)n_groups * p.n_slabs * kP2Strips) return;
+  const int strip = (int)(wg % kP2Strips);
+  const int slab = (int)((wg / kP2Strips) % p.n_slabs);
+#ifdef P2_FORWARD
+  const int group = (int)(wg / ((int64_t)kP2Strips * p.n_slabs));
+#else
+  // LAST windows first: conv1 wrote c1 in window order, so the windows it wrote last are the ones still in the 256 MB
+  // Infinity Cache when this launch starts — reading them first takes them from there before this launch's own traffic
+  // evicts them
+  const int group = n_groups - 1 - (int)(wg / ((int64_t)kP2Strips * p.n_slabs));
+#endif
+  const int ta = slab * p.slab_rows;
+  const int tb = ta + p.slab_rows < kFrames ? ta + p.slab_rows : kFrames;
+
+  const f16x8 a1 = __builtin_bit_cast(f16x8, p.wfrag[lane]);
+  const f16x8 a2 = __builtin_bit_cast(f16x8, WLO ? p.wfrag[64 + lane] : uint4{0u, 0u, 0u, 0u});
+
+  // this lane's pixel column of the two tiles: flat column 60 strip - 2 + 32 tile + n, clamped into the group (a clamped
+  // column is never stored and only ever feeds columns that are not stored either).  32-bit offsets from uniform bases.
+  uint32_t src_off[2], dst_off[2];
+  bool store[2];
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl) {
+    const int j = 32 * tl + n;
+    const int fc = kP2Stride * strip - 2 + j;
+    const int fcc = fc < 0 ? 0 : (fc > kP2Cols - 1 ? kP2Cols - 1 : fc);
+    const int wl = fcc / kC1Row, pb = fcc - wl * kC1Row;
+    const int win = group * kP2Group + wl;
+    const int winc = win < p.n_windows ? win : p.n_windows - 1;
+    src_off[tl] = (uint32_t)winc * (uint32_t)kC1Win + (uint32_t)(pb * 8 + 4 * h);  // floats: < 2^30 for <= 256 windows a launch
+    const bool ok = h == 1 && j >= 2 && j < 2 + kP2Stride && fc == fcc && win < p.n_windows && pb >= kC1Pad && pb < kC1Pad + kFreqC;
+    store[tl] = ok;
+    dst_off[tl] = ok ? (uint32_t)winc * (uint32_t)kPlaneC + (uint32_t)(pb - kC1Pad) : 0u;
+  }
+  const int xhalf4 = (lane ^ 32) * 4;
+  int sh4[4];  // ds_bpermute addresses of the frequency taps df = 0, 1, 3, 4: lane n + df - 2 of half 1
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sh4[k] = (32 + ((n + (k < 2 ? k - 2 : k - 1)) & 31)) * 4;
+  const float bias_s = p.bias * kLoScale;
+  const float sig_k = -1.44269504088896341f * kLoUnscale;
+  const float hmask = h ? 1.0f : 0.0f;  // half 0's chain starts at 0, half 1's at half 0's finished sum
+
+  float X0[2][5], X1[2][5], IN[2][5];
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+    for (int df = 0; df < 5; ++df) X0[tl][df] = X1[tl][df] = IN[tl][df] = 0.0f;
+
+  constexpr int kRowFloats = kC1Row * 8;
+  auto load = [&](int rho, int tl) {  // rows outside the window are never used: a row of it
+    const int rc = rho < 0 ? 0 : (rho > kFrames - 1 ? kFrames - 1 : rho);
+    const float* row = p.c1 + (int64_t)rc * kRowFloats;  // wave-uniform base
+    return *reinterpret_cast<const float4*>(row + src_off[tl]);
+  };
+  const int r_first = ta - 2, r_last = tb + 1;
+  // Three rows in flight ahead of the one in work, in three register sets whose roles rotate with the row (the loop is
+  // written out three times: a rotation by copies would make the copy wait for the load it moves — the first version ran
+  // with ONE row in flight per wave and 3,400 cycles per row, 3.8 TB/s).
+  float4 buf[3][2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) buf[k][tl] = load(r_first + k, tl);
+
+  auto step = [&](auto PH, int rho) {
+    constexpr int ph = decltype(PH)::v;
+    const int t = rho - 2;                // the output row half 1 completes now
+    const bool emit = t >= ta && t < tb;  // wave-uniform
+    float V[2][5];
+#ifdef P2_STREAM  // tools only: the launch's loads and stores without its arithmetic (the access pattern's own pace)
+    {
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        const float v = (buf[ph][tl].x + buf[ph][tl].y) + (buf[ph][tl].z + buf[ph][tl].w);
+        buf[ph][tl] = load(rho + 3, tl);
+#pragma unroll
+        for (int df = 0; df < 5; ++df) V[tl][df] = v;
+      }
+      if (emit) {
+        float* orow = p.out + (int64_t)t * kFreqC;
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+          if (store[tl]) orow[dst_off[tl]] = V[tl][2];
+      }
+      return;
+    }
+#endif
+    if (rho >= 0 && rho < kFrames) {  // wave-uniform
+      f16x8 b[2];
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        uint32_t h01, l01, h23, l23;
+        split_f16x2(f32x2{buf[ph][tl].x, buf[ph][tl].y}, h01, l01);
+        split_f16x2(f32x2{buf[ph][tl].z, buf[ph][tl].w}, h23, l23);
+        b[tl] = __builtin_bit_cast(f16x8, uint4{h01, h23, l01, l23});
+        buf[ph][tl] = load(rho + 3, tl);  // this set's next row
+      }
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 P = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[tl], zero16, 0, 0, 0);
+        if (WLO) P = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b[tl], P, 0, 0, 0);
+        // the chain of open output rows (half 0: dt = 0, 1, 2; half 1: dt = 3, 4 behind half 0's finished sum)
+#pragma unroll
+        for (int df = 0; df < 5; ++df) {
+          const float x2 = X1[tl][df] + P[10 + df];
+          const float x1 = X0[tl][df] + P[5 + df];
+          X0[tl][df] = __builtin_fmaf(IN[tl][df], hmask, P[df]);
+          X1[tl][df] = x1;
+          V[tl][df] = x1;  // half 1: all five frame taps of output row rho - 2
+          IN[tl][df] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(xhalf4, __builtin_bit_cast(int, x2)));
+        }
+      }
+    } else {  // a row outside the window is "same" padding: P = 0
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        buf[ph][tl] = load(rho + 3, tl);
+#pragma unroll
+        for (int df = 0; df < 5; ++df) {
+          const float x2 = X1[tl][df];
+          V[tl][df] = X1[tl][df] = X0[tl][df];
+          X0[tl][df] = IN[tl][df] * hmask;
+          IN[tl][df] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(xhalf4, __builtin_bit_cast(int, x2)));
+        }
+      }
+    }
+    if (emit) {
+      // out[n] = sum_df V[df][n + df - 2]; the tiles hand over their edge pixels: a source lane offers the other tile's value
+      // to the readers that wrap around
+      float y[2] = {V[0][2], V[1][2]};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int df = k < 2 ? k : k + 1, s = df - 2;
+        const float d0 = s > 0 ? (n < s ? V[1][df] : V[0][df]) : V[0][df];
+        const float d1 = s < 0 ? (n >= 32 + s ? V[0][df] : V[1][df]) : V[1][df];
+        y[0] += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sh4[k], __builtin_bit_cast(int, d0)));
+        y[1] += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sh4[k], __builtin_bit_cast(int, d1)));
+      }
+      float* orow = p.out + (int64_t)t * kFreqC;  // wave-uniform base
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl)
+        if (store[tl]) orow[dst_off[tl]] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((y[tl] + bias_s) * sig_k));
+    }
+  };
+  int rho = r_first;
+#pragma unroll 1
+  for (;;) {
+    step(P2Phase<0>{}, rho);
+    if (++rho > r_last) break;
+    step(P2Phase<1>{}, rho);
+    if (++rho > r_last) break;
+    step(P2Phase<2>{}, rho);
+    if (++rho > r_last) break;
+  }
+}
+
+void launch_contour_conv2_proj(const float* c1, const void* wfrag, float bias, float* contour, int n_windows, int n_cu,
+                               bool weights_have_lo, hipStream_t stream) {
+  // sub-batches of 256 windows, each cut into as many frame slabs as keep one launch within the resident waves
+  const int64_t slots = (int64_t)n_cu * 4 * kP2Occ;
+  const int per_launch = 256;
+  for (int w0 = 0; w0 < n_windows; w0 += per_launch) {
+    const int n = n_windows - w0 < per_launch ? n_windows - w0 : per_launch;
+    const int n_groups = (n + kP2Group - 1) / kP2Group;
+    int n_slabs = (int)(slots / ((int64_t)n_groups * kP2Strips));
+    n_slabs = n_slabs < 1 ? 1 : (n_slabs > 16 ? 16 : n_slabs);
+    const int slab_rows = (kFrames + n_slabs - 1) / n_slabs;
+    n_slabs = (kFrames + slab_rows - 1) / slab_rows;
+    Conv2ProjParams p{c1 + (int64_t)w0 * kC1Win, static_cast<const uint4*>(wfrag), bias, contour + (int64_t)w0 * kPlaneC, n,
+                      slab_rows, n_slabs};
+    const int64_t waves = (int64_t)n_groups * n_slabs * kP2Strips;
+    if (weights_have_lo)
+      hipLaunchKernelGGL(contour_conv2_proj_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL(contour_conv2_proj_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, p);
+  }
+}
+
+#ifdef BP_AB_KERNELS  // the round-2 vector kernel (BP_CONV2=valu)
 
 // ---------------------------------------------------------------------------------------------------------
 // conv2: Conv2D 8->1 5x5 + sigmoid as a march down the frames with ONE OUTPUT BIN PER LANE.
@@ -173,5 +423,7 @@ void launch_contour_conv2(const float* c1, const float* w2, float bias, float* c
                        p.out, p.n_windows, p.slab_rows, p.n_slabs);
   }
 }
+
+#endif  // BP_AB_KERNELS
 
 }  // namespace bp

@@ -807,7 +807,7 @@ def _ab_env(**switches):
     only exist in the A/B library (build.py: build_library(ab=True), -DBP_AB_KERNELS), which is built here if the tree
     does not hold a current one; with no switches, the product library."""
     e = dict(os.environ)
-    for k in ("BASIC_PITCH_AMD_LIB", "BP_ONSET", "BP_NOTE", "BP_CONV1", "BP_RIM", "BP_RESAMPLE", "BP_CONTOUR_PARTS"):
+    for k in ("BASIC_PITCH_AMD_LIB", "BP_ONSET", "BP_NOTE", "BP_CONV1", "BP_CONV2", "BP_RIM", "BP_RESAMPLE", "BP_CONTOUR_PARTS"):
         e.pop(k, None)
     if switches:
         from basic_pitch_amd import build as B
@@ -1100,6 +1100,26 @@ def test_rim_march_equals_rim_gemm(tmp_path):
     d = np.abs(outs["march"] - outs["gemm"])
     assert d.max() <= 2e-6, d.max()
     assert d[..., 24:240].max() == 0.0  # away from the rim nothing changed
+
+
+def test_conv2_projection_equals_the_vector_kernel(tmp_path):
+    """Contour conv2 as a tap projection on the matrix cores (conv_contour2.hip contour_conv2_proj_kernel, the default since
+    round 6: per input pixel 25 taps x 8 channels on v_mfma_f32_32x32x8_f16 with split operands, 25 additions per output) and
+    the round-2 vector kernel (200 fp32 FMAs per output, BP_CONV2=valu in the A/B library) compute the same sums in another
+    order: the contour maps of the whole contour stage (same conv1 kernels in both runs) agree to accumulation-order noise,
+    at the rim bins (c1's zero pad columns), the first / last frames and the slab cuts too."""
+    import subprocess
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "experiments", "contour_ab.py")
+    outs = {}
+    for name, env in (("proj", {}), ("valu", {"BP_CONV2": "valu"})):
+        out = str(tmp_path / f"{name}.npy")
+        subprocess.run([sys.executable, tool, out], check=True, env=_ab_env(**env), timeout=600)
+        outs[name] = np.load(out)
+    assert np.isfinite(outs["proj"]).all()
+    d = np.abs(outs["proj"] - outs["valu"]).max()
+    assert d <= 2e-6, d
 
 
 def test_note_march16_equals_note_march32(tmp_path):
