@@ -92,6 +92,18 @@ class bp_note_params(C.Structure):
     ]
 
 
+class bp_flac_stream_layout(C.Structure):
+    _fields_ = [
+        ("channels", C.c_int32),
+        ("sample_rate", C.c_int32),
+        ("bits_per_sample", C.c_int32),
+        ("min_block", C.c_int32),
+        ("max_block", C.c_int32),
+        ("n_frames", C.c_int64),
+        ("audio_start", C.c_int64),
+    ]
+
+
 class bp_transcribe_params(C.Structure):
     _fields_ = [
         ("notes", bp_note_params),
@@ -102,7 +114,8 @@ class bp_transcribe_params(C.Structure):
         ("threads", C.c_int32),
         ("host_decode", C.c_int32),
         ("direct_io", C.c_int32),
-        ("reserved", C.c_int32 * 2),
+        ("host_flac", C.c_int32),
+        ("reserved", C.c_int32 * 1),
     ]
 
 
@@ -175,6 +188,10 @@ EXPORTED_SYMBOLS = [
     "bp_notes_last_error",
     "bp_flac_info",
     "bp_flac_decode",
+    "bp_flac_layout",
+    "bp_flac_decode_device",
+    "bp_infer_flac",
+    "bp_infer_flac_candidates",
     "bp_audio_last_error",
     "bp_transcribe_params_default",
     "bp_transcribe_files",
@@ -236,6 +253,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bp_infer_pcm.restype = C.c_int
     lib.bp_infer_pcm_raw.argtypes = [vp, vp, C.c_int, i64, C.c_int, C.c_int, fp, fp, fp, C.c_int]
     lib.bp_infer_pcm_raw.restype = C.c_int
+    lib.bp_flac_layout.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(bp_flac_stream_layout)]
+    lib.bp_flac_layout.restype = C.c_int
+    lib.bp_flac_decode_device.argtypes = [vp, C.c_char_p, C.c_size_t, vp, i64, C.POINTER(i64)]
+    lib.bp_flac_decode_device.restype = C.c_int
+    lib.bp_infer_flac.argtypes = [vp, C.c_char_p, C.c_size_t, fp, fp, fp, C.c_int]
+    lib.bp_infer_flac.restype = C.c_int
     lib.bp_host_alloc.argtypes = [C.c_size_t]
     lib.bp_host_alloc.restype = C.c_void_p
     lib.bp_host_free.argtypes = [C.c_void_p]
@@ -327,6 +350,6 @@ def check(lib: C.CDLL, handle, rc: int, what: str) -> None:
         return
     msg = lib.bp_last_error(handle)
     text = f"{what}: {_ERR_NAMES.get(rc, rc)}: {msg.decode(errors='replace') if msg else ''}"
-    if rc in (-1, -2, -6):
+    if rc in (-1, -2, -6, -7):  # -7: undecodable audio (what audio.read_audio raises ValueError for)
         raise ValueError(text)  # reference: ValueError for bad model / bad shapes (inference.py:148-154)
     raise NativeLibraryError(text)

@@ -33,6 +33,7 @@ SOURCES = [
     "onset_march16.hip",
     "note_device.hip",
     "audio_ingest.hip",
+    "flac_device.hip",
     "note_decode.cpp",
     "flac_decode.cpp",
     "file_pipeline.cpp",

@@ -101,6 +101,29 @@ void launch_contour_conv2(const float* c1, const float* w2, float bias, float* c
 #endif
 void launch_contour_conv2_proj(const float* c1, const void* wfrag, float bias, float* contour, int n_windows, int n_cu,
                                bool weights_have_lo, hipStream_t stream);
+// flac_device.hip
+struct FdStream {
+  int channels, bits, min_block, max_block;
+  int64_t total;
+  uint32_t audio_start, nbytes;
+};
+struct FlacDeviceBuffers {
+  uint8_t* file = nullptr;
+  size_t file_cap = 0;
+  void* cands = nullptr;
+  uint32_t* counts = nullptr;
+  size_t cands_cap = 0, counts_cap = 0;
+  void* packed = nullptr;
+  uint32_t* offs = nullptr;
+  size_t packed_cap = 0, offs_cap = 0;
+  void* frames = nullptr;
+  int32_t* scratch = nullptr;
+  size_t frames_cap = 0, scratch_cap = 0;
+  int* meta = nullptr;
+  uint16_t* crc_tab = nullptr;
+};
+int flac_device_decode(FlacDeviceBuffers& b, const FdStream& st, void* d_pcm, hipStream_t stream);
+void flac_device_free(FlacDeviceBuffers& b);
 #ifdef BP_AB_KERNELS  // note_march.hip: the 32x32x16 form of the note march (A/B builds only)
 void launch_note_march(const float* contour, const void* wfrag, const float* wf32, float* note, int n_windows,
                        bool weights_have_lo, hipStream_t stream);
@@ -315,6 +338,8 @@ struct bp_context {
   float* nd_buf = nullptr;
   int64_t nd_cap = 0;          // floats
   float* nd_tables = nullptr;  // [88] int4 windows, [51] double Gaussian, then the stats record
+  FlacDeviceBuffers fd;            // flac_device.hip: the file's bytes, the frame lists, the scratch rows
+  int* fd_status_host = nullptr;   // page-locked: the device decoder's error bits of the last call
   float* nd_stats_host = nullptr;  // page-locked copy of the stats record
   void* nd_stats_host_dev = nullptr;  // the same buffer as the device sees it
   bool nd_stats_ready = false;     // the device record holds its initial values (the export kernel leaves it so)
@@ -953,6 +978,8 @@ int free_all(bp_handle h) {
       for (auto& e : row) (void)hipEventDestroy(e);
   if (h->done) (void)hipEventDestroy(h->done);
   if (h->nd_stats_host) (void)hipHostFree(h->nd_stats_host);
+  if (h->fd_status_host) (void)hipHostFree(h->fd_status_host);
+  flac_device_free(h->fd);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   return BP_OK;
 }
@@ -2025,6 +2052,153 @@ int bp_infer_pcm_raw_candidates(bp_handle h, const void* pcm, int format, int64_
   if (rc) return rc;
   float *d_note = h->track_out, *d_onset = d_note + T * 88, *d_contour = d_onset + T * 88;
   return candidates_core(h, d_note, d_onset, d_contour, T, params, note_out, cand_bits, bend_map, status);
+}
+
+// ---- FLAC decoded on the device (flac_device.hip) ---------------------------------------------------------------------------
+// The file's bytes to the device, the three decode launches queued on the handle's stream, the error bits on their way to a
+// page-locked word; *fmt / *lay describe the PCM now (being) written to h->pcm_dev.
+static int flac_to_device_pcm(bp_handle h, const void* file, size_t nbytes, bp_flac_stream_layout* lay, int* fmt) {
+  if (!file || nbytes < 42) {
+    h->err = "FLAC on the device: null or too short";
+    return BP_ERR_INVALID_ARG;
+  }
+  if (bp_flac_layout(file, nbytes, lay) != BP_OK) {
+    h->err = std::string("FLAC on the device: ") + bp_audio_last_error();
+    return BP_ERR_BAD_AUDIO;
+  }
+  if (lay->n_frames <= 0 || lay->min_block < 16 || lay->max_block < lay->min_block || lay->bits_per_sample > 24 ||
+      lay->bits_per_sample < 4 || lay->channels > 8 || nbytes >= ((size_t)1 << 31) ||
+      lay->n_frames * lay->channels >= ((int64_t)1 << 33)) {
+    h->err = "FLAC on the device: a stream the device decoder leaves to the host (no sample count / block sizes in STREAMINFO, "
+             "more than 24 bits or 8 channels, or 2 GB and more)";
+    return BP_ERR_UNSUPPORTED;
+  }
+  BP_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  if (!h->fd_status_host) BP_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->fd_status_host), 2 * sizeof(int), hipHostMallocPortable));
+  if (nbytes + 64 > h->fd.file_cap) {
+    if (h->fd.file) BP_HIP(hipFree(h->fd.file));
+    h->fd.file = nullptr, h->fd.file_cap = 0;
+    const size_t cap = nbytes + nbytes / 4 + 4096;
+    BP_HIP(hipMalloc(&h->fd.file, cap));
+    h->fd.file_cap = cap;
+  }
+  BP_HIP(hipMemcpyAsync(h->fd.file, file, nbytes, hipMemcpyHostToDevice, s));
+  BP_HIP(hipMemsetAsync(h->fd.file + nbytes, 0, 64, s));
+  const int wide = lay->bits_per_sample > 16;
+  *fmt = wide ? BP_PCM_S32 : BP_PCM_S16;
+  const int64_t bytes = lay->n_frames * lay->channels * (wide ? 4 : 2);
+  int rc = grow(h, &h->pcm_dev, &h->pcm_cap, (bytes + 3) / 4);
+  if (rc) return rc;
+  FdStream st{lay->channels, lay->bits_per_sample, lay->min_block, lay->max_block, lay->n_frames, (uint32_t)lay->audio_start,
+              (uint32_t)nbytes};
+  if (flac_device_decode(h->fd, st, h->pcm_dev, s) != 0) {
+    h->err = "FLAC on the device: allocation or launch failed";
+    (void)hipGetLastError();
+    return BP_ERR_HIP;
+  }
+  BP_HIP(hipMemcpyAsync(h->fd_status_host, h->fd.meta, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  return BP_OK;
+}
+
+// after the stream has been waited for: what the decode kernels reported
+static int flac_device_verdict(bp_handle h) {
+  const int st = h->fd_status_host ? h->fd_status_host[0] : 0;
+  if (st == 0) return BP_OK;
+  h->err = std::string("FLAC on the device: the stream could not be decoded (") + ((st & 2) ? "frame chain " : "") +
+           ((st & 4) ? "CRC-16 " : "") + ((st & 8) ? "reserved value / overrun " : "") + ((st & 16) ? "candidate overflow " : "") +
+           "); the host decoder (bp_flac_decode) reports the cause";
+  return BP_ERR_BAD_AUDIO;
+}
+
+int bp_flac_decode_device(bp_handle h, const void* file, size_t nbytes, int32_t* pcm, int64_t capacity_frames, int64_t* n_frames) {
+  if (!h || !n_frames) return BP_ERR_INVALID_ARG;
+  bp_flac_stream_layout lay;
+  int fmt = 0;
+  int rc = flac_to_device_pcm(h, file, nbytes, &lay, &fmt);
+  if (rc) return rc;
+  rc = wait_stream(h);
+  if (rc) return rc;
+  rc = flac_device_verdict(h);
+  if (rc) return rc;
+  *n_frames = lay.n_frames;
+  if (!pcm) return BP_OK;
+  if (capacity_frames < lay.n_frames) {
+    h->err = "bp_flac_decode_device: the output buffer is too small";
+    return BP_ERR_INVALID_ARG;
+  }
+  const int64_t n = lay.n_frames * lay.channels;
+  if (fmt == BP_PCM_S32) {
+    BP_HIP(hipMemcpy(pcm, h->pcm_dev, (size_t)n * 4, hipMemcpyDeviceToHost));
+    const int sh = 32 - lay.bits_per_sample;
+    for (int64_t i = 0; i < n; ++i) pcm[i] >>= sh;  // left-justified on the device
+  } else {
+    std::vector<int16_t> tmp((size_t)n);
+    BP_HIP(hipMemcpy(tmp.data(), h->pcm_dev, (size_t)n * 2, hipMemcpyDeviceToHost));
+    const int sh = 16 - lay.bits_per_sample;
+    for (int64_t i = 0; i < n; ++i) pcm[i] = (int32_t)tmp[(size_t)i] >> sh;
+  }
+  return BP_OK;
+}
+
+int bp_infer_flac(bp_handle h, const void* file, size_t nbytes, float* note, float* onset, float* contour, int mem_kind) {
+  if (!h) return BP_ERR_INVALID_ARG;
+  bp_flac_stream_layout lay;
+  int fmt = 0;
+  int rc = flac_to_device_pcm(h, file, nbytes, &lay, &fmt);
+  if (rc) return rc;
+  const float* d = nullptr;
+  int64_t n = 0;
+  rc = ingest(h, h->pcm_dev, fmt, lay.n_frames, lay.channels, lay.sample_rate, BP_MEM_DEVICE, &d, &n);
+  if (rc) return rc;
+  if (h_track_n_windows(h, n) == 0) {
+    rc = wait_stream(h);
+    return rc ? rc : flac_device_verdict(h);
+  }
+  if (h_track_n_frames(h, n) > 0 && (!note || !onset || !contour)) {
+    h->err = "bp_infer_flac: null output pointer";
+    return BP_ERR_INVALID_ARG;
+  }
+  rc = track_core(h, d, n, note, onset, contour, mem_kind);
+  if (rc) return rc;
+  if (mem_kind != BP_MEM_HOST) {
+    rc = wait_stream(h);
+    if (rc) return rc;
+  }
+  return flac_device_verdict(h);
+}
+
+int bp_infer_flac_candidates(bp_handle h, const void* file, size_t nbytes, const bp_note_params* params, float* note_out,
+                             uint8_t* cand_bits, int8_t* bend_map, int* status) {
+  if (!h) return BP_ERR_INVALID_ARG;
+  if (!params || !status) {
+    h->err = "bp_infer_flac_candidates: null params / status";
+    return BP_ERR_INVALID_ARG;
+  }
+  bp_flac_stream_layout lay;
+  int fmt = 0;
+  int rc = flac_to_device_pcm(h, file, nbytes, &lay, &fmt);
+  if (rc) return rc;
+  const float* d = nullptr;
+  int64_t n = 0;
+  rc = ingest(h, h->pcm_dev, fmt, lay.n_frames, lay.channels, lay.sample_rate, BP_MEM_DEVICE, &d, &n);
+  if (rc) return rc;
+  *status = 0;
+  const int64_t T = h_track_n_frames(h, n);
+  if (h_track_n_windows(h, n) == 0 || T == 0) {
+    rc = wait_stream(h);
+    return rc ? rc : flac_device_verdict(h);
+  }
+  if (!note_out || !cand_bits) {
+    h->err = "bp_infer_flac_candidates: null output pointer";
+    return BP_ERR_INVALID_ARG;
+  }
+  rc = track_core(h, d, n, nullptr, nullptr, nullptr, kTrackOutInternal);
+  if (rc) return rc;
+  float *d_note = h->track_out, *d_onset = d_note + T * 88, *d_contour = d_onset + T * 88;
+  rc = candidates_core(h, d_note, d_onset, d_contour, T, params, note_out, cand_bits, bend_map, status);
+  if (rc) return rc;
+  return flac_device_verdict(h);
 }
 
 void* bp_host_alloc(size_t bytes) {

@@ -755,6 +755,26 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
       int channels = 0, sr = 0, format = BP_PCM_F32;
       int64_t n_frames = 0;
       const void* pcm = nullptr;
+      bool flac_on_device = false;
+      auto host_flac_decode = [&]() -> bool {  // the host decoder (flac_decode.cpp): float32 samples in `decoded`
+        int bits = 0;
+        if (bp_flac_info(fb, n_bytes, &channels, &sr, &bits, &n_frames) != BP_OK) {
+          set_report(rep, BP_ERR_BAD_AUDIO, path + ": " + bp_audio_last_error());
+          return false;
+        }
+        if (!decoded.ensure((size_t)(n_frames * channels) * sizeof(float) + 4)) {
+          set_report(rep, BP_ERR_OUT_OF_MEMORY, path + ": " + g_file_error);
+          return false;
+        }
+        int64_t got = 0;
+        if (bp_flac_decode(fb, n_bytes, static_cast<float*>(decoded.p), n_frames, &got) != BP_OK || got != n_frames) {
+          set_report(rep, BP_ERR_BAD_AUDIO, path + ": " + bp_audio_last_error());
+          return false;
+        }
+        pcm = decoded.p;
+        format = BP_PCM_F32;
+        return true;
+      };
       if (n_bytes >= 12 && std::memcmp(fb, "RIFF", 4) == 0 && std::memcmp(fb + 8, "WAVE", 4) == 0) {
         WavInfo w;
         if (!wav_parse(fb, n_bytes, w)) {
@@ -764,21 +784,17 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
         // the samples go to the device as the file stores them (bp_infer_pcm_raw converts there)
         channels = w.channels, sr = w.sample_rate, n_frames = w.n_frames, pcm = w.pcm, format = wav_pcm_format(w);
       } else if (n_bytes >= 4 && (std::memcmp(fb, "fLaC", 4) == 0 || std::memcmp(fb, "ID3", 3) == 0)) {
-        int bits = 0;
-        if (bp_flac_info(fb, n_bytes, &channels, &sr, &bits, &n_frames) != BP_OK) {
-          set_report(rep, BP_ERR_BAD_AUDIO, path + ": " + bp_audio_last_error());
+        // FLAC: the file's BYTES go to the device and are decoded there (flac_device.hip) — no core-time per sample here,
+        // half the PCIe bytes of the PCM — unless the stream is one the device decoder leaves to the host (no sample count
+        // or block sizes in STREAMINFO, more than 24 bits / 8 channels) or params.host_flac asks for the host decoder
+        bp_flac_stream_layout lay;
+        if (!prm.host_flac && bp_flac_layout(fb, n_bytes, &lay) == BP_OK && lay.n_frames > 0 && lay.min_block >= 16 &&
+            lay.max_block >= lay.min_block && lay.bits_per_sample <= 24 && lay.bits_per_sample >= 4 && lay.channels <= 8) {
+          flac_on_device = true;
+          channels = lay.channels, sr = lay.sample_rate, n_frames = lay.n_frames;
+        } else if (!host_flac_decode()) {
           continue;
         }
-        if (!decoded.ensure((size_t)(n_frames * channels) * sizeof(float) + 4)) {
-          set_report(rep, BP_ERR_OUT_OF_MEMORY, path + ": " + g_file_error);
-          continue;
-        }
-        int64_t got = 0;
-        if (bp_flac_decode(fb, n_bytes, static_cast<float*>(decoded.p), n_frames, &got) != BP_OK || got != n_frames) {
-          set_report(rep, BP_ERR_BAD_AUDIO, path + ": " + bp_audio_last_error());
-          continue;
-        }
-        pcm = decoded.p;
       } else {
         set_report(rep, BP_ERR_BAD_AUDIO, path + ": not a WAV or FLAC file (the native pipeline reads RIFF/WAVE and FLAC)");
         continue;
@@ -798,24 +814,40 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
       int8_t* bend_map = reinterpret_cast<int8_t*>(cand_bits + ((T * BP_NOTE_CAND_ROW_BYTES + 15) & ~(int64_t)15));
       bool use_cand = !prm.host_decode && prm.notes.onset_threshold > 0.0;
       rep->ms_read = lap();
-      const int lane = acquire();
-      rep->ms_lane_wait = lap();
-      bp_handle h = handles[lane];
       int rc = BP_OK;
       std::string err;
-      if (T > 0) {
-        if (use_cand) {
-          int status = 0;
-          rc = bp_infer_pcm_raw_candidates(h, pcm, format, n_frames, channels, sr, &prm.notes, note, cand_bits,
-                                           prm.notes.include_pitch_bends ? bend_map : nullptr, &status);
-          if (rc == BP_OK && status != 0) use_cand = false;  // a NaN in the maps: numpy's rules need the maps themselves
+      bool reported = false;
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        const int lane = acquire();
+        rep->ms_lane_wait += lap();
+        bp_handle h = handles[lane];
+        rc = BP_OK;
+        if (T > 0) {
+          if (use_cand) {
+            int status = 0;
+            rc = flac_on_device ? bp_infer_flac_candidates(h, fb, n_bytes, &prm.notes, note, cand_bits,
+                                                           prm.notes.include_pitch_bends ? bend_map : nullptr, &status)
+                                : bp_infer_pcm_raw_candidates(h, pcm, format, n_frames, channels, sr, &prm.notes, note, cand_bits,
+                                                              prm.notes.include_pitch_bends ? bend_map : nullptr, &status);
+            if (rc == BP_OK && status != 0) use_cand = false;  // a NaN in the maps: numpy's rules need the maps themselves
+          }
+          if (rc == BP_OK && !use_cand)
+            rc = flac_on_device ? bp_infer_flac(h, fb, n_bytes, note, onset, contour, BP_MEM_HOST)
+                                : bp_infer_pcm_raw(h, pcm, format, n_frames, channels, sr, note, onset, contour, BP_MEM_HOST);
+          if (rc != BP_OK) err = bp_last_error(h);
         }
-        if (rc == BP_OK && !use_cand)
-          rc = bp_infer_pcm_raw(h, pcm, format, n_frames, channels, sr, note, onset, contour, BP_MEM_HOST);
-        if (rc != BP_OK) err = bp_last_error(h);
+        release(lane);
+        rep->ms_device += lap();
+        if (!(flac_on_device && (rc == BP_ERR_BAD_AUDIO || rc == BP_ERR_UNSUPPORTED))) break;
+        // the device decoder could not follow the stream: the host decoder either decodes it or names the fault
+        flac_on_device = false;
+        if (!host_flac_decode()) {
+          reported = true;
+          break;
+        }
+        rep->ms_read += lap();
       }
-      release(lane);
-      rep->ms_device = lap();
+      if (reported) continue;
       if (rc != BP_OK) {
         set_report(rep, rc, path + ": " + err);
         continue;

@@ -262,6 +262,7 @@ struct Md5 {
 
 struct StreamInfo {
   int sample_rate = 0, channels = 0, bits = 0;
+  int min_block = 0, max_block = 0;
   int64_t total = 0;
   uint8_t md5[16] = {0};
   size_t audio_start = 0;
@@ -296,6 +297,8 @@ bool parse_header(const uint8_t* d, size_t n, StreamInfo& si) {
         return false;
       }
       const uint8_t* s = d + pos;
+      si.min_block = (s[0] << 8) | s[1];
+      si.max_block = (s[2] << 8) | s[3];
       si.sample_rate = (s[10] << 12) | (s[11] << 4) | (s[12] >> 4);
       si.channels = ((s[12] >> 1) & 7) + 1;
       si.bits = (((s[12] & 1) << 4) | (s[13] >> 4)) + 1;
@@ -599,6 +602,20 @@ int bp_flac_decode(const void* file, size_t nbytes, float* pcm, int64_t capacity
   }
   StreamInfo si;
   return decode(static_cast<const uint8_t*>(file), nbytes, pcm, capacity_frames, si, n_frames);
+}
+
+int bp_flac_layout(const void* file, size_t nbytes, bp_flac_stream_layout* out) {
+  if (!file || !out) {
+    g_err = "bp_flac_layout: null argument";
+    return BP_ERR_INVALID_ARG;
+  }
+  StreamInfo si;
+  if (!parse_header(static_cast<const uint8_t*>(file), nbytes, si)) return BP_ERR_BAD_AUDIO;
+  out->channels = si.channels, out->sample_rate = si.sample_rate, out->bits_per_sample = si.bits;
+  out->min_block = si.min_block, out->max_block = si.max_block;
+  out->n_frames = si.total;
+  out->audio_start = (int64_t)si.audio_start;
+  return BP_OK;
 }
 
 const char* bp_audio_last_error(void) { return g_err.c_str(); }

@@ -1,0 +1,652 @@
+// FLAC decode on the device (round 6; SURVEY.md 8(f) rank 2: "WAV/FLAC decode").  The container half of
+// `librosa.load(path, sr=22050, mono=True)` (basic_pitch/inference.py:239; README.md:182-189 lists .flac) for the file job:
+// the host decoder (flac_decode.cpp) sustains ~80 M samples per second and core — five three-minute stereo files per second
+// and core against the ~1,400 a GPU transcribes — and FLAC halves the bytes a file costs on the storage device, in host
+// DRAM and on PCIe, which are what an 8-GPU file job runs out of first.
+//
+// The format (RFC 9639) is serial inside a frame — a Rice code's position is the sum of the lengths of all codes before
+// it, a subframe starts where the previous one ends, linear prediction is a recurrence — and independent from frame to
+// frame, each frame beginning on a byte boundary with a sync code and a CRC-8-protected header that carries its own
+// position in the stream.  So the FILE's bytes go to the device as they are, and three launches decode them:
+//   1. flac_scan_kernel     every byte position that looks like a frame header (sync code, no reserved value, sample size
+//                           and channel count of STREAMINFO, CRC-8 right) becomes a candidate (offset, coded number,
+//                           block size), kept in file order (a workgroup owns 64 KB of the file and a slice of the list);
+//   2. flac_chain_kernel    one workgroup compacts the candidates in file order and keeps those that continue their
+//                           predecessor or are continued by their successor (coded number + 1 / sample number + block
+//                           size): a sync pattern inside compressed data passes the CRC-8 once in ~10^7 bytes and the number
+//                           check practically never — and if it did, the chain as a whole or the frame's CRC-16 fails and
+//                           the call reports the file as not decodable here;
+//   3. flac_decode_kernel   ONE LANE PER FRAME: subframe headers, Rice / escaped residuals from a 64-bit register bit buffer,
+//                           prediction (constant, verbatim, fixed order 0..4, LPC order 1..32 with 64-bit sums; the last 32
+//                           samples of the lane in LDS), wasted bits, the stereo decorrelations, the frame's CRC-16 (eight
+//                           bytes per step, tables in LDS); the channels as coded go to scratch rows;
+//   4. flac_finalize_kernel the parallel tail, a thread per sample: stereo decorrelation and the interleaved 16- or 32-bit
+//                           PCM the ingest kernels read (audio_ingest.hip downmix_raw_kernel) — bit for bit what the host
+//                           decoder produces.  A three-minute stereo file is ~1,940 frames = 31 waves; the serial decode of
+//                           a frame sets the latency of the call (~1 - 2 ms), not the throughput of the job, whose lanes
+//                           keep several files in flight.
+// Not decoded here (status BP_FLACDEV_UNSUPPORTED, the caller uses the host decoder): streams without a sample count or
+// block sizes in STREAMINFO, more than 24 bits per sample, more than 8 channels.  The MD5 of STREAMINFO is not checked on
+// the device (one serial pass over the whole stream); every frame's CRC-16 and the stream's sample count are.
+#include <stdint.h>
+#include <stdio.h>
+
+#include "bp_common.h"
+
+namespace bp {
+
+enum : int {
+  kFdOk = 0,
+  kFdUnsupported = 1,   // a feature the device decoder leaves to the host
+  kFdChain = 2,         // frames missing / out of order / sample count differs from STREAMINFO
+  kFdCrc16 = 4,         // a frame's CRC-16 does not match
+  kFdParse = 8,         // reserved value, overrun or inconsistent subframe
+  kFdOverflow = 16,     // more candidates in a 64 KB chunk than the list holds
+};
+
+constexpr int kFdChunk = 65536;      // bytes of the file a scan workgroup owns
+constexpr int kFdChunkCands = 512;   // candidates a chunk may hold (a frame is >= ~14 bytes; real streams: a handful)
+
+struct FdCand {
+  uint32_t offset;     // of the sync code
+  uint32_t blocksize;
+  uint64_t number;     // coded frame number (fixed block size) or sample number (variable)
+  uint32_t hdr_bytes;  // header length including the CRC-8
+  uint32_t flags;      // bit 0: variable block size; bits 4..7: channel assignment code
+};
+
+struct FdFrame {
+  uint32_t offset, end;  // the frame's bytes: [offset, end) (end = the next frame's offset or the file's end)
+  uint32_t blocksize, hdr_bytes;
+  int64_t first_sample;
+  uint32_t ch_code, pad;
+};
+
+struct FdStream {
+  int channels, bits, min_block, max_block;
+  int64_t total;       // samples per channel
+  uint32_t audio_start, nbytes;
+};
+
+__device__ __forceinline__ uint8_t fd_crc8(const uint8_t* d, int n) {
+  uint32_t c = 0;
+  for (int i = 0; i < n; ++i) {
+    c ^= d[i];
+    for (int b = 0; b < 8; ++b) c = (c & 0x80) ? ((c << 1) ^ 0x07) & 0xff : (c << 1) & 0xff;
+  }
+  return (uint8_t)c;
+}
+
+// A frame header at d[0..] (at least 16 readable bytes)?  Fills the candidate; RFC 9639 section 9.1.
+__device__ bool fd_parse_header(const uint8_t* d, const FdStream& st, FdCand& c) {
+  if (d[0] != 0xff || (d[1] & 0xfe) != 0xf8) return false;
+  const int variable = d[1] & 1;
+  const int bs_code = d[2] >> 4, sr_code = d[2] & 15, ch_code = d[3] >> 4, sz_code = (d[3] >> 1) & 7;
+  if ((d[3] & 1) || bs_code == 0 || sr_code == 15 || ch_code > 10 || sz_code == 3) return false;
+  int p = 4;
+  const int lead = d[p++];
+  uint64_t number = 0;
+  if (lead & 0x80) {
+    int extra = 0;
+    while (extra < 7 && (lead & (0x40 >> extra))) ++extra;
+    if (extra == 0 || extra > 6) return false;
+    number = lead & (0x3f >> extra);
+    for (int i = 0; i < extra; ++i) {
+      if ((d[p] & 0xc0) != 0x80) return false;
+      number = (number << 6) | (d[p++] & 0x3f);
+    }
+  } else {
+    number = (uint64_t)lead;
+  }
+  int blocksize;
+  if (bs_code == 1) blocksize = 192;
+  else if (bs_code <= 5) blocksize = 576 << (bs_code - 2);
+  else if (bs_code == 6) blocksize = d[p++] + 1;
+  else if (bs_code == 7) { blocksize = ((d[p] << 8) | d[p + 1]) + 1; p += 2; }
+  else blocksize = 256 << (bs_code - 8);
+  if (sr_code == 12) p += 1;
+  else if (sr_code == 13 || sr_code == 14) p += 2;
+  const int sz_table[8] = {0, 8, 12, 0, 16, 20, 24, 32};
+  const int bits = sz_code ? sz_table[sz_code] : st.bits;
+  const int n_ch = ch_code < 8 ? ch_code + 1 : 2;
+  if (bits != st.bits || n_ch != st.channels) return false;
+  if (blocksize > st.max_block) return false;
+  if (fd_crc8(d, p) != d[p]) return false;
+  c.blocksize = (uint32_t)blocksize;
+  c.number = number;
+  c.hdr_bytes = (uint32_t)(p + 1);
+  c.flags = (uint32_t)variable | ((uint32_t)ch_code << 4);
+  return true;
+}
+
+// ---- 1. candidates, in file order ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flac_scan_kernel(const uint8_t* __restrict__ file, FdStream st, FdCand* __restrict__ cands,
+                                                        uint32_t* __restrict__ counts, int* __restrict__ status) {
+  __shared__ FdCand found[kFdChunkCands];
+  __shared__ uint32_t n_found;
+  if (threadIdx.x == 0) n_found = 0;
+  __syncthreads();
+  const uint32_t chunk0 = st.audio_start + blockIdx.x * (uint32_t)kFdChunk;
+  const uint32_t per = kFdChunk / 256;
+  const uint32_t a = chunk0 + threadIdx.x * per;
+  // the file's buffer is padded with zeros: a header read may run up to 16 bytes past the end
+  for (uint32_t p = a; p < a + per && p + 2 <= st.nbytes; ++p) {
+    if (file[p] != 0xff) continue;
+    FdCand c;
+    if (!fd_parse_header(file + p, st, c)) continue;
+    c.offset = p;
+    const uint32_t slot = atomicAdd(&n_found, 1u);
+    if (slot < kFdChunkCands) found[slot] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t n = n_found;
+    if (n > kFdChunkCands) {
+      atomicOr(status, kFdOverflow);
+      n = kFdChunkCands;
+    }
+    for (uint32_t i = 1; i < n; ++i) {  // a handful: insertion sort by offset
+      const FdCand c = found[i];
+      uint32_t j = i;
+      for (; j > 0 && found[j - 1].offset > c.offset; --j) found[j] = found[j - 1];
+      found[j] = c;
+    }
+    counts[blockIdx.x] = n;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n_found && i < kFdChunkCands; i += 256) cands[(size_t)blockIdx.x * kFdChunkCands + i] = found[i];
+}
+
+// ---- 2. the chain of real frames ---------------------------------------------------------------------------------------------
+// One workgroup, everything parallel (the first version — one lane walking the candidates through global memory — took 1.2 ms
+// of a 3-minute file's 4 ms): offsets of the chunks' slices by a block scan, the candidates compacted in file order, a
+// candidate kept iff it continues its predecessor or is continued by its successor (coded number + 1, or sample number +
+// block size: a false sync code passes the CRC-8 once in ~10^7 bytes and then carries an arbitrary number), the kept ones
+// compacted into frames, and the chain checked as a whole: frame k starts at sample k x block size (or where frame k - 1
+// ended), the first at 0, the last reaches STREAMINFO's count.  Anything else is kFdChain: the host decoder takes the file.
+constexpr int kFdChainThreads = 1024;
+
+__device__ __forceinline__ uint32_t fd_block_scan(uint32_t v, uint32_t* lds, uint32_t* total) {  // exclusive, 1024 threads
+  const int t = threadIdx.x;
+  lds[t] = v;
+  __syncthreads();
+  for (int d = 1; d < kFdChainThreads; d <<= 1) {
+    const uint32_t x = t >= d ? lds[t - d] : 0u;
+    __syncthreads();
+    lds[t] += x;
+    __syncthreads();
+  }
+  const uint32_t incl = lds[t];
+  *total = lds[kFdChainThreads - 1];
+  __syncthreads();
+  return incl - v;
+}
+
+__global__ __launch_bounds__(kFdChainThreads) void flac_chain_kernel(const FdCand* __restrict__ cands, const uint32_t* __restrict__ counts,
+                                                                     int n_chunks, FdStream st, FdCand* __restrict__ packed,
+                                                                     uint32_t* __restrict__ offs, FdFrame* __restrict__ frames,
+                                                                     int max_frames, int* __restrict__ n_frames,
+                                                                     int* __restrict__ status) {
+  __shared__ uint32_t lds[kFdChainThreads];
+  __shared__ uint32_t carry_s;
+  const int t = threadIdx.x;
+  // (a) offsets of the chunks' slices
+  uint32_t carry = 0;
+  for (int base = 0; base < n_chunks; base += kFdChainThreads) {
+    const int ch = base + t;
+    const uint32_t c = ch < n_chunks ? counts[ch] : 0u;
+    uint32_t tot;
+    const uint32_t ex = fd_block_scan(c, lds, &tot);
+    if (ch < n_chunks) offs[ch] = carry + ex;
+    carry += tot;
+  }
+  const uint32_t n_cand = carry;
+  // (b) candidates in file order
+  for (int ch = t / 32; ch < n_chunks; ch += kFdChainThreads / 32) {
+    const uint32_t c = counts[ch], o = offs[ch];
+    for (uint32_t i = t & 31; i < c; i += 32) packed[o + i] = cands[(size_t)ch * kFdChunkCands + i];
+  }
+  __threadfence_block();
+  __syncthreads();
+  const uint32_t variable = n_cand ? (packed[0].flags & 1u) : 0u;
+  auto follows = [&](const FdCand& a, const FdCand& b) {  // b is the frame right behind a
+    if ((a.flags & 1u) != variable || (b.flags & 1u) != variable) return false;
+    return variable ? b.number == a.number + a.blocksize : b.number == a.number + 1;
+  };
+  // (c) + (d) kept candidates -> frames
+  carry = 0;
+  for (uint32_t base = 0; base < n_cand; base += kFdChainThreads) {
+    const uint32_t j = base + t;
+    bool good = false;
+    FdCand c{};
+    if (j < n_cand) {
+      c = packed[j];
+      good = (j > 0 && follows(packed[j - 1], c)) || (j + 1 < n_cand && follows(c, packed[j + 1])) || n_cand == 1;
+    }
+    uint32_t tot;
+    const uint32_t idx = carry + fd_block_scan(good ? 1u : 0u, lds, &tot);
+    if (good && (int)idx < max_frames) {
+      FdFrame f;
+      f.offset = c.offset, f.end = st.nbytes, f.blocksize = c.blocksize, f.hdr_bytes = c.hdr_bytes;
+      f.first_sample = variable ? (int64_t)c.number : (int64_t)c.number * (int64_t)packed[0].blocksize;
+      f.ch_code = c.flags >> 4, f.pad = 0;
+      frames[idx] = f;
+    }
+    carry += tot;
+  }
+  const uint32_t n = carry;
+  __threadfence_block();
+  __syncthreads();
+  if (t == 0) {
+    carry_s = 0;
+    *n_frames = (int)(n < (uint32_t)max_frames ? n : (uint32_t)max_frames);
+  }
+  __syncthreads();
+  // (e) a frame ends where the next begins; the chain as a whole
+  bool bad = n == 0 || (int)n > max_frames;
+  for (uint32_t k = t; k < n && (int)k < max_frames; k += kFdChainThreads) {
+    const FdFrame f = frames[k];
+    if (k + 1 < n) {
+      const FdFrame g = frames[k + 1];
+      frames[k].end = g.offset;
+      if (f.first_sample + (int64_t)f.blocksize != g.first_sample) bad = true;
+    } else if (f.first_sample + (int64_t)f.blocksize < st.total) {
+      bad = true;
+    }
+    if (k == 0 && f.first_sample != 0) bad = true;
+  }
+  if (bad) atomicOr(status, kFdChain);
+}
+
+// ---- 3. one lane per frame -----------------------------------------------------------------------------------------------------
+// The stream as 32-bit words: `hi` and `lo` hold the next 64 bits, `o` of `hi`'s are consumed, `nx` is the word behind them,
+// loaded two refills ahead of its use (a lane is alone on its chain: nothing else hides a load's latency).  A peek is one
+// funnel shift, a skip an add and — every 32 bits — a rotation of the three words; no 64-bit shifts on the serial path.
+struct FdBits {
+  const uint8_t* base;
+  uint32_t pos;  // byte offset of the next word to LOAD
+  uint32_t hi, lo, nx;  // nx as loaded (little-endian): swapped when it moves up, so that nothing touches a word before the
+                        // load that brings it has had two refills' time
+  int o;         // bits of `hi` already consumed, 0..31
+  __device__ __forceinline__ uint32_t ld_raw(uint32_t off) const {
+    uint32_t w;
+    __builtin_memcpy(&w, base + off, 4);
+    return w;
+  }
+  __device__ __forceinline__ void init(const uint8_t* b, uint32_t off) {
+    base = b, o = 0;
+    hi = __builtin_bswap32(ld_raw(off)), lo = __builtin_bswap32(ld_raw(off + 4)), nx = ld_raw(off + 8);
+    pos = off + 12;
+  }
+  __device__ __forceinline__ uint32_t peek() const {  // the next 32 bits
+    return o ? __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(32 - o)) : hi;
+  }
+  __device__ __forceinline__ void skip(int n) {  // n <= 32
+    o += n;
+    if (o >= 32) {
+      hi = lo, lo = __builtin_bswap32(nx);
+      nx = ld_raw(pos);
+      pos += 4;
+      o -= 32;
+    }
+  }
+  __device__ __forceinline__ uint32_t bits(int k) {  // k <= 32
+    if (k == 0) return 0;
+    const uint32_t v = peek() >> (32 - k);
+    skip(k);
+    return v;
+  }
+  __device__ __forceinline__ int32_t sbits(int k) {  // k <= 32
+    if (k == 0) return 0;
+    const int32_t v = (int32_t)peek() >> (32 - k);  // arithmetic: sign-extends
+    skip(k);
+    return v;
+  }
+  __device__ __forceinline__ uint32_t unary() {  // zeros before the next one
+    uint32_t q = 0;
+    for (;;) {
+      const uint32_t w = peek();
+      if (w) {
+        const int lz = __builtin_clz(w);
+        skip(lz + 1);
+        return q + (uint32_t)lz;
+      }
+      skip(32);
+      q += 32;
+      if (q > (1u << 13)) return q;  // a run no encoder writes (the zero padding behind the file, a misread stream): the caller's
+                                     // position check ends the frame
+    }
+  }
+  // one Rice code: the whole code inside the 32-bit window (every code of ordinary audio) is one peek
+  __device__ __forceinline__ int32_t rice(int k) {
+    const uint32_t w = peek();
+    const int lz = w ? __builtin_clz(w) : 32;
+    uint32_t v;
+    if (lz + 1 + k <= 32) {
+      const uint32_t rem = k ? (w << ((lz + 1) & 31)) >> (32 - k) : 0u;
+      skip(lz + 1 + k);
+      v = ((uint32_t)lz << k) | rem;
+    } else {
+      const uint32_t q = unary();
+      v = (q << k) | bits(k);
+    }
+    return (int32_t)(v >> 1) ^ -(int32_t)(v & 1);
+  }
+  __device__ __forceinline__ uint32_t byte_pos() const { return pos - 12 + (uint32_t)(o >> 3); }  // of the next unread bit
+  __device__ __forceinline__ uint32_t bytes_consumed_aligned() {  // after dropping the bits up to the next byte boundary
+    if (o & 7) skip(8 - (o & 7));
+    return byte_pos();
+  }
+};
+
+// Linear prediction with the history in registers, as float64: a sample has <= 25 bits, a coefficient <= 15, a sum of <= 12
+// products stays far below 2^53 — every operation is exact — and floor(sum 2^-shift) is the reference's arithmetic shift.
+// (The vector pipe runs v_fma_f64 at a fraction of the cost of the 64-bit integer multiply-adds it replaces, and the
+// history moves down by register copies, no addressing.)  The generic path below (LDS ring, 64-bit integers) takes the orders
+// above 12.
+template <int ORD>
+struct FdLpc {
+  double c[ORD], h[ORD];  // h[0] = s[i - 1]
+  double scale;           // 2^-shift
+  __device__ __forceinline__ int32_t step(int32_t res) {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j = 0; j + 1 < ORD; j += 2) {
+      a0 = __builtin_fma(c[j], h[j], a0);
+      a1 = __builtin_fma(c[j + 1], h[j + 1], a1);
+    }
+    if (ORD & 1) a0 = __builtin_fma(c[ORD - 1], h[ORD - 1], a0);
+    const int32_t pred = (int32_t)__builtin_floor((a0 + a1) * scale);
+    const int32_t v = (int32_t)((uint32_t)res + (uint32_t)pred);
+#pragma unroll
+    for (int j = ORD - 1; j > 0; --j) h[j] = h[j - 1];
+    h[0] = (double)v;
+    return v;
+  }
+};
+
+struct FdDecodeParams {
+  const uint8_t* file;
+  const FdFrame* frames;
+  const int* n_frames;
+  FdStream st;
+  int32_t* scratch;   // [max_frames][channels][max_block] int32: every channel of a frame as coded (wasted bits restored)
+  void* pcm;          // interleaved output: int16 (bits <= 16) or int32 (left-justified) samples
+  int out_shift;      // sample << out_shift fills the output word
+  int out_wide;       // 0: int16, 1: int32
+  int* status;
+  const uint16_t* crc_tab;  // [8][256]
+};
+
+constexpr int kFdLanes = 64;  // lanes (frames) per workgroup: one wave
+
+__global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p) {
+  __shared__ int32_t hist[32][kFdLanes];   // the lane's last 32 restored samples, a ring
+  __shared__ int32_t coefs[32][kFdLanes];
+  __shared__ uint16_t crc[8][256];
+  for (int i = threadIdx.x; i < 8 * 256; i += kFdLanes) crc[i >> 8][i & 255] = p.crc_tab[i];
+  __syncthreads();
+  const int lane = threadIdx.x;
+  const int f = blockIdx.x * kFdLanes + lane;
+  if (f >= *p.n_frames) return;
+  const FdFrame fr = p.frames[f];
+  const int bs = (int)fr.blocksize, n_ch = p.st.channels;
+  int err = 0;
+
+  FdBits br;
+  br.init(p.file, fr.offset + fr.hdr_bytes);
+  int32_t* scr = p.scratch + (size_t)f * p.st.max_block * n_ch;
+  const uint32_t guard = fr.end + 16;  // a lane that reads past this has lost the stream
+
+  for (int c = 0; c < n_ch && !err; ++c) {
+    const bool side = (fr.ch_code == 8 && c == 1) || (fr.ch_code == 9 && c == 0) || (fr.ch_code == 10 && c == 1);
+    int bps = p.st.bits + (side ? 1 : 0);
+    if (br.bits(1)) err |= kFdParse;
+    const int type = (int)br.bits(6);
+    int wasted = 0;
+    if (br.bits(1)) wasted = (int)br.unary() + 1;
+    bps -= wasted;
+    if (bps <= 0 || bps > 32) {
+      err |= kFdParse;
+      break;
+    }
+    int32_t* row = scr + (size_t)c * p.st.max_block;
+    // predictor of this subframe: order, shift, coefficients in LDS (fixed predictors are LPC with binomial coefficients)
+    int order = 0, shift = 0;
+    if (type == 0) {  // constant
+      const int32_t v = (int32_t)((uint32_t)br.sbits(bps) << wasted);
+      for (int i = 0; i < bs; ++i) row[i] = v;
+      continue;
+    }
+    if (type == 1) {  // verbatim
+      for (int i = 0; i < bs && br.pos <= guard; ++i) row[i] = (int32_t)((uint32_t)br.sbits(bps) << wasted);
+      if (br.pos > guard) err |= kFdParse;
+      continue;
+    }
+    if (type >= 8 && type <= 12) {
+      order = type - 8;
+      const int fx[5][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {2, -1, 0, 0}, {3, -3, 1, 0}, {4, -6, 4, -1}};
+      for (int j = 0; j < order; ++j) coefs[j][lane] = fx[order][j];
+    } else if (type >= 32) {
+      order = type - 31;
+    } else {
+      err |= kFdParse;
+      break;
+    }
+    if (order > bs) {
+      err |= kFdParse;
+      break;
+    }
+    for (int i = 0; i < order; ++i) {
+      const int32_t v = br.sbits(bps);
+      hist[i & 31][lane] = v;
+      row[i] = (int32_t)((uint32_t)v << wasted);
+    }
+    if (type >= 32) {
+      const int prec = (int)br.bits(4) + 1;
+      shift = br.sbits(5);
+      if (prec == 16 || shift < 0) {
+        err |= kFdParse;
+        break;
+      }
+      for (int j = 0; j < order; ++j) coefs[j][lane] = br.sbits(prec);
+    }
+    // residual (RFC 9639 section 9.2.7): partitions of Rice codes or escaped raw values
+    const int method = (int)br.bits(2);
+    if (method > 1) {
+      err |= kFdParse;
+      break;
+    }
+    const int pbits = method ? 5 : 4, esc = method ? 31 : 15;
+    const int porder = (int)br.bits(4);
+    const int parts = 1 << porder;
+    if ((bs & (parts - 1)) || (bs >> porder) < order) {
+      err |= kFdParse;
+      break;
+    }
+    int i = order;
+    // the subframe's residual + prediction, partition by partition; `restore` is the predictor (registers for orders <= 12)
+    auto run = [&](auto&& restore) {
+      for (int part = 0; part < parts; ++part) {
+        const int count = (bs >> porder) - (part == 0 ? order : 0);
+        const int k = (int)br.bits(pbits);
+        if (k == esc) {
+          const int raw = (int)br.bits(5);
+          for (int j = 0; j < count && br.pos <= guard; ++j, ++i) row[i] = (int32_t)((uint32_t)restore(br.sbits(raw)) << wasted);
+        } else {
+          for (int j = 0; j < count && br.pos <= guard; ++j, ++i) row[i] = (int32_t)((uint32_t)restore(br.rice(k)) << wasted);
+        }
+        if (br.pos > guard) {  // ran off the frame (corrupt): never read far behind the file's buffer
+          err |= kFdParse;
+          break;
+        }
+      }
+    };
+    auto run_regs = [&](auto lpc) {
+      constexpr int ORD = sizeof(lpc.c) / sizeof(double);
+#pragma unroll
+      for (int j = 0; j < ORD; ++j) {
+        lpc.c[j] = j < order ? (double)coefs[j][lane] : 0.0;
+        lpc.h[j] = j < order ? (double)hist[(order - 1 - j) & 31][lane] : 0.0;
+      }
+      lpc.scale = __builtin_ldexp(1.0, -shift);
+      run([&](int32_t res) { return lpc.step(res); });
+    };
+    if (order == 0) {
+      run([&](int32_t res) { return res; });
+    } else if (order <= 4) {
+      run_regs(FdLpc<4>());
+    } else if (order <= 8) {
+      run_regs(FdLpc<8>());
+    } else if (order <= 12) {
+      run_regs(FdLpc<12>());
+    } else {
+      run([&](int32_t res) {
+        // s[i] = res + (sum_j coef[j] s[i - 1 - j]) >> shift with 64-bit wrapping sums (flac_decode.cpp lpc_restore_n)
+        uint64_t acc = 0;
+        for (int j2 = 0; j2 < order; ++j2)
+          acc += (uint64_t)((int64_t)coefs[j2][lane] * (int64_t)hist[(i - 1 - j2) & 31][lane]);
+        const int32_t v = (int32_t)((uint32_t)res + (uint32_t)((int64_t)acc >> shift));
+        hist[i & 31][lane] = v;
+        return v;
+      });
+    }
+  }
+  if (!err) {
+    // the frame's CRC-16 over [offset, aligned end), eight bytes per step (flac_decode.cpp crc16)
+    const uint32_t body_end = br.bytes_consumed_aligned();
+    if (body_end + 2 > fr.end || body_end <= fr.offset) {
+      err |= kFdParse;
+    } else {
+      const uint8_t* d = p.file + fr.offset;
+      const uint32_t n = body_end - fr.offset;
+      uint32_t cc = 0, i = 0;
+      for (; i + 8 <= n; i += 8) {
+        uint32_t w0, w1;
+        __builtin_memcpy(&w0, d + i, 4);
+        __builtin_memcpy(&w1, d + i + 4, 4);
+        cc = crc[7][((cc >> 8) ^ w0) & 0xff] ^ crc[6][((cc & 0xff) ^ (w0 >> 8)) & 0xff] ^ crc[5][(w0 >> 16) & 0xff] ^ crc[4][w0 >> 24] ^
+             crc[3][w1 & 0xff] ^ crc[2][(w1 >> 8) & 0xff] ^ crc[1][(w1 >> 16) & 0xff] ^ crc[0][w1 >> 24];
+      }
+      for (; i < n; ++i) cc = ((cc << 8) & 0xffff) ^ crc[0][((cc >> 8) ^ d[i]) & 0xff];
+      const uint32_t want = ((uint32_t)p.file[body_end] << 8) | p.file[body_end + 1];
+      if ((cc & 0xffff) != want) err |= kFdCrc16;
+      // the next frame must begin right behind the CRC (the last frame may be followed by padding / tags)
+      if (body_end + 2 != fr.end && f + 1 < *p.n_frames) err |= kFdChain;
+    }
+  }
+#ifdef FD_DEBUG
+  if (err || f < 2) printf("FDDBG frame %d off %u end %u bs %d err %d pos %u\n", f, fr.offset, fr.end, bs, err, br.pos);
+#endif
+  if (err) atomicOr(p.status, err);
+}
+
+// ---- 4. the parallel tail: stereo decorrelation (RFC 9639 section 4.2) and the interleaved output words ------------------------
+__global__ __launch_bounds__(256) void flac_finalize_kernel(FdDecodeParams p) {
+  const int f = blockIdx.y;
+  if (f >= *p.n_frames) return;
+  const FdFrame fr = p.frames[f];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int64_t keep = fr.first_sample + fr.blocksize <= p.st.total ? (int64_t)fr.blocksize : (p.st.total - fr.first_sample);
+  if (i >= keep) return;
+  const int n_ch = p.st.channels;
+  const int32_t* scr = p.scratch + (size_t)f * p.st.max_block * n_ch;
+  const int64_t o = (fr.first_sample + i) * n_ch;
+  if (n_ch == 2) {
+    int32_t a = scr[i], b = scr[p.st.max_block + i];  // channel 0, channel 1 as coded
+    if (fr.ch_code == 8) {         // left / side
+      b = (int32_t)((uint32_t)a - (uint32_t)b);
+    } else if (fr.ch_code == 9) {  // side / right
+      a = (int32_t)((uint32_t)a + (uint32_t)b);
+    } else if (fr.ch_code == 10) {  // mid / side
+      const int64_t side_v = b, mid = ((int64_t)a << 1) + (side_v & 1);
+      a = (int32_t)((mid + side_v) >> 1);
+      b = (int32_t)((mid - side_v) >> 1);
+    }
+    if (p.out_wide) {
+      static_cast<int32_t*>(p.pcm)[o] = (int32_t)((uint32_t)a << p.out_shift);
+      static_cast<int32_t*>(p.pcm)[o + 1] = (int32_t)((uint32_t)b << p.out_shift);
+    } else {
+      static_cast<int16_t*>(p.pcm)[o] = (int16_t)((uint32_t)a << p.out_shift);
+      static_cast<int16_t*>(p.pcm)[o + 1] = (int16_t)((uint32_t)b << p.out_shift);
+    }
+  } else {
+    for (int c = 0; c < n_ch; ++c) {
+      const int32_t v = scr[(size_t)c * p.st.max_block + i];
+      if (p.out_wide) static_cast<int32_t*>(p.pcm)[o + c] = (int32_t)((uint32_t)v << p.out_shift);
+      else static_cast<int16_t*>(p.pcm)[o + c] = (int16_t)((uint32_t)v << p.out_shift);
+    }
+  }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------------------
+struct FlacDeviceBuffers {  // (the same layout is declared in bp_api.hip)
+  uint8_t* file = nullptr;      // the file's bytes + 64 zero bytes
+  size_t file_cap = 0;
+  void* cands = nullptr;        // FdCand [chunks][kFdChunkCands]
+  uint32_t* counts = nullptr;
+  size_t cands_cap = 0, counts_cap = 0;
+  void* packed = nullptr;       // FdCand, in file order
+  uint32_t* offs = nullptr;
+  size_t packed_cap = 0, offs_cap = 0;
+  void* frames = nullptr;       // FdFrame
+  int32_t* scratch = nullptr;
+  size_t frames_cap = 0, scratch_cap = 0;
+  int* meta = nullptr;          // [0] status, [1] n_frames
+  uint16_t* crc_tab = nullptr;
+};
+
+static int fd_grow(void** p, size_t* cap, size_t want, size_t elem) {
+  if (want <= *cap) return 0;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr, *cap = 0;
+  const size_t n = want + want / 4 + 64;
+  if (hipMalloc(p, n * elem) != hipSuccess) return -1;
+  *cap = n;
+  return 0;
+}
+
+// Decode the FLAC stream at `d_file` (already on the device, padded with >= 64 zero bytes) into interleaved PCM at `d_pcm`
+// (int16 when bits <= 16, else int32 left-justified).  Asynchronous on `stream`; *status (device) receives the error bits.
+int flac_device_decode(FlacDeviceBuffers& b, const FdStream& st, void* d_pcm, hipStream_t stream) {
+  const int n_chunks = (int)((st.nbytes - st.audio_start + kFdChunk - 1) / kFdChunk);
+  const int64_t max_frames = (st.total + st.min_block - 1) / st.min_block + 1;
+  if (fd_grow(&b.cands, &b.cands_cap, (size_t)n_chunks * kFdChunkCands, sizeof(FdCand))) return -1;
+  if (fd_grow(reinterpret_cast<void**>(&b.counts), &b.counts_cap, (size_t)n_chunks, sizeof(uint32_t))) return -1;
+  if (fd_grow(&b.packed, &b.packed_cap, (size_t)n_chunks * kFdChunkCands, sizeof(FdCand))) return -1;
+  if (fd_grow(reinterpret_cast<void**>(&b.offs), &b.offs_cap, (size_t)n_chunks, sizeof(uint32_t))) return -1;
+  if (fd_grow(&b.frames, &b.frames_cap, (size_t)max_frames, sizeof(FdFrame))) return -1;
+  const size_t rows = (size_t)max_frames * st.max_block * st.channels;
+  if (fd_grow(reinterpret_cast<void**>(&b.scratch), &b.scratch_cap, rows, sizeof(int32_t))) return -1;
+  if (!b.meta && hipMalloc(&b.meta, 2 * sizeof(int)) != hipSuccess) return -1;
+  if (!b.crc_tab) {
+    uint16_t tab[8][256];
+    for (int i = 0; i < 256; ++i) {
+      uint16_t c = (uint16_t)(i << 8);
+      for (int k = 0; k < 8; ++k) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : c << 1);
+      tab[0][i] = c;
+    }
+    for (int k = 1; k < 8; ++k)
+      for (int i = 0; i < 256; ++i) tab[k][i] = (uint16_t)((tab[k - 1][i] << 8) ^ tab[0][tab[k - 1][i] >> 8]);
+    if (hipMalloc(&b.crc_tab, sizeof tab) != hipSuccess) return -1;
+    if (hipMemcpy(b.crc_tab, tab, sizeof tab, hipMemcpyHostToDevice) != hipSuccess) return -1;
+  }
+  if (hipMemsetAsync(b.meta, 0, 2 * sizeof(int), stream) != hipSuccess) return -1;
+  hipLaunchKernelGGL(flac_scan_kernel, dim3(n_chunks), dim3(256), 0, stream, b.file, st, static_cast<FdCand*>(b.cands), b.counts, b.meta);
+  hipLaunchKernelGGL(flac_chain_kernel, dim3(1), dim3(kFdChainThreads), 0, stream, static_cast<const FdCand*>(b.cands), b.counts, n_chunks,
+                     st, static_cast<FdCand*>(b.packed), b.offs, static_cast<FdFrame*>(b.frames), (int)max_frames, b.meta + 1, b.meta);
+  FdDecodeParams p{b.file, static_cast<const FdFrame*>(b.frames), b.meta + 1, st, b.scratch, d_pcm, st.bits <= 16 ? 16 - st.bits : 32 - st.bits,
+                   st.bits <= 16 ? 0 : 1, b.meta, b.crc_tab};
+  hipLaunchKernelGGL(flac_decode_kernel, dim3((unsigned)((max_frames + kFdLanes - 1) / kFdLanes)), dim3(kFdLanes), 0, stream, p);
+  hipLaunchKernelGGL(flac_finalize_kernel, dim3((unsigned)((st.max_block + 255) / 256), (unsigned)max_frames), dim3(256), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+void flac_device_free(FlacDeviceBuffers& b) {
+  void* ptrs[] = {b.file, b.cands, b.counts, b.packed, b.offs, b.frames, b.scratch, b.meta, b.crc_tab};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  b = FlacDeviceBuffers();
+}
+
+}  // namespace bp

@@ -376,6 +376,41 @@ class Model:
         _native.check(self._lib, self._handle, rc, "bp_infer_pcm_raw")
         return out
 
+    def flac_layout(self, data: bytes) -> Dict[str, int]:
+        """STREAMINFO of a FLAC file's bytes (host, no decoding): channels, sample_rate, bits_per_sample, block sizes,
+        n_frames (0: not in the header)."""
+        lay = _native.bp_flac_stream_layout()
+        rc = self._lib.bp_flac_layout(data, len(data), C.byref(lay))
+        if rc != _native.BP_OK:
+            raise ValueError(f"bp_flac_layout: {self._lib.bp_audio_last_error().decode(errors='replace')}")
+        return {k: int(getattr(lay, k)) for k, _ in lay._fields_}
+
+    def flac_decode_device(self, data: bytes) -> Tuple[np.ndarray, int]:
+        """A FLAC file's bytes decoded ON THE DEVICE (csrc/flac_device.hip): (int32 samples [n_frames, channels], sample
+        rate) — the integers the host decoder's floats are made of.  ValueError if the stream cannot be decoded there
+        (`NativeLibraryError` BP_ERR_UNSUPPORTED for what is left to the host decoder)."""
+        lay = self.flac_layout(data)
+        pcm = np.empty((max(0, lay["n_frames"]), lay["channels"]), dtype=np.int32)
+        n = C.c_int64(0)
+        rc = self._lib.bp_flac_decode_device(self._handle, data, len(data), pcm.ctypes.data if pcm.size else None, pcm.shape[0], C.byref(n))
+        _native.check(self._lib, self._handle, rc, "bp_flac_decode_device")
+        return pcm[: n.value], lay["sample_rate"]
+
+    def predict_flac(self, data: bytes) -> Dict[str, np.ndarray]:
+        """The posteriorgrams of a FLAC file's bytes: decode on the device, then what predict_pcm_raw does (bp_infer_flac)."""
+        lay = self.flac_layout(data)
+        n22 = int(self._lib.bp_handle_resampled_length(self._handle, lay["n_frames"], lay["sample_rate"]))
+        T = int(self._lib.bp_handle_track_n_frames(self._handle, n22))
+        out = {
+            "note": np.empty((T, N_FREQ_BINS_NOTES), dtype=np.float32),
+            "onset": np.empty((T, N_FREQ_BINS_NOTES), dtype=np.float32),
+            "contour": np.empty((T, N_FREQ_BINS_CONTOURS), dtype=np.float32),
+        }
+        rc = self._lib.bp_infer_flac(self._handle, data, len(data), out["note"].ctypes.data, out["onset"].ctypes.data,
+                                     out["contour"].ctypes.data, _native.BP_MEM_HOST)
+        _native.check(self._lib, self._handle, rc, "bp_infer_flac")
+        return out
+
     # -- introspection ----------------------------------------------------------------------------
     def info(self) -> Dict[str, Any]:
         inf = _native.bp_info()
@@ -505,6 +540,22 @@ def run_inference(
                (1, 32): _native.BP_PCM_S32, (3, 32): _native.BP_PCM_F32, (3, 64): _native.BP_PCM_F64}[(tag, bits)]
         n_file_frames = len(raw) // (bits // 8) // channels
         unwrapped_output = model.predict_pcm_raw(raw, fmt, n_file_frames, channels, file_sr)
+    elif head[:4] == b"fLaC" and hasattr(model, "predict_flac"):
+        # a FLAC file's BYTES go to the device and are decoded there (csrc/flac_device.hip): half the PCIe bytes of the PCM and
+        # no host core-time per sample; what the device decoder leaves to the host (or cannot follow) is decoded here as
+        # before — the host decoder also names the fault of a corrupt file
+        with open(audio_path, "rb") as f:
+            blob = f.read()
+        try:
+            lay = model.flac_layout(blob)
+            if lay["n_frames"] <= 0:
+                raise _native.NativeLibraryError("no sample count in STREAMINFO")
+            unwrapped_output = model.predict_flac(blob)
+            n_file_frames, file_sr = lay["n_frames"], lay["sample_rate"]
+        except (ValueError, _native.NativeLibraryError):
+            pcm, file_sr = _audio.read_audio(str(audio_path))
+            n_file_frames = pcm.shape[0]
+            unwrapped_output = model.predict_pcm(pcm, file_sr)
     else:
         pcm, file_sr = _audio.read_audio(str(audio_path))
         n_file_frames = pcm.shape[0]
@@ -944,6 +995,7 @@ def transcribe_files(
     devices: Optional[Sequence[int]] = None,
     host_decode: bool = False,
     direct_io: bool = False,
+    host_flac: bool = False,
 ) -> List[Dict[str, Any]]:
     """The batch job of `predict_and_save` (inference.py:509-604) for WAV / FLAC input and MIDI / note-event output, run
     natively: ONE call into the library (`bp_transcribe_files`, csrc/file_pipeline.cpp), C++ worker threads from the
@@ -981,6 +1033,7 @@ def transcribe_files(
         prm.save_midi, prm.save_notes, prm.threads = int(bool(save_midi)), int(bool(save_notes)), int(threads)
         prm.host_decode = int(bool(host_decode))
         prm.direct_io = int(bool(direct_io))
+        prm.host_flac = int(bool(host_flac))  # FLAC files: decoded on the device unless asked otherwise
         handles = (C.c_void_p * len(models))(*[m._handle for m in models])
         cpaths = (C.c_char_p * max(1, n))(*paths)
         reports = (_native.bp_file_report * max(1, n))()

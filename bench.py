@@ -55,7 +55,7 @@ D1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 264 * 8 * 4  # zp read + c1 written
 HBM_PEAK_GBS = 8000.0
 DTYPE_F16 = "f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands, all three products of every layer on f16 MFMA"
 DTYPE_DEFAULT = DTYPE_F16  # since round 3 the default IS the all-f16 split (fp32-class)
-PMC_PROFILE = "r05_e"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
+PMC_PROFILE = "r06_a"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
 
 
 def pmc_traffic(kernel_key: str, batch: int):
@@ -218,6 +218,14 @@ def run_files(args, torch=None, dist=None, world: int = 1, rank: int = 0, local_
     with tempfile.TemporaryDirectory() as d:
         paths = []
         distinct = min(args.files, 32)  # the rest are hard links to these (same bytes, another name): 0.4 s of numpy per file
+        synth = None
+        if args.flac:
+            # a FLAC copy of the corpus: tools/flac_synth.c (LPC order 8 + Rice partitions, like a real encoder's output) is
+            # compiled here; the product itself has no encoder
+            import subprocess
+
+            synth = os.path.join(d, "flac_synth")
+            subprocess.run(["gcc", "-O2", "-o", synth, os.path.join(ROOT, "tools", "flac_synth.c"), "-lm"], check=True)
         for i in range(args.files):
             p = os.path.join(d, f"f{i}.wav")
             if i >= distinct:
@@ -233,6 +241,21 @@ def run_files(args, torch=None, dist=None, world: int = 1, rank: int = 0, local_
                 w.setframerate(44100)
                 w.writeframes(pcm.tobytes())
             paths.append(p)
+        if synth:
+            import subprocess
+
+            flac_paths = []
+            for i, p in enumerate(paths):
+                q = p[:-4] + ".flac"
+                if i >= distinct:
+                    os.link(flac_paths[i % distinct], q)
+                else:
+                    subprocess.run([synth, p, q], check=True, stderr=subprocess.DEVNULL)
+                flac_paths.append(q)
+            flac_bytes = os.path.getsize(flac_paths[0])
+            for p in paths:
+                os.unlink(p)
+            paths = flac_paths
         model = Model(device=local_rank, max_windows=256)
         windows = sum(int(model._lib.bp_track_n_windows(int(np.ceil(n / 2)))) for _ in paths)
         per_rank = None
@@ -247,7 +270,7 @@ def run_files(args, torch=None, dist=None, world: int = 1, rank: int = 0, local_
             out_dir, warm_dir = os.path.join(d, "out"), os.path.join(d, "warm")
             os.mkdir(out_dir)
             os.mkdir(warm_dir)
-            kw = dict(models=lanes, threads=threads, host_decode=args.host_decode, direct_io=args.direct_io)
+            kw = dict(models=lanes, threads=threads, host_decode=args.host_decode, direct_io=args.direct_io, host_flac=args.host_flac)
             transcribe_files(paths[: min(8, len(paths))], warm_dir, **kw)  # warm-up
             if args.cold_files:
                 # the corpus does not sit in the page cache: written back, then dropped from it (the distinct files; the rest
@@ -287,6 +310,9 @@ def run_files(args, torch=None, dist=None, world: int = 1, rank: int = 0, local_
                        "direct_io_requested": bool(args.direct_io),
                        "files_read_with_o_direct": int(lanes[0]._lib.bp_files_direct_reads()) - direct_before,
                        "cold_files": bool(args.cold_files), "distinct_files": distinct, "tmp_dir": d}
+            if args.flac:
+                io_note["flac"] = {"decoder": "host (bp_flac_decode)" if args.host_flac else "device (flac_device.hip)",
+                                   "bytes_per_file": flac_bytes, "wav_bytes_per_file": file_bytes}
             for m in lanes:
                 m.close()
             back = ("all three posteriorgrams back (27.6 MB per file), note decoding on the host" if args.host_decode else
@@ -346,7 +372,7 @@ def run_files(args, torch=None, dist=None, world: int = 1, rank: int = 0, local_
         "metric": f"files/sec end-to-end predict() (decode + resample + CQT + CNN + note decoding), {world} MI355X",
         "value": n_all / el, "unit": "files/s", "n_gpus": world, "higher_is_better": True, "data": "synthetic",
         "audio_seconds_per_s": n_all * args.file_seconds / el, "windows_per_s": windows / el,
-        "config": {"workload": f"{n_all} synthetic 16-bit stereo 44.1 kHz WAV files ({min(len(paths), 32)} distinct signals per rank) of {args.file_seconds:g} s through "
+        "config": {"workload": f"{n_all} synthetic 16-bit stereo 44.1 kHz {'FLAC' if args.flac else 'WAV'} files ({min(len(paths), 32)} distinct signals per rank) of {args.file_seconds:g} s through "
                    + how, "host_threads": min(16, os.cpu_count() or 1), "note_events": n_events,
                    "sharding": "sharding.plan_shards (LPT over the files' sizes), no collective on the data path"},
         **extra,
@@ -467,6 +493,9 @@ def main() -> None:
     ap.add_argument("--native", action="store_true",
                     help="--workload files: the native pipeline (bp_transcribe_files: C++ worker threads, no Python in the loop)")
     ap.add_argument("--lanes", type=int, default=3, help="--native: GPU lanes (handles) the workers queue for")
+    ap.add_argument("--flac", action="store_true",
+                    help="--workload files --native: the corpus as FLAC (encoded here by tools/flac_synth.c), decoded on the device")
+    ap.add_argument("--host-flac", action="store_true", help="--flac: decode on the host (bp_flac_decode) instead")
     ap.add_argument("--direct-io", action="store_true",
                     help="--native: read the files with O_DIRECT straight into the page-locked buffers (no page-cache copy)")
     ap.add_argument("--cold-files", action="store_true",

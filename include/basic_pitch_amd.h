@@ -219,6 +219,27 @@ void bp_host_free(void* p);
 int bp_flac_info(const void* file, size_t nbytes, int* channels, int* sample_rate, int* bits_per_sample,
                  int64_t* n_frames);
 int bp_flac_decode(const void* file, size_t nbytes, float* pcm, int64_t capacity_frames, int64_t* n_frames);
+
+/* FLAC decode ON THE DEVICE (round 6; csrc/flac_device.hip): the file's bytes go over PCIe as they are (about half the PCM's)
+ * and three launches decode them — a scan for frame headers (sync code + CRC-8 + STREAMINFO's sample size / channel count), a
+ * one-lane walk that keeps the chain of consecutive frame / sample numbers, and one lane per frame for the serial part (Rice
+ * residuals, prediction, stereo decorrelation, CRC-16) — into the interleaved 16- / 32-bit PCM the ingest kernels read.  The
+ * samples are bit-identical to bp_flac_decode's.  What it leaves to the host decoder (BP_ERR_UNSUPPORTED): streams whose
+ * STREAMINFO lacks the sample count or the block sizes, more than 24 bits per sample, more than 8 channels; a stream the
+ * device cannot follow (lost chain, CRC-16 mismatch, reserved values) is BP_ERR_BAD_AUDIO — the host decoder then says
+ * why.  The MD5 of STREAMINFO is not checked on the device; every frame's CRC-16 and the sample count are.
+ *   bp_flac_layout          STREAMINFO without decoding (host): what the device call needs to size its buffers
+ *   bp_flac_decode_device   the samples back on the host as interleaved int32 (sign-extended): the test / tool entry
+ *   bp_infer_flac           the posteriorgrams of a FLAC file's bytes: device decode + what bp_infer_pcm_raw does
+ *   bp_infer_flac_candidates  ... + the device half of note decoding (bp_infer_pcm_raw_candidates) */
+typedef struct bp_flac_stream_layout {
+  int32_t channels, sample_rate, bits_per_sample, min_block, max_block;
+  int64_t n_frames;     /* samples per channel; 0: unknown */
+  int64_t audio_start;  /* byte offset of the first frame */
+} bp_flac_stream_layout;
+int bp_flac_layout(const void* file, size_t nbytes, bp_flac_stream_layout* out);
+int bp_flac_decode_device(bp_handle h, const void* file, size_t nbytes, int32_t* pcm, int64_t capacity_frames, int64_t* n_frames);
+int bp_infer_flac(bp_handle h, const void* file, size_t nbytes, float* note, float* onset, float* contour, int mem_kind);
 const char* bp_audio_last_error(void);
 
 /* ceil((n_samples + 3840) / 36164) windows (inference.py:207,242); 0 for n_samples <= 0 */
@@ -374,6 +395,9 @@ int bp_note_candidates(bp_handle h, const float* note, const float* onset, const
 int bp_infer_pcm_raw_candidates(bp_handle h, const void* pcm, int format, int64_t n_frames, int channels, int sample_rate,
                                 const bp_note_params* params, float* note_out, uint8_t* cand_bits, int8_t* bend_map,
                                 int* status);
+/* the same from a FLAC file's bytes, decoded on the device (bp_infer_flac) */
+int bp_infer_flac_candidates(bp_handle h, const void* file, size_t nbytes, const bp_note_params* params, float* note_out,
+                             uint8_t* cand_bits, int8_t* bend_map, int* status);
 /* The sequential half (host): output_to_notes_polyphonic from the candidates (note_creation.py:404-509), pitch bends read
  * from bend_map, frame times as bp_notes_decode.  `note` is only read. */
 int bp_notes_decode_candidates(const float* note, const uint8_t* cand_bits, const int8_t* bend_map, int64_t n_frames,
@@ -408,7 +432,10 @@ typedef struct bp_transcribe_params {
                                    host-DRAM traffic per file and no core-ms for it; a file system that refuses O_DIRECT is
                                    read buffered).  For corpora that do NOT fit the page cache — a file that is already
                                    cached is read faster from there */
-  int32_t reserved[2];
+  int32_t host_flac;            /* 0 (default): FLAC files are decoded on the device (bp_infer_flac: the file's bytes over PCIe,
+                                   no host core-time per sample; streams it leaves to the host fall back by themselves);
+                                   1: on the host (bp_flac_decode), the round-4 path */
+  int32_t reserved[1];
 } bp_transcribe_params;
 
 typedef struct bp_file_report {

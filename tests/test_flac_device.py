@@ -1,0 +1,197 @@
+"""FLAC decoded ON THE DEVICE (csrc/flac_device.hip) against the host decoder (csrc/flac_decode.cpp,
+itself pinned to RFC 9639's worked example and to WAV <-> FLAC pairs in tests/test_audio_decode.py): the same integers,
+sample for sample, on the RFC's example file, on streams from the test-side encoder that exercise every subframe type /
+stereo mode / residual coding / sample size, and on the reference's second recording; the MD5 of STREAMINFO is checked
+here on the device's output; corrupt and truncated streams are errors; `predict()` on a .flac file goes through it."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import flac_writer as FW
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model():
+    from basic_pitch_amd import Model
+
+    m = Model(max_windows=32)
+    yield m
+    m.close()
+
+
+def _host_ints(data, bits):
+    """the host decoder's floats back as the integers they were made of"""
+    from basic_pitch_amd import _native
+
+    import ctypes as C
+
+    lib = _native.load_library()
+    ch, sr, b, n = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+    assert lib.bp_flac_info(data, len(data), C.byref(ch), C.byref(sr), C.byref(b), C.byref(n)) == 0
+    pcm = np.empty((n.value, ch.value), np.float32)
+    got = C.c_int64()
+    rc = lib.bp_flac_decode(data, len(data), pcm.ctypes.data_as(C.POINTER(C.c_float)), n.value, C.byref(got))
+    assert rc == 0 and got.value == n.value
+    return np.round(pcm.astype(np.float64) * (1 << (bits - 1))).astype(np.int64), sr.value
+
+
+def _md5_of(pcm, bits):
+    bps = (bits + 7) // 8
+    raw = b"".join(int(v).to_bytes(bps, "little", signed=True) for v in pcm.reshape(-1))
+    return hashlib.md5(raw).digest()
+
+
+def test_rfc9639_example_on_the_device(model):
+    data = bytes.fromhex(
+        "664c6143" "80000022" "10001000" "00000f00000f" "0ac442f000000001" "3e84b41807dc690307586a3dad1a2e0f"
+        "fff869180000bf" "0358fd03128b" "aa9a"
+    )
+    pcm, sr = model.flac_decode_device(data)
+    assert sr == 44100 and pcm.tolist() == [[25588, 10416]]
+    assert _md5_of(pcm, 16) == data[26:42]
+    for pos in (0x2C, 0x30, 0x33, 0x38):  # a flipped bit in the frame: CRC-8 / CRC-16 / chain
+        bad = bytearray(data)
+        bad[pos] ^= 0x04
+        with pytest.raises(ValueError):
+            model.flac_decode_device(bytes(bad))
+
+
+@pytest.mark.parametrize(
+    "bits,ch,sr,n,bs",
+    [(16, 1, 44100, 5000, 1152), (16, 2, 44100, 9000, 1152), (24, 2, 48000, 4000, 576), (8, 1, 8000, 3000, 192),
+     (16, 3, 22050, 2500, 1000), (16, 2, 12345, 700, 300), (20, 2, 96000, 2000, 4096), (12, 1, 16000, 1200, 256)],
+)
+def test_device_decoder_equals_host_decoder_on_the_round_trip_matrix(model, bits, ch, sr, n, bs):
+    """tests/test_audio_decode.py::test_flac_round_trip's streams (the test-side encoder cycles through constant / verbatim /
+    fixed 0..4 / LPC subframes, Rice and Rice2 with several partition orders, escaped partitions, all four stereo modes,
+    wasted bits, an ID3 tag in front): device == source PCM == host decoder, and the MD5 of STREAMINFO holds."""
+    rng = np.random.default_rng(bits * 100 + ch)
+    t = np.arange(n) / sr
+    x = np.stack([0.4 * np.sin(2 * np.pi * 220 * (c + 1) * t) + 0.05 * rng.standard_normal(n) for c in range(ch)], 1)
+    full = 1 << (bits - 1)
+    pcm = np.clip(np.round(x * full), -full, full - 1).astype(np.int64)
+    pcm[100:400] = 0
+    pcm[1200:1500] = (pcm[1200:1500] >> 3) << 3
+    pcm[50] = -full
+    data = FW.encode(pcm, sr, bits, blocksize=bs, id3=(ch == 3))
+    got, sr2 = model.flac_decode_device(data)
+    assert sr2 == sr and got.shape == (n, ch)
+    assert np.array_equal(got, pcm)
+    host, _ = _host_ints(data, bits)
+    assert np.array_equal(got, host)
+    lay = model.flac_layout(data)
+    md5_at = data.index(b"fLaC") + 8 + 18
+    assert _md5_of(got, bits) == data[md5_at : md5_at + 16] and lay["n_frames"] == n
+    # truncation and corruption are errors, not silence
+    with pytest.raises(ValueError):
+        model.flac_decode_device(data[: len(data) - 7])
+    bad = bytearray(data)
+    bad[len(data) // 2] ^= 0x10
+    with pytest.raises(ValueError):
+        model.flac_decode_device(bytes(bad))
+
+
+def test_second_recording_and_whole_path(model, tmp_path):
+    """tests/golden/vocadito_14.flac (537,924 frames, 132 frames of 4096): device == host decoder on every sample, MD5 of
+    STREAMINFO on the device's output; its posteriorgrams through bp_infer_flac equal those of the host-decoded samples
+    through bp_infer_pcm bit for bit (the same ingest kernels run on the same integers); `predict()` takes the device path
+    for a .flac file and returns the same events as for the host-decoded samples."""
+    from basic_pitch_amd import audio, inference as inf
+
+    path = os.path.join(GOLDEN, "vocadito_14.flac")
+    data = open(path, "rb").read()
+    got, sr = model.flac_decode_device(data)
+    host, sr2 = _host_ints(data, 16)
+    assert sr == sr2 == 44100 and got.shape == host.shape == (537924, 1) and np.array_equal(got, host)
+    md5_at = data.index(b"fLaC") + 8 + 18
+    assert _md5_of(got, 16) == data[md5_at : md5_at + 16]
+    a = model.predict_flac(data)
+    pcm, _ = audio.read_audio(path)
+    b = model.predict_pcm(pcm, sr)
+    for k in ("note", "onset", "contour"):
+        assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+    calls = []
+    orig = model.predict_flac
+    model.predict_flac = lambda blob: (calls.append(len(blob)), orig(blob))[1]
+    try:
+        mo, _, ev = inf.predict(path, model)
+    finally:
+        del model.predict_flac
+    assert calls == [len(data)] and all(np.array_equal(mo[k], a[k]) for k in a) and len(ev) > 20
+    # a stream without a sample count in STREAMINFO is left to the host decoder — predict() still works
+    rng = np.random.default_rng(5)
+    pcm16 = (3000 * np.sin(np.arange(30000) * 0.05) + rng.integers(-200, 200, 30000)).astype(np.int64)[:, None]
+    nohdr = FW.encode(pcm16, 22050, 16, blocksize=1024, total_in_header=False)
+    p = tmp_path / "nototal.flac"
+    p.write_bytes(nohdr)
+    from basic_pitch_amd._native import NativeLibraryError
+
+    with pytest.raises((ValueError, NativeLibraryError)):
+        model.flac_decode_device(nohdr)
+    mo2 = inf.run_inference(str(p), model)
+    assert mo2["note"].shape[0] == int(30000 / 36164 * 142)
+
+
+def test_long_random_streams_with_every_coding_choice(model):
+    """Fuzz: noise-like and tonal 16-bit stereo material, 20 frames each, block sizes 192..4608, the encoder's coding
+    choices cycling per frame — device == host on every sample."""
+    for seed, bs in ((1, 192), (2, 1024), (3, 4608), (4, 2304)):
+        rng = np.random.default_rng(seed)
+        n = bs * 20 + 77
+        t = np.arange(n)
+        x = np.stack([6000 * np.sin(t * 0.01 * (seed + 1)) + rng.integers(-3000, 3000, n),
+                      5000 * np.sin(t * 0.013) + rng.integers(-30, 30, n)], 1).astype(np.int64)
+        data = FW.encode(x, 44100, 16, blocksize=bs)
+        got, _ = model.flac_decode_device(data)
+        assert np.array_equal(got, x), (seed, bs)
+
+
+def test_bench_corpus_encoder(model, tmp_path):
+    """tools/flac_synth.c (the encoder `bench.py --workload files --native --flac` makes its corpus with: LPC order 8, Rice
+    partitions, block size 4096, a short last block) writes streams both decoders accept: host (every CRC checked) == device
+    == the WAV it was given; and the native pipeline transcribes the .flac through the device decoder to the bytes it
+    writes for the .wav."""
+    import subprocess
+    import wave
+
+    from basic_pitch_amd import audio, transcribe_files
+
+    exe = str(tmp_path / "flac_synth")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["gcc", "-O2", "-o", exe, os.path.join(root, "tools", "flac_synth.c"), "-lm"], check=True)
+    rng = np.random.default_rng(9)
+    n = 44100 * 12 + 333
+    t = np.arange(n) / 44100.0
+    x = 0.3 * np.sin(2 * np.pi * 330.0 * t) * (np.sin(2 * np.pi * 1.1 * t) > 0) + 0.01 * rng.standard_normal(n)
+    pcm = (np.clip(np.stack([x, x[::-1]], 1), -1, 1) * 32767).astype("<i2")
+    wav, flac = tmp_path / "tone.wav", tmp_path / "tone.flac"
+    with wave.open(str(wav), "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(44100)
+        w.writeframes(pcm.tobytes())
+    subprocess.run([exe, str(wav), str(flac)], check=True, stderr=subprocess.DEVNULL)
+    data = flac.read_bytes()
+    assert len(data) < 0.9 * pcm.nbytes
+    y, sr = audio.read_audio(flac)
+    assert sr == 44100 and np.array_equal(np.round(y * 32768).astype(np.int64), pcm.astype(np.int64))
+    got, _ = model.flac_decode_device(data)
+    assert np.array_equal(got, pcm.astype(np.int32))
+    outs = {}
+    before = model._lib.bp_files_direct_reads()
+    for name, src, kw in (("wav", wav, {}), ("flac_dev", flac, {}), ("flac_host", flac, {"host_flac": True})):
+        o = tmp_path / name
+        o.mkdir()
+        (rep,) = transcribe_files([str(src)], o, models=[model], threads=1, **kw)
+        assert rep["status"] == 0 and rep["n_note_events"] > 5, rep
+        outs[name] = {f: open(os.path.join(o, f), "rb").read() for f in sorted(os.listdir(o))}
+    assert model._lib.bp_files_direct_reads() == before
+    names = [sorted(v) for v in outs.values()]
+    assert names[0] == names[1] == names[2] == ["tone_basic_pitch.csv", "tone_basic_pitch.mid"]
+    for f in names[0]:
+        assert outs["wav"][f] == outs["flac_dev"][f] == outs["flac_host"][f], f
