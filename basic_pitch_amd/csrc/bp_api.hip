@@ -1973,23 +1973,37 @@ static int candidates_core(bp_handle h, float* d_note, float* d_onset, const flo
   // the copy engine serialises the copies of all lanes in both directions (measured: a lane's 27 MB of posteriorgrams
   // going out kept the next file's samples from coming in), and it is busy with the inbound samples.  Pageable
   // destinations take ordinary copies.
-  auto device_view = [](void* p) -> void* {
+  // (the attributes describe the START of a buffer only — a pointer into a page-locked block that ends before
+  // `bytes` would send the kernel's writes past the registration.  The whole extent must lie inside the allocation the
+  // pointer belongs to: hipMemGetAddressRange gives its base and size for the device view of a page-locked block; where that
+  // cannot be established the copies take over.)
+  auto device_view = [](void* p, size_t bytes) -> void* {
     if (!p) return nullptr;
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) {
       (void)hipGetLastError();
       return nullptr;
     }
-    return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, at.devicePointer) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    const uintptr_t b0 = reinterpret_cast<uintptr_t>(base), q = reinterpret_cast<uintptr_t>(at.devicePointer);
+    return (q >= b0 && q + bytes <= b0 + size) ? at.devicePointer : nullptr;
   };
-  void *v_note = device_view(note_out), *v_bits = device_view(cand_out), *v_bend = want_bends ? device_view(bend_out) : nullptr;
+  bool exported_by_kernel = false;
+  void *v_note = device_view(note_out, (size_t)T * 88 * 4), *v_bits = device_view(cand_out, (size_t)bits_bytes),
+       *v_bend = want_bends ? device_view(bend_out, (size_t)bend_bytes) : nullptr;
   const bool aligned = !((reinterpret_cast<uintptr_t>(v_note) | reinterpret_cast<uintptr_t>(v_bits) | reinterpret_cast<uintptr_t>(v_bend)) & 3);
   if (v_note && v_bits && (v_bend || !want_bends) && aligned) {
     // ... the stats record with them; the same kernel leaves the device record initialised for the next track
     launch_note_export(d_note, v_note, T * 88 * 4, d_bits, v_bits, bits_bytes, d_bend, v_bend, bend_bytes, d_stats,
                        h->nd_stats_host_dev, s);
     BP_HIP(hipGetLastError());
-    h->nd_stats_ready = true;
+    exported_by_kernel = true;
   } else {
     BP_HIP(hipMemcpyAsync(h->nd_stats_host, d_stats, kStatsBytes, hipMemcpyDeviceToHost, s));
     BP_HIP(hipMemcpyAsync(note_out, d_note, (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
@@ -1998,6 +2012,7 @@ static int candidates_core(bp_handle h, float* d_note, float* d_onset, const flo
   }
   rc = wait_stream(h);
   if (rc) return rc;
+  if (exported_by_kernel) h->nd_stats_ready = true;  // only now: the export kernel, which re-initialises the record, has run
   const int nan_flag = reinterpret_cast<const int*>(h->nd_stats_host)[1];
   // numpy's rules for NaN cells, and an onset threshold <= 0 (every cell that is not a peak qualifies), need the maps
   // themselves: the host decoder takes over (bp_infer_* + bp_notes_decode)

@@ -71,6 +71,7 @@ __device__ __forceinline__ void rm_dma16(const void* gsrc, uint4* lds_wave_base)
 #endif
 constexpr int kRmDepth = BP_RM_DEPTH;        // items whose zp words are in flight (LDS-DMA)
 constexpr int kRmRing = kRmDepth + 1;        // raw buffers
+static_assert(kRmDepth >= 2, "the counted s_waitcnt vmcnt(1 + 3 (kRmDepth - 2)) of the item loop assumes at least two items in flight");
 constexpr int kRmRawU = 2 * kRmPlaneU + 2;   // 648 pieces of 16 bytes + 2 dummies (every wave issues two DMA instructions)
 static_assert(2 * kRmPlaneU == kRmBlocks * 64 + 8, "piece q = 64 wave + lane, and one more piece for waves 0..7");
 static_assert((kRmRing * kRmRawU + 2 * kRmBufU) * 16 <= 160 * 1024, "LDS budget");

@@ -265,11 +265,11 @@ def test_no_kernel_of_the_product_library_uses_scratch():
     assert len(rows) >= 40, len(rows)
     names = " ".join(r["name"] for r in rows)
     for must in ("pl_pyramid_window_kernel", "cqt_filterbank_planes_kernel", "contour_conv1_march_kernel",
-                 "contour_conv1_rim_kernel", "contour_conv1_rim_march_kernel", "contour_conv2_kernel", "note_march16_kernel", "onset_march16_kernel"):
+                 "contour_conv1_rim_kernel", "contour_conv1_rim_march_kernel", "contour_conv2_proj_kernel", "note_march16_kernel", "onset_march16_kernel", "flac_decode_kernel"):
         assert must in names, must
     # kernels that left the product library (the A/B library carries them): the 32x32x16 marches, the workgroup branch
     # kernel and the fp8-corrections mode's kernels
-    for gone in ("note_march_kernel", "branch_kernel", "contour_conv1_fold_mx_kernel", "onset_march_kernel"):
+    for gone in ("note_march_kernel", "branch_kernel", "contour_conv1_fold_mx_kernel", "onset_march_kernel", "contour_conv2_kernel"):
         assert gone + "<" not in names and gone + "(" not in names, gone
     bad = [(r["name"], r["scratch"], r["vgpr_spill"], r["sgpr_spill"]) for r in rows
            if r["scratch"] or r["vgpr_spill"] or r["sgpr_spill"]]
