@@ -241,6 +241,9 @@ void launch_contour_conv2_proj(const float* c1, const void* wfrag, float bias, f
     const int n_groups = (n + kP2Group - 1) / kP2Group;
     int n_slabs = (int)(slots / ((int64_t)n_groups * kP2Strips));
     n_slabs = n_slabs < 1 ? 1 : (n_slabs > 16 ? 16 : n_slabs);
+#ifdef P2_SLABS  // tools only
+    n_slabs = P2_SLABS;
+#endif
     const int slab_rows = (kFrames + n_slabs - 1) / n_slabs;
     n_slabs = (kFrames + slab_rows - 1) / slab_rows;
     Conv2ProjParams p{c1 + (int64_t)w0 * kC1Win, static_cast<const uint4*>(wfrag), bias, contour + (int64_t)w0 * kPlaneC, n,

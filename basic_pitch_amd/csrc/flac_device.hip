@@ -470,12 +470,20 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
       for (int part = 0; part < parts; ++part) {
         const int count = (bs >> porder) - (part == 0 ? order : 0);
         const int k = (int)br.bits(pbits);
+        int32_t* dst = row + i;
+        int j = 0;
         if (k == esc) {
           const int raw = (int)br.bits(5);
-          for (int j = 0; j < count && br.pos <= guard; ++j, ++i) row[i] = (int32_t)((uint32_t)restore(br.sbits(raw)) << wasted);
+          for (; j < count && br.pos <= guard; ++j) dst[j] = (int32_t)((uint32_t)restore(br.sbits(raw)) << wasted);
         } else {
-          for (int j = 0; j < count && br.pos <= guard; ++j, ++i) row[i] = (int32_t)((uint32_t)restore(br.rice(k)) << wasted);
+          // four codes per trip: the history's register shifts of four steps fold into one, the position check is per trip
+          for (; j + 4 <= count && br.pos <= guard; j += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dst[j + u] = (int32_t)((uint32_t)restore(br.rice(k)) << wasted);
+          }
+          for (; j < count && br.pos <= guard; ++j) dst[j] = (int32_t)((uint32_t)restore(br.rice(k)) << wasted);
         }
+        i += j;
         if (br.pos > guard) {  // ran off the frame (corrupt): never read far behind the file's buffer
           err |= kFdParse;
           break;
@@ -501,13 +509,15 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
     } else if (order <= 12) {
       run_regs(FdLpc<12>());
     } else {
+      int at = order;  // index of the sample being restored (run() advances `i` per partition)
       run([&](int32_t res) {
         // s[i] = res + (sum_j coef[j] s[i - 1 - j]) >> shift with 64-bit wrapping sums (flac_decode.cpp lpc_restore_n)
         uint64_t acc = 0;
         for (int j2 = 0; j2 < order; ++j2)
-          acc += (uint64_t)((int64_t)coefs[j2][lane] * (int64_t)hist[(i - 1 - j2) & 31][lane]);
+          acc += (uint64_t)((int64_t)coefs[j2][lane] * (int64_t)hist[(at - 1 - j2) & 31][lane]);
         const int32_t v = (int32_t)((uint32_t)res + (uint32_t)((int64_t)acc >> shift));
-        hist[i & 31][lane] = v;
+        hist[at & 31][lane] = v;
+        ++at;
         return v;
       });
     }

@@ -309,7 +309,8 @@ def run_files(args, torch=None, dist=None, world: int = 1, rank: int = 0, local_
                                                 "system": (ru1.ru_stime - ru0.ru_stime) * 1e3 / max(1, len(paths))},
                        "direct_io_requested": bool(args.direct_io),
                        "files_read_with_o_direct": int(lanes[0]._lib.bp_files_direct_reads()) - direct_before,
-                       "cold_files": bool(args.cold_files), "distinct_files": distinct, "tmp_dir": d}
+                       "cold_files": bool(args.cold_files), "distinct_files": distinct, "tmp_dir": d,
+                       "lanes": args.lanes, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")}
             if args.flac:
                 io_note["flac"] = {"decoder": "host (bp_flac_decode)" if args.host_flac else "device (flac_device.hip)",
                                    "bytes_per_file": flac_bytes, "wav_bytes_per_file": file_bytes}
@@ -527,6 +528,12 @@ def main() -> None:
     ap.add_argument("--bf16-weights", action="store_true",
                     help="BASELINE.json configs[3]: bf16 CNN weights + fp32 CQT (use with --batch 1024); not the headline line")
     args = ap.parse_args()
+
+    if args.workload == "files" and args.native and args.lanes > 4:
+        # the HIP runtime maps a process's streams onto FOUR hardware queues by default; kernels of lanes that share a queue
+        # run one after the other (a FLAC file's 2.7 ms decode kernel holds its queue that long: profiles/r06_flac_device.md).
+        # One queue per lane, set before the runtime initialises; reported on the line.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(args.lanes, 16)))
 
     import torch
     import torch.distributed as dist
