@@ -211,7 +211,8 @@ __device__ __forceinline__ float norm_bn(float lp, float mn, float range, const 
 
 // The same map as the default path evaluates it (round 5): the affine part folded into one scale per window,
 // z = (lp - min) * (bn_a / range) + bn_b — one subtraction and one FMA per element instead of sub, IEEE division, mul, add
-// (the division alone is ~10 instructions).  <= 1.5 ulp of z from the sequence above; every kernel of the default path
+// (the division alone is ~10 instructions).  <= 2 ulp of the product nrm x bn_a (<= 4.8e-7 absolute; z itself passes
+// through 0) from the sequence above — tests/test_gpu_parity.py::test_zpack_folded_affine_is_within_two_ulp_of_the_graph_order; every kernel of the default path
 // (the fused filterbank's normalise phase, zpack_kernel) uses THESE two functions, so a window's words do not depend on
 // which of them produced it.  range == 0 (a silent window): scale 0, z = bn_b, as divide_no_nan gives.
 __device__ __forceinline__ float norm_scale(float mn, float mx, const LogConsts& k) {

@@ -122,6 +122,42 @@ def test_stage_zpack(runner, cases):
     assert np.abs(z - r32["z"]).max() <= 2e-6  # fp32 rounding of the normalisation + 2^-22 split residue
 
 
+def test_zpack_folded_affine_is_within_two_ulp_of_the_graph_order(runner, weights):
+    """the default path folds the frozen graph's sub, IEEE div, mul, add (signal.py:177-183, models.py:187-189)
+    into z = (lp - min) * (bn_a / range) + bn_b with an FMA (bp_common.h norm_bn_k): no longer the reference's operation
+    order, bounded here against it — <= 2 ulp of the product nrm x bn_a (4.8e-7 absolute) plus the operand split's 2^-22 — on the windows where the fold could
+    bite: a silent window (range exactly 0: divide_no_nan's constant map, z = bn_b), ranges of 1e-6 and 3e-5 dB (a scale
+    of ~1e6 on differences of a few ulp of lp), an ordinary window, and one whose extrema are extreme."""
+    from stage_harness import ord_encode, zp_unpack
+
+    rng = np.random.default_rng(21)
+    n = 5
+    lp = np.empty((n, 172, 309), np.float32)
+    lp[0] = -100.0                                                      # silent: range 0
+    lp[1] = np.float32(-37.5) + rng.integers(0, 2, (172, 309)).astype(np.float32) * np.float32(1e-6 * 4)   # a few ulp of range
+    lp[2] = np.float32(-12.25) + rng.random((172, 309), dtype=np.float32) * np.float32(3e-5)
+    lp[3] = rng.uniform(-100.0, 40.0, (172, 309)).astype(np.float32)
+    lp[4] = rng.uniform(-0.001, 0.001, (172, 309)).astype(np.float32)
+    lp[4, 0, 0], lp[4, 171, 308] = -100.0, 75.0
+    mn = lp.reshape(n, -1).min(1)
+    mx = lp.reshape(n, -1).max(1)
+    mm = np.stack([mn, mx], 1).astype(np.float32)
+    out = runner.run("zpack", n, {"lp": lp, "mm": ord_encode(mm)}, {"zp": ((n, 174, 448), torch.int32)})
+    z = zp_unpack(out["zp"].view(np.uint32))
+    bn_a, bn_b = np.float32(weights["bn_affine"][0]), np.float32(weights["bn_affine"][1])
+    off = lp - mn[:, None, None]
+    rngs = (mx - mn).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        nrm = np.where(rngs[:, None, None] == 0, np.float32(0), off / rngs[:, None, None]).astype(np.float32)
+    ref = (nrm * bn_a).astype(np.float32) + bn_b                          # the graph's order: Mul, then Add
+    assert np.array_equal(z[0], np.full((172, 309), bn_b, np.float32))    # the silent window: exactly bn_b
+    # two roundings differ (the scale bn_a / range instead of the quotient, one FMA instead of Mul + Add): each is half an ulp
+    # of the product nrm * bn_a <= 2.48, so the bound is absolute — 2 ulp of 2.48 — not relative to z, which passes through 0
+    err = np.abs(z - ref)
+    print("folded affine vs graph order, max |dz| per window:", err.reshape(n, -1).max(1))
+    assert (err <= 2 * np.spacing(np.float32(2.48)) + np.abs(ref) * np.float32(2.0 ** -21)).all()
+
+
 @pytest.mark.parametrize("branch", ["contour", "note", "onset"])
 def test_stage_fused_branch(runner, cases, branch):
     """The fused split-precision branches (conv -> ReLU -> conv -> sigmoid in one kernel) against the
