@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -1613,12 +1614,21 @@ int64_t bp_track_n_frames(int64_t n_samples) {
 }
 
 // windows of a device-resident 22.05 kHz signal -> un-overlapped posteriorgrams (host or device outputs)
-// end of a host-blocking call: spin on the stream (lowest latency) or, with BP_FLAG_BLOCKING_WAIT, sleep until the device
-// raises the event's interrupt (the core goes to another worker thread)
+// end of a host-blocking call: spin on the stream (lowest latency) or, with BP_FLAG_BLOCKING_WAIT, give the core to another
+// worker thread while the device works.  hipEventSynchronize on a hipEventBlockingSync event does not do that here: measured
+// on the MI355X box its user time equals its wall time (tools/experiments/host_cpu.py — the runtime polls the signal), so
+// the wait is a query every 20..160 us with the thread asleep in between (a call of a few ms ends ~0.1 ms late).
 static int wait_stream(bp_handle h) {
   if (h->done) {
     BP_HIP(hipEventRecord(h->done, h->stream));
-    BP_HIP(hipEventSynchronize(h->done));
+    for (long ns = 20000;;) {
+      const hipError_t e = hipEventQuery(h->done);
+      if (e == hipSuccess) break;
+      if (e != hipErrorNotReady) BP_HIP(e);
+      const timespec ts{0, ns};
+      nanosleep(&ts, nullptr);
+      if (ns < 80000) ns *= 2;
+    }
   } else {
     BP_HIP(hipStreamSynchronize(h->stream));
   }

@@ -262,34 +262,122 @@ __global__ __launch_bounds__(kFdChainThreads) void flac_chain_kernel(const FdCan
 // The stream as 32-bit words: `hi` and `lo` hold the next 64 bits, `o` of `hi`'s are consumed, `nx` is the word behind them,
 // loaded two refills ahead of its use (a lane is alone on its chain: nothing else hides a load's latency).  A peek is one
 // funnel shift, a skip an add and — every 32 bits — a rotation of the three words; no 64-bit shifts on the serial path.
+constexpr int kFdLanes = 64;     // lanes (frames) per workgroup: one wave
+constexpr int kFdRing = 128;     // words of its stream a lane holds in LDS
+constexpr int kFdRingRow = 132;  // row stride in words: 16-byte rows for ds_write_b128, the lanes' equal indices on four banks
+constexpr int kFdBurst = 16;     // codes between two services
+constexpr int kFdStageRow = 20;  // kFdBurst samples + padding (16-byte rows)
+
+// A lane's view of its frame: the bit window, the words behind it, the samples on their way out.
+//
+// What bounds this kernel is neither arithmetic nor bandwidth but the latency of the lanes' own memory operations, and the
+// fact that a wave has ONE counter for them (vmcnt: loads and stores alike on gfx9).  A lane needs its next word every ~5
+// codes, but SOME lane of the 64 needs one at nearly every code: with a load per refill the wave sat out an L2 / HBM round
+// trip per code (measured: 490 core cycles per Rice code with prediction and stores compiled out, SQ_WAIT_ANY 60 - 68 % of
+// the wave's cycles, 1.2 load instructions per code and wave).  So the lanes touch global memory together, at a SERVICE
+// every kFdBurst codes:
+//   * the stream lives in a ring of kFdRing words per lane in LDS; a refill of the window is a ds_read (its own counter,
+//     ~64 cycles, asked for one refill ahead);
+//   * a service commits the <= 4 blocks of 16 bytes it asked for at the PREVIOUS service (the one wait: everything in
+//     flight is a burst old), asks for the next <= 4 where the ring has room, and sends the previous burst's samples —
+//     staged in LDS — to global memory.  Invariant: a lane that consumes <= 16 words per burst (a code of the fast path is
+//     <= 32 bits) has >= 32 words committed after every service (c' = c - u + 16 while c < 112; >= 109 - 16 above), the
+//     header fields of a subframe (<= 34 + 16 words) sit between two double services (refuel()), a code longer than the
+//     window (unary runs of hundreds of zeros: the test-side encoder writes them) serves itself every four words and is
+//     followed by a refuel.  Should a lane run dry anyway it reads stale words: memory-safe, the frame's CRC-16 fails, the
+//     call reports the stream as not decodable here.
 struct FdBits {
-  const uint8_t* base;
-  uint32_t pos;  // byte offset of the next word to LOAD
-  uint32_t hi, lo, nx;  // nx as loaded (little-endian): swapped when it moves up, so that nothing touches a word before the
-                        // load that brings it has had two refills' time
-  int o;         // bits of `hi` already consumed, 0..31
-  __device__ __forceinline__ uint32_t ld_raw(uint32_t off) const {
-    uint32_t w;
-    __builtin_memcpy(&w, base + off, 4);
-    return w;
+  const uint8_t* org;  // the byte the stream's word 0 starts on (frame offset + header length)
+  uint32_t off0;       // its offset from the file's start
+  uint32_t hi, lo;
+  uint32_t nx, n2;     // the two words behind `lo` as read (little-endian): swapped when they move up, and read two refills
+                       // ahead, so that a refill never waits for its own read
+  int s;         // the window starts s bits above the bottom of `hi`: 0..31 (0 = all of `hi` consumed, the window is `lo`) —
+                 // v_alignbit's own shift operand, so a peek is that one instruction whatever the position
+  uint32_t* ring;      // LDS, this lane's kFdRing words
+  uint32_t rd, wr;     // words read from / committed to the ring (stream word numbers): `lo` is word rd - 3
+  typedef uint32_t Block __attribute__((ext_vector_type(4)));
+  Block pb0, pb1, pb2, pb3;  // blocks in flight (named, not an array: they live in registers)
+  int np;
+  int32_t* stg;        // LDS, this lane's staged samples
+  int32_t* out;        // where the first of them goes
+  int sn;
+
+  __device__ __forceinline__ Block get(uint32_t word) const {
+    Block b;
+    __builtin_memcpy(&b, org + 4 * (size_t)word, 16);
+    return b;
   }
-  __device__ __forceinline__ void init(const uint8_t* b, uint32_t off) {
-    base = b, o = 0;
-    hi = __builtin_bswap32(ld_raw(off)), lo = __builtin_bswap32(ld_raw(off + 4)), nx = ld_raw(off + 8);
-    pos = off + 12;
+  __device__ __forceinline__ void put(uint32_t word, Block b) { __builtin_memcpy(ring + (word & (kFdRing - 1)), &b, 16); }
+  __device__ __forceinline__ void init(const uint8_t* file, uint32_t off, uint32_t* ring_row, int32_t* stage_row) {
+    org = file + off, off0 = off, s = 0, hi = 0, ring = ring_row, stg = stage_row, out = nullptr, sn = 0, wr = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // 32 words committed before the first bit is read
+      pb0 = get(wr), pb1 = get(wr + 4), pb2 = get(wr + 8), pb3 = get(wr + 12);
+      put(wr, pb0), put(wr + 4, pb1), put(wr + 8, pb2), put(wr + 12, pb3);
+      wr += 16;
+    }
+    pb0 = get(wr), pb1 = get(wr + 4), pb2 = get(wr + 8), pb3 = get(wr + 12);
+    np = 4;
+    lo = __builtin_bswap32(ring[0]), nx = ring[1], n2 = ring[2], rd = 3;
   }
-  __device__ __forceinline__ uint32_t peek() const {  // the next 32 bits
-    return o ? __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(32 - o)) : hi;
+  // the samples of the previous burst leave (they were staged before the wait that opened this service)
+  __device__ __forceinline__ void flush() {
+#ifndef FD_NO_STORE  // tools only: what the stores cost
+    int t = 0;
+    for (; t + 4 <= sn; t += 4) {
+      int32_t v[4];
+      __builtin_memcpy(v, stg + t, 16);
+      __builtin_memcpy(out + t, v, 16);
+    }
+    for (; t < sn; ++t) out[t] = stg[t];
+#endif
+    out += sn;
+    sn = 0;
   }
+  __device__ __forceinline__ void service() {
+    if (np > 0) put(wr, pb0);
+    if (np > 1) put(wr + 4, pb1);
+    if (np > 2) put(wr + 8, pb2);
+    if (np > 3) put(wr + 12, pb3);
+    wr += 4 * (uint32_t)np;
+    const int room = (kFdRing - 1 - (int)(wr - rd)) >> 2;  // word rd - 1 (n2) stays: skip_select() reads it again
+    np = room < 4 ? room : 4;
+    // all four asked for whatever the room: a load under a lane mask would make the compiler guard its target registers
+    // with a wait of its own — behind the load issued just before; the blocks without room are asked for again next time
+    pb0 = get(wr), pb1 = get(wr + 4), pb2 = get(wr + 8), pb3 = get(wr + 12);
+    flush();
+  }
+  __device__ __forceinline__ void refuel() {  // up to 32 more words committed at once (before a subframe's header fields)
+    service();
+    service();
+  }
+  __device__ __forceinline__ void begin_row(int32_t* row) {
+    flush();
+    out = row;
+  }
+  __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)s); }  // the next 32 bits
   __device__ __forceinline__ void skip(int n) {  // n <= 32
-    o += n;
-    if (o >= 32) {
-      hi = lo, lo = __builtin_bswap32(nx);
-      nx = ld_raw(pos);
-      pos += 4;
-      o -= 32;
+    s -= n;
+    if (s < 0) {
+      hi = lo, lo = __builtin_bswap32(nx), nx = n2;
+      n2 = ring[rd & (kFdRing - 1)];
+      ++rd, s += 32;
     }
   }
+  // the same without a branch (n <= 32 for a valid step): the trip of four codes is one basic block, its instructions
+  // interleave; n2 is read again at every step (the same word until a refill moves rd)
+  __device__ __forceinline__ void skip_select(int n) {
+    s -= n;
+    const bool need = s < 0;
+    hi = need ? lo : hi;
+    lo = need ? __builtin_bswap32(nx) : lo;
+    nx = need ? n2 : nx;
+    rd += need ? 1u : 0u;
+    s += need ? 32 : 0;
+    n2 = ring[(rd - 1) & (kFdRing - 1)];
+  }
+  __device__ __forceinline__ uint32_t at() const { return off0 + 4 * (rd - 3); }  // byte offset of the start of `lo`
   __device__ __forceinline__ uint32_t bits(int k) {  // k <= 32
     if (k == 0) return 0;
     const uint32_t v = peek() >> (32 - k);
@@ -313,55 +401,86 @@ struct FdBits {
       }
       skip(32);
       q += 32;
+      if ((q & 127) == 0) service();  // a long run outlives the ring: four words at most between two services
       if (q > (1u << 13)) return q;  // a run no encoder writes (the zero padding behind the file, a misread stream): the caller's
                                      // position check ends the frame
     }
   }
-  // one Rice code: the whole code inside the 32-bit window (every code of ordinary audio) is one peek
+  // one Rice code: the whole code inside the 32-bit window (every code of ordinary audio) is one peek; a longer one (the
+  // ring's invariant counts 32 bits per code) refuels behind itself
   __device__ __forceinline__ int32_t rice(int k) {
     const uint32_t w = peek();
-    const int lz = w ? __builtin_clz(w) : 32;
+    const int n = (w ? __builtin_clz(w) : 32) + 1 + k;  // the code's length
     uint32_t v;
-    if (lz + 1 + k <= 32) {
-      const uint32_t rem = k ? (w << ((lz + 1) & 31)) >> (32 - k) : 0u;
-      skip(lz + 1 + k);
-      v = ((uint32_t)lz << k) | rem;
+    if (__builtin_expect(n <= 32, 1)) {
+      v = ((uint32_t)(n - 1 - k) << k) | __builtin_amdgcn_ubfe(w, (uint32_t)(32 - n), (uint32_t)k);
+      skip(n);
     } else {
       const uint32_t q = unary();
       v = (q << k) | bits(k);
+      refuel();
     }
     return (int32_t)(v >> 1) ^ -(int32_t)(v & 1);
   }
-  __device__ __forceinline__ uint32_t byte_pos() const { return pos - 12 + (uint32_t)(o >> 3); }  // of the next unread bit
+  // the same for a trip that checks afterwards: no branch for the long code, *nmax collects the lengths; a trip with one
+  // beyond the window is decoded again from the trip's start by rice() (what this wrote and skipped then was garbage)
+  __device__ __forceinline__ int32_t rice_window(int k, int* nmax) {
+    const uint32_t w = peek();
+    const int n = (w ? __builtin_clz(w) : 32) + 1 + k;
+    *nmax = n > *nmax ? n : *nmax;
+    const uint32_t v = ((uint32_t)(n - 1 - k) << k) | __builtin_amdgcn_ubfe(w, (uint32_t)(32 - n), (uint32_t)k);
+    skip_select(n);
+    return (int32_t)(v >> 1) ^ -(int32_t)(v & 1);
+  }
+  __device__ __forceinline__ uint32_t byte_pos() const { return at() - (uint32_t)((s + 7) >> 3); }  // of the next unread bit
   __device__ __forceinline__ uint32_t bytes_consumed_aligned() {  // after dropping the bits up to the next byte boundary
-    if (o & 7) skip(8 - (o & 7));
+    if (s & 7) skip(s & 7);
     return byte_pos();
   }
 };
 
-// Linear prediction with the history in registers, as float64: a sample has <= 25 bits, a coefficient <= 15, a sum of <= 12
-// products stays far below 2^53 — every operation is exact — and floor(sum 2^-shift) is the reference's arithmetic shift.
-// (The vector pipe runs v_fma_f64 at a fraction of the cost of the 64-bit integer multiply-adds it replaces, and the
-// history moves down by register copies, no addressing.)  The generic path below (LDS ring, 64-bit integers) takes the orders
-// above 12.
-template <int ORD>
-struct FdLpc {
-  double c[ORD], h[ORD];  // h[0] = s[i - 1]
-  double scale;           // 2^-shift
+// Linear prediction with the history in registers, as float64: a restored sample is an int32, a coefficient has <= 15 bits, a
+// sum of <= 12 products stays below 2^51 — every operation is exact.  (The vector pipe runs v_fma_f64 at a fraction of the
+// cost of the 64-bit integer multiply-adds it replaces, and the history moves down by register copies, no addressing.)  One
+// set of 12 coefficients and 12 samples serves the orders 1..12 in three classes (4, 8, 12 products per sample, the unused
+// coefficients zero); the orders above 12 take the generic path in the kernel (LDS ring, 64-bit integers).
+struct FdPred {
+  double c[12], h[12];  // h[0] = s[i - 1]
+  int shift;            // 0..15 (a 5-bit signed field, negative refused)
+  template <int ORD>
   __device__ __forceinline__ int32_t step(int32_t res) {
-    double a0 = 0.0, a1 = 0.0;
+    // the sum rides on 1.5 * 2^52: |sum| < 2^51 is an integer, so the double's low 51 bits ARE its two's complement and
+    // the arithmetic shift is a funnel shift of the two words (no multiply, floor or conversion)
+    double a0 = 6755399441055744.0, a1 = 0.0;
+    // oldest samples first: only the last product waits for the sample the previous step has just restored
 #pragma unroll
-    for (int j = 0; j + 1 < ORD; j += 2) {
-      a0 = __builtin_fma(c[j], h[j], a0);
-      a1 = __builtin_fma(c[j + 1], h[j + 1], a1);
+    for (int j = ORD - 1; j >= 1; j -= 2) {
+      a1 = __builtin_fma(c[j], h[j], a1);
+      a0 = __builtin_fma(c[j - 1], h[j - 1], a0);
     }
-    if (ORD & 1) a0 = __builtin_fma(c[ORD - 1], h[ORD - 1], a0);
-    const int32_t pred = (int32_t)__builtin_floor((a0 + a1) * scale);
+    const uint64_t sb = __builtin_bit_cast(uint64_t, a0 + a1);
+    const int32_t pred = (int32_t)__builtin_amdgcn_alignbit((uint32_t)(sb >> 32), (uint32_t)sb, (uint32_t)shift);
     const int32_t v = (int32_t)((uint32_t)res + (uint32_t)pred);
 #pragma unroll
     for (int j = ORD - 1; j > 0; --j) h[j] = h[j - 1];
     h[0] = (double)v;
     return v;
+  }
+  // a full burst: the residuals staged in LDS become samples (wasted bits restored) in place; written out sixteen times, the
+  // history's moves are register names
+  template <int ORD>
+  __device__ __forceinline__ void burst(int32_t* stg, int wasted) {
+    int32_t r[kFdBurst];
+#pragma unroll
+    for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(r + t, stg + t, 16);
+#pragma unroll
+    for (int t = 0; t < kFdBurst; ++t) r[t] = (int32_t)((uint32_t)step<ORD>(r[t]) << wasted);
+#pragma unroll
+    for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(stg + t, r + t, 16);
+  }
+  template <int ORD>
+  __device__ __forceinline__ void some(int32_t* stg, int n, int wasted) {
+    for (int t = 0; t < n; ++t) stg[t] = (int32_t)((uint32_t)step<ORD>(stg[t]) << wasted);
   }
 };
 
@@ -378,29 +497,34 @@ struct FdDecodeParams {
   const uint16_t* crc_tab;  // [8][256]
 };
 
-constexpr int kFdLanes = 64;  // lanes (frames) per workgroup: one wave
-
 __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p) {
-  __shared__ int32_t hist[32][kFdLanes];   // the lane's last 32 restored samples, a ring
+  __shared__ int32_t hist[32][kFdLanes];   // the lane's last 32 restored samples, a ring (orders above 12; warm-up samples)
   __shared__ int32_t coefs[32][kFdLanes];
   __shared__ uint16_t crc[8][256];
+  __shared__ __attribute__((aligned(16))) uint32_t ring[kFdLanes][kFdRingRow];
+  __shared__ __attribute__((aligned(16))) int32_t stage[kFdLanes][kFdStageRow];
   for (int i = threadIdx.x; i < 8 * 256; i += kFdLanes) crc[i >> 8][i & 255] = p.crc_tab[i];
   __syncthreads();
   const int lane = threadIdx.x;
   const int f = blockIdx.x * kFdLanes + lane;
   if (f >= *p.n_frames) return;
+#ifdef FD_CLOCK  // tools only: the shader clock this kernel runs at (core cycles against the 100 MHz wall clock)
+  const long long fd_c0 = clock64(), fd_w0 = wall_clock64();
+#endif
   const FdFrame fr = p.frames[f];
   const int bs = (int)fr.blocksize, n_ch = p.st.channels;
   int err = 0;
 
   FdBits br;
-  br.init(p.file, fr.offset + fr.hdr_bytes);
+  br.init(p.file, fr.offset + fr.hdr_bytes, ring[lane], stage[lane]);
+  int32_t* const stg = stage[lane];
   int32_t* scr = p.scratch + (size_t)f * p.st.max_block * n_ch;
   const uint32_t guard = fr.end + 16;  // a lane that reads past this has lost the stream
 
   for (int c = 0; c < n_ch && !err; ++c) {
     const bool side = (fr.ch_code == 8 && c == 1) || (fr.ch_code == 9 && c == 0) || (fr.ch_code == 10 && c == 1);
     int bps = p.st.bits + (side ? 1 : 0);
+    br.refuel();
     if (br.bits(1)) err |= kFdParse;
     const int type = (int)br.bits(6);
     int wasted = 0;
@@ -411,6 +535,7 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
       break;
     }
     int32_t* row = scr + (size_t)c * p.st.max_block;
+    br.begin_row(row);
     // predictor of this subframe: order, shift, coefficients in LDS (fixed predictors are LPC with binomial coefficients)
     int order = 0, shift = 0;
     if (type == 0) {  // constant
@@ -419,8 +544,11 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
       continue;
     }
     if (type == 1) {  // verbatim
-      for (int i = 0; i < bs && br.pos <= guard; ++i) row[i] = (int32_t)((uint32_t)br.sbits(bps) << wasted);
-      if (br.pos > guard) err |= kFdParse;
+      for (int i = 0; i < bs && br.at() <= guard; ++i) {
+        if ((i & 7) == 0) br.service();
+        row[i] = (int32_t)((uint32_t)br.sbits(bps) << wasted);
+      }
+      if (br.at() > guard) err |= kFdParse;
       continue;
     }
     if (type >= 8 && type <= 12) {
@@ -442,6 +570,8 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
       hist[i & 31][lane] = v;
       row[i] = (int32_t)((uint32_t)v << wasted);
     }
+    br.out = row + order;  // where the first residual's sample goes
+    br.refuel();
     if (type >= 32) {
       const int prec = (int)br.bits(4) + 1;
       shift = br.sbits(5);
@@ -464,64 +594,96 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
       err |= kFdParse;
       break;
     }
-    int i = order;
-    // the subframe's residual + prediction, partition by partition; `restore` is the predictor (registers for orders <= 12)
-    auto run = [&](auto&& restore) {
-      for (int part = 0; part < parts; ++part) {
-        const int count = (bs >> porder) - (part == 0 ? order : 0);
-        const int k = (int)br.bits(pbits);
-        int32_t* dst = row + i;
-        int j = 0;
-        if (k == esc) {
-          const int raw = (int)br.bits(5);
-          for (; j < count && br.pos <= guard; ++j) dst[j] = (int32_t)((uint32_t)restore(br.sbits(raw)) << wasted);
-        } else {
-          // four codes per trip: the history's register shifts of four steps fold into one, the position check is per trip
-          for (; j + 4 <= count && br.pos <= guard; j += 4) {
+    // the predictor's class: 0 none, 1..3 = 4 / 8 / 12 products in registers, 4 the generic path
+    const int cls = order == 0 ? 0 : order <= 4 ? 1 : order <= 8 ? 2 : order <= 12 ? 3 : 4;
+    FdPred lpc;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dst[j + u] = (int32_t)((uint32_t)restore(br.rice(k)) << wasted);
+    for (int j = 0; j < 12; ++j) {
+      const bool live = cls >= 1 && cls <= 3 && j < order;
+      lpc.c[j] = live ? (double)coefs[j][lane] : 0.0;
+      lpc.h[j] = live ? (double)hist[(order - 1 - j) & 31][lane] : 0.0;
+    }
+    lpc.shift = shift;
+    int hat = order;  // generic path: index of the sample being restored
+    // n staged residuals -> samples, in place
+    auto restore = [&](int n) {
+#ifdef FD_NO_LPC  // tools only: what the prediction costs
+      return;
+#endif
+      if (cls == 0) {
+        if (wasted)
+          for (int t = 0; t < n; ++t) stg[t] = (int32_t)((uint32_t)stg[t] << wasted);
+      } else if (cls == 1) {
+        if (n == kFdBurst) lpc.burst<4>(stg, wasted);
+        else lpc.some<4>(stg, n, wasted);
+      } else if (cls == 2) {
+        if (n == kFdBurst) lpc.burst<8>(stg, wasted);
+        else lpc.some<8>(stg, n, wasted);
+      } else if (cls == 3) {
+        if (n == kFdBurst) lpc.burst<12>(stg, wasted);
+        else lpc.some<12>(stg, n, wasted);
+      } else {
+        for (int t = 0; t < n; ++t) {
+          // s[i] = res + (sum_j coef[j] s[i - 1 - j]) >> shift with 64-bit wrapping sums (flac_decode.cpp lpc_restore_n)
+          uint64_t acc = 0;
+          for (int j2 = 0; j2 < order; ++j2)
+            acc += (uint64_t)((int64_t)coefs[j2][lane] * (int64_t)hist[(hat - 1 - j2) & 31][lane]);
+          const int32_t v = (int32_t)((uint32_t)stg[t] + (uint32_t)((int64_t)acc >> shift));
+          hist[hat & 31][lane] = v;
+          ++hat;
+          stg[t] = (int32_t)((uint32_t)v << wasted);
+        }
+      }
+    };
+    for (int part = 0; part < parts && br.at() <= guard; ++part) {
+      const int count = (bs >> porder) - (part == 0 ? order : 0);
+      const int k = (int)br.bits(pbits);
+      int j = 0;
+      if (k == esc) {
+        const int raw = (int)br.bits(5);
+        while (j < count && br.at() <= guard) {
+          const int n = count - j < 8 ? count - j : 8;
+          br.service();
+          for (int t = 0; t < n; ++t) stg[t] = br.sbits(raw);
+          restore(n);
+          br.sn = n;
+          j += n;
+        }
+      } else {
+        while (j < count && br.at() <= guard) {
+          const int n = count - j < kFdBurst ? count - j : kFdBurst;
+          br.service();
+          if (n == kFdBurst) {
+            // four trips of four codes: the residuals go to the stage 16 bytes at a time
+            for (int t = 0; t < kFdBurst; t += 4) {
+              int32_t r4[4];
+              const uint32_t hi0 = br.hi, lo0 = br.lo, nx0 = br.nx, n20 = br.n2, rd0 = br.rd;
+              const int s0 = br.s;
+              int nmax = 0;
+#pragma unroll
+              for (int u = 0; u < 4; ++u) r4[u] = br.rice_window(k, &nmax);
+              if (__builtin_expect(nmax > 32, 0)) {
+                br.hi = hi0, br.lo = lo0, br.nx = nx0, br.n2 = n20, br.rd = rd0, br.s = s0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) r4[u] = br.rice(k);
+              }
+              __builtin_memcpy(stg + t, r4, 16);
+            }
+          } else {
+            for (int t = 0; t < n; ++t) stg[t] = br.rice(k);
           }
-          for (; j < count && br.pos <= guard; ++j) dst[j] = (int32_t)((uint32_t)restore(br.rice(k)) << wasted);
-        }
-        i += j;
-        if (br.pos > guard) {  // ran off the frame (corrupt): never read far behind the file's buffer
-          err |= kFdParse;
-          break;
+          restore(n);
+          br.sn = n;
+          j += n;
         }
       }
-    };
-    auto run_regs = [&](auto lpc) {
-      constexpr int ORD = sizeof(lpc.c) / sizeof(double);
-#pragma unroll
-      for (int j = 0; j < ORD; ++j) {
-        lpc.c[j] = j < order ? (double)coefs[j][lane] : 0.0;
-        lpc.h[j] = j < order ? (double)hist[(order - 1 - j) & 31][lane] : 0.0;
-      }
-      lpc.scale = __builtin_ldexp(1.0, -shift);
-      run([&](int32_t res) { return lpc.step(res); });
-    };
-    if (order == 0) {
-      run([&](int32_t res) { return res; });
-    } else if (order <= 4) {
-      run_regs(FdLpc<4>());
-    } else if (order <= 8) {
-      run_regs(FdLpc<8>());
-    } else if (order <= 12) {
-      run_regs(FdLpc<12>());
-    } else {
-      int at = order;  // index of the sample being restored (run() advances `i` per partition)
-      run([&](int32_t res) {
-        // s[i] = res + (sum_j coef[j] s[i - 1 - j]) >> shift with 64-bit wrapping sums (flac_decode.cpp lpc_restore_n)
-        uint64_t acc = 0;
-        for (int j2 = 0; j2 < order; ++j2)
-          acc += (uint64_t)((int64_t)coefs[j2][lane] * (int64_t)hist[(at - 1 - j2) & 31][lane]);
-        const int32_t v = (int32_t)((uint32_t)res + (uint32_t)((int64_t)acc >> shift));
-        hist[at & 31][lane] = v;
-        ++at;
-        return v;
-      });
+    }
+    if (br.at() > guard) {  // ran off the frame (corrupt): never read far behind the file's buffer
+      err |= kFdParse;
+      break;
     }
   }
+  br.flush();
   if (!err) {
     // the frame's CRC-16 over [offset, aligned end), eight bytes per step (flac_decode.cpp crc16)
     const uint32_t body_end = br.bytes_consumed_aligned();
@@ -545,8 +707,14 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
       if (body_end + 2 != fr.end && f + 1 < *p.n_frames) err |= kFdChain;
     }
   }
+#ifdef FD_CLOCK
+  if (f == 0 || f == 700) {
+    const long long dc = clock64() - fd_c0, dw = wall_clock64() - fd_w0;
+    printf("FDCLK frame %d: %lld core cycles, %lld wall ticks (100 MHz) = %.1f us, %.0f MHz\n", f, dc, dw, dw / 100.0, dc * 100.0 / dw);
+  }
+#endif
 #ifdef FD_DEBUG
-  if (err || f < 2) printf("FDDBG frame %d off %u end %u bs %d err %d pos %u\n", f, fr.offset, fr.end, bs, err, br.pos);
+  if (err || f < 2) printf("FDDBG frame %d off %u end %u bs %d err %d at %u\n", f, fr.offset, fr.end, bs, err, br.at());
 #endif
   if (err) atomicOr(p.status, err);
 }
