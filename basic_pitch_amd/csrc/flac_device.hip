@@ -302,6 +302,8 @@ struct FdBits {
   int32_t* stg;        // LDS, this lane's staged samples
   int32_t* out;        // where the first of them goes
   int sn;
+  int32_t o[kFdBurst];  // a full burst's samples stay in registers until the next service
+  int on;              // 0 or kFdBurst
 
   __device__ __forceinline__ Block get(uint32_t word) const {
     Block b;
@@ -310,7 +312,7 @@ struct FdBits {
   }
   __device__ __forceinline__ void put(uint32_t word, Block b) { __builtin_memcpy(ring + (word & (kFdRing - 1)), &b, 16); }
   __device__ __forceinline__ void init(const uint8_t* file, uint32_t off, uint32_t* ring_row, int32_t* stage_row) {
-    org = file + off, off0 = off, s = 0, hi = 0, ring = ring_row, stg = stage_row, out = nullptr, sn = 0, wr = 0;
+    org = file + off, off0 = off, s = 0, hi = 0, ring = ring_row, stg = stage_row, out = nullptr, sn = 0, on = 0, wr = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {  // 32 words committed before the first bit is read
       pb0 = get(wr), pb1 = get(wr + 4), pb2 = get(wr + 8), pb3 = get(wr + 12);
@@ -323,6 +325,14 @@ struct FdBits {
   }
   // the samples of the previous burst leave (they were staged before the wait that opened this service)
   __device__ __forceinline__ void flush() {
+    if (on) {
+#ifndef FD_NO_STORE
+#pragma unroll
+      for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(out + t, o + t, 16);
+#endif
+      out += kFdBurst;
+      on = 0;
+    }
 #ifndef FD_NO_STORE  // tools only: what the stores cost
     int t = 0;
     for (; t + 4 <= sn; t += 4) {
@@ -374,7 +384,7 @@ struct FdBits {
     lo = need ? __builtin_bswap32(nx) : lo;
     nx = need ? n2 : nx;
     rd += need ? 1u : 0u;
-    s += need ? 32 : 0;
+    s &= 31;  // + 32 where it went below zero (>= -32 for a valid step)
     n2 = ring[(rd - 1) & (kFdRing - 1)];
   }
   __device__ __forceinline__ uint32_t at() const { return off0 + 4 * (rd - 3); }  // byte offset of the start of `lo`
@@ -466,17 +476,12 @@ struct FdPred {
     h[0] = (double)v;
     return v;
   }
-  // a full burst: the residuals staged in LDS become samples (wasted bits restored) in place; written out sixteen times, the
+  // a full burst: sixteen residuals in registers become samples (wasted bits restored); written out sixteen times, the
   // history's moves are register names
   template <int ORD>
-  __device__ __forceinline__ void burst(int32_t* stg, int wasted) {
-    int32_t r[kFdBurst];
-#pragma unroll
-    for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(r + t, stg + t, 16);
+  __device__ __forceinline__ void burst(int32_t (&r)[kFdBurst], int wasted) {
 #pragma unroll
     for (int t = 0; t < kFdBurst; ++t) r[t] = (int32_t)((uint32_t)step<ORD>(r[t]) << wasted);
-#pragma unroll
-    for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(stg + t, r + t, 16);
   }
   template <int ORD>
   __device__ __forceinline__ void some(int32_t* stg, int n, int wasted) {
@@ -606,7 +611,7 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
     lpc.shift = shift;
     int hat = order;  // generic path: index of the sample being restored
     // n staged residuals -> samples, in place
-    auto restore = [&](int n) {
+    auto restore = [&](int n) __attribute__((always_inline)) {
 #ifdef FD_NO_LPC  // tools only: what the prediction costs
       return;
 #endif
@@ -614,14 +619,11 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
         if (wasted)
           for (int t = 0; t < n; ++t) stg[t] = (int32_t)((uint32_t)stg[t] << wasted);
       } else if (cls == 1) {
-        if (n == kFdBurst) lpc.burst<4>(stg, wasted);
-        else lpc.some<4>(stg, n, wasted);
+        lpc.some<4>(stg, n, wasted);
       } else if (cls == 2) {
-        if (n == kFdBurst) lpc.burst<8>(stg, wasted);
-        else lpc.some<8>(stg, n, wasted);
+        lpc.some<8>(stg, n, wasted);
       } else if (cls == 3) {
-        if (n == kFdBurst) lpc.burst<12>(stg, wasted);
-        else lpc.some<12>(stg, n, wasted);
+        lpc.some<12>(stg, n, wasted);
       } else {
         for (int t = 0; t < n; ++t) {
           // s[i] = res + (sum_j coef[j] s[i - 1 - j]) >> shift with 64-bit wrapping sums (flac_decode.cpp lpc_restore_n)
@@ -654,26 +656,44 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
           const int n = count - j < kFdBurst ? count - j : kFdBurst;
           br.service();
           if (n == kFdBurst) {
-            // four trips of four codes: the residuals go to the stage 16 bytes at a time
-            for (int t = 0; t < kFdBurst; t += 4) {
-              int32_t r4[4];
+            // sixteen codes, residuals and samples in registers all the way to the next service's stores
+            int32_t r[kFdBurst];
+            {
               const uint32_t hi0 = br.hi, lo0 = br.lo, nx0 = br.nx, n20 = br.n2, rd0 = br.rd;
               const int s0 = br.s;
               int nmax = 0;
 #pragma unroll
-              for (int u = 0; u < 4; ++u) r4[u] = br.rice_window(k, &nmax);
-              if (__builtin_expect(nmax > 32, 0)) {
+              for (int t = 0; t < kFdBurst; ++t) r[t] = br.rice_window(k, &nmax);  // one basic block
+              if (__builtin_expect(nmax > 32, 0)) {  // a code beyond the window somewhere: the burst again, code by code
                 br.hi = hi0, br.lo = lo0, br.nx = nx0, br.n2 = n20, br.rd = rd0, br.s = s0;
+                for (int t = 0; t < kFdBurst; ++t) stg[t] = br.rice(k);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) r4[u] = br.rice(k);
+                for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(r + t, stg + t, 16);
               }
-              __builtin_memcpy(stg + t, r4, 16);
             }
+#ifndef FD_NO_LPC
+            if (cls == 1) {
+              lpc.burst<4>(r, wasted);
+            } else if (cls == 2) {
+              lpc.burst<8>(r, wasted);
+            } else if (cls == 3) {
+              lpc.burst<12>(r, wasted);
+            } else {  // no predictor, or the generic one: through the stage
+#pragma unroll
+              for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(stg + t, r + t, 16);
+              restore(n);
+#pragma unroll
+              for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(r + t, stg + t, 16);
+            }
+#endif
+#pragma unroll
+            for (int t = 0; t < kFdBurst; ++t) br.o[t] = r[t];
+            br.on = kFdBurst;
           } else {
             for (int t = 0; t < n; ++t) stg[t] = br.rice(k);
+            restore(n);
+            br.sn = n;
           }
-          restore(n);
-          br.sn = n;
           j += n;
         }
       }
