@@ -639,66 +639,74 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
         }
       }
     };
-    for (int part = 0; part < parts && br.at() <= guard; ++part) {
-      const int count = (bs >> porder) - (part == 0 ? order : 0);
-      const int k = (int)br.bits(pbits);
-      int j = 0;
-      if (k == esc) {
-        const int raw = (int)br.bits(5);
-        while (j < count && br.at() <= guard) {
-          const int n = count - j < 8 ? count - j : 8;
-          br.service();
-          for (int t = 0; t < n; ++t) stg[t] = br.sbits(raw);
-          restore(n);
-          br.sn = n;
-          j += n;
+    // ONE loop over bursts for the whole subframe, whatever its partitions: the lanes of a wave are frames whose partition
+    // orders differ (a libFLAC stream: 0..6 from subframe to subframe), and a loop nest over (partition, burst) would hold
+    // every lane at each partition's end until the lane with the longest partition got there.  Here a partition's header is
+    // a short branch at the top and every trip is a burst.
+    const int psize = bs >> porder;
+    int left = 0, part = 0, k = 0, raw = 0;
+    for (int i = order; i < bs && br.at() <= guard;) {
+      if (left == 0) {  // a partition begins (the first one may hold no residual at all)
+        k = (int)br.bits(pbits);
+        raw = k == esc ? (int)br.bits(5) : 0;
+        left = psize - (part == 0 ? order : 0);
+        ++part;
+        if (left == 0) continue;
+      }
+      const bool escaped = k == esc;
+      const int cap = escaped ? 8 : kFdBurst;
+      const int n = left < cap ? left : cap;
+      br.service();
+      if (!escaped && n == kFdBurst) {
+        // sixteen codes, residuals and samples in registers all the way to the next service's stores
+        int32_t r[kFdBurst];
+        {
+          const uint32_t hi0 = br.hi, lo0 = br.lo, nx0 = br.nx, n20 = br.n2, rd0 = br.rd;
+          const int s0 = br.s;
+          int nmax = 0;
+#pragma unroll
+          for (int t = 0; t < kFdBurst; ++t) r[t] = br.rice_window(k, &nmax);  // one basic block
+          if (__builtin_expect(nmax > 32, 0)) {  // a code beyond the window somewhere: the burst again, code by code
+            br.hi = hi0, br.lo = lo0, br.nx = nx0, br.n2 = n20, br.rd = rd0, br.s = s0;
+            for (int t = 0; t < kFdBurst; ++t) stg[t] = br.rice(k);
+#pragma unroll
+            for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(r + t, stg + t, 16);
+          }
         }
-      } else {
-        while (j < count && br.at() <= guard) {
-          const int n = count - j < kFdBurst ? count - j : kFdBurst;
-          br.service();
-          if (n == kFdBurst) {
-            // sixteen codes, residuals and samples in registers all the way to the next service's stores
-            int32_t r[kFdBurst];
-            {
-              const uint32_t hi0 = br.hi, lo0 = br.lo, nx0 = br.nx, n20 = br.n2, rd0 = br.rd;
-              const int s0 = br.s;
-              int nmax = 0;
-#pragma unroll
-              for (int t = 0; t < kFdBurst; ++t) r[t] = br.rice_window(k, &nmax);  // one basic block
-              if (__builtin_expect(nmax > 32, 0)) {  // a code beyond the window somewhere: the burst again, code by code
-                br.hi = hi0, br.lo = lo0, br.nx = nx0, br.n2 = n20, br.rd = rd0, br.s = s0;
-                for (int t = 0; t < kFdBurst; ++t) stg[t] = br.rice(k);
-#pragma unroll
-                for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(r + t, stg + t, 16);
-              }
-            }
 #ifndef FD_NO_LPC
-            if (cls == 1) {
-              lpc.burst<4>(r, wasted);
-            } else if (cls == 2) {
-              lpc.burst<8>(r, wasted);
-            } else if (cls == 3) {
-              lpc.burst<12>(r, wasted);
-            } else {  // no predictor, or the generic one: through the stage
+        if (cls >= 1 && cls <= 3) {
+          // the widest class among the lanes here serves them all (the coefficients beyond a lane's order are zero): one pass
+          // of the prediction per burst instead of one per class present in the wave
+          const int wcls = __builtin_amdgcn_ballot_w64(cls == 3) ? 3 : __builtin_amdgcn_ballot_w64(cls == 2) ? 2 : 1;
+          if (wcls == 1) {
+            lpc.burst<4>(r, wasted);
+          } else if (wcls == 2) {
+            lpc.burst<8>(r, wasted);
+          } else {
+            lpc.burst<12>(r, wasted);
+          }
+        } else {  // no predictor, or the generic one: through the stage
 #pragma unroll
-              for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(stg + t, r + t, 16);
-              restore(n);
+          for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(stg + t, r + t, 16);
+          restore(n);
 #pragma unroll
-              for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(r + t, stg + t, 16);
-            }
+          for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(r + t, stg + t, 16);
+        }
 #endif
 #pragma unroll
-            for (int t = 0; t < kFdBurst; ++t) br.o[t] = r[t];
-            br.on = kFdBurst;
-          } else {
-            for (int t = 0; t < n; ++t) stg[t] = br.rice(k);
-            restore(n);
-            br.sn = n;
-          }
-          j += n;
+        for (int t = 0; t < kFdBurst; ++t) br.o[t] = r[t];
+        br.on = kFdBurst;
+      } else {
+        if (escaped) {
+          for (int t = 0; t < n; ++t) stg[t] = br.sbits(raw);
+        } else {
+          for (int t = 0; t < n; ++t) stg[t] = br.rice(k);
         }
+        restore(n);
+        br.sn = n;
       }
+      left -= n;
+      i += n;
     }
     if (br.at() > guard) {  // ran off the frame (corrupt): never read far behind the file's buffer
       err |= kFdParse;
