@@ -184,6 +184,7 @@ EXPORTED_SYMBOLS = [
     "bp_notes_decode",
     "bp_note_candidates",
     "bp_infer_pcm_raw_candidates",
+    "bp_track_maps",
     "bp_notes_decode_candidates",
     "bp_notes_last_error",
     "bp_flac_info",
@@ -311,6 +312,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         vp, vp, C.c_int, i64, C.c_int, C.c_int, C.POINTER(bp_note_params), vp, vp, vp, C.POINTER(C.c_int)
     ]
     lib.bp_infer_pcm_raw_candidates.restype = C.c_int
+    lib.bp_track_maps.argtypes = [vp, i64, vp, vp, vp, C.c_int]
+    lib.bp_track_maps.restype = C.c_int
     lib.bp_notes_decode_candidates.argtypes = [
         vp, vp, vp, i64, C.POINTER(bp_note_params), vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64)
     ]

@@ -335,6 +335,7 @@ struct bp_context {
   ResamplePlan plan{};
   float* track_out = nullptr;  // [T, 88+88+264] staging when outputs are host pointers
   int64_t track_out_cap = 0;
+  int64_t maps_rows = 0;       // rows of the maps a *_candidates call left in track_out (bp_track_maps); 0: none
   // device-side note candidates (note_device.hip): bitmap [T][11] + bend map [T][88] (bytes), stats, the bend tables
   float* nd_buf = nullptr;
   int64_t nd_cap = 0;          // floats
@@ -1644,6 +1645,7 @@ static int track_core(bp_handle h, const float* d_samples, int64_t n_samples, fl
   const int64_t n_win = h_track_n_windows(h, n_samples);
   const int64_t T = h_track_n_frames(h, n_samples);
   float *d_note = note, *d_onset = onset, *d_contour = contour;
+  h->maps_rows = 0;
   if (out_kind == BP_MEM_HOST || out_kind == kTrackOutInternal) {
     const int64_t need = T * (88 + 88 + 264);
     if (need > h->track_out_cap) {
@@ -1665,7 +1667,10 @@ static int track_core(bp_handle h, const float* d_samples, int64_t n_samples, fl
     if (T > 0) launch_unwrap3(h->note, h->onset, h->contour, w0, n, T, d_note, d_onset, d_contour, s);
   }
   BP_HIP(hipGetLastError());
-  if (out_kind == kTrackOutInternal) return BP_OK;
+  if (out_kind == kTrackOutInternal) {
+    h->maps_rows = T;
+    return BP_OK;
+  }
   if (out_kind == BP_MEM_HOST && T > 0) {
     BP_HIP(hipMemcpyAsync(note, d_note, (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
     BP_HIP(hipMemcpyAsync(onset, d_onset, (size_t)T * 88 * 4, hipMemcpyDeviceToHost, s));
@@ -2077,6 +2082,24 @@ int bp_infer_pcm_raw_candidates(bp_handle h, const void* pcm, int format, int64_
   if (rc) return rc;
   float *d_note = h->track_out, *d_onset = d_note + T * 88, *d_contour = d_onset + T * 88;
   return candidates_core(h, d_note, d_onset, d_contour, T, params, note_out, cand_bits, bend_map, status);
+}
+
+int bp_track_maps(bp_handle h, int64_t n_frames, float* note, float* onset, float* contour, int mem_kind) {
+  if (!h) return BP_ERR_INVALID_ARG;
+  if (n_frames <= 0 || n_frames != h->maps_rows || !note || !onset || !contour ||
+      (mem_kind != BP_MEM_HOST && mem_kind != BP_MEM_DEVICE)) {
+    h->err = "bp_track_maps: no maps of that many rows are left on the device (call it right after a *_candidates call of "
+             "this handle, with that call's row count) or a null / unknown destination";
+    return BP_ERR_INVALID_ARG;
+  }
+  BP_HIP(hipSetDevice(h->device));
+  const int64_t T = n_frames;
+  const float *d_note = h->track_out, *d_onset = d_note + T * 88, *d_contour = d_onset + T * 88;
+  const hipMemcpyKind kind = mem_kind == BP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  BP_HIP(hipMemcpyAsync(note, d_note, (size_t)T * 88 * 4, kind, h->stream));
+  BP_HIP(hipMemcpyAsync(onset, d_onset, (size_t)T * 88 * 4, kind, h->stream));
+  BP_HIP(hipMemcpyAsync(contour, d_contour, (size_t)T * 264 * 4, kind, h->stream));
+  return wait_stream(h);
 }
 
 // ---- FLAC decoded on the device (flac_device.hip) ---------------------------------------------------------------------------

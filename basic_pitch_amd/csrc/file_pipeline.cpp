@@ -829,11 +829,14 @@ int bp_transcribe_files(bp_handle* handles, int n_handles, const char* const* pa
                                                            prm.notes.include_pitch_bends ? bend_map : nullptr, &status)
                                 : bp_infer_pcm_raw_candidates(h, pcm, format, n_frames, channels, sr, &prm.notes, note, cand_bits,
                                                               prm.notes.include_pitch_bends ? bend_map : nullptr, &status);
-            if (rc == BP_OK && status != 0) use_cand = false;  // a NaN in the maps: numpy's rules need the maps themselves
-          }
-          if (rc == BP_OK && !use_cand)
+            if (rc == BP_OK && status != 0) {  // a NaN in the maps: numpy's rules need the maps themselves — they are
+              use_cand = false;                // still on the device, the lane is still ours
+              rc = bp_track_maps(h, T, note, onset, contour, BP_MEM_HOST);
+            }
+          } else {
             rc = flac_on_device ? bp_infer_flac(h, fb, n_bytes, note, onset, contour, BP_MEM_HOST)
                                 : bp_infer_pcm_raw(h, pcm, format, n_frames, channels, sr, note, onset, contour, BP_MEM_HOST);
+          }
           if (rc != BP_OK) err = bp_last_error(h);
         }
         release(lane);

@@ -398,6 +398,11 @@ int bp_infer_pcm_raw_candidates(bp_handle h, const void* pcm, int format, int64_
 /* the same from a FLAC file's bytes, decoded on the device (bp_infer_flac) */
 int bp_infer_flac_candidates(bp_handle h, const void* file, size_t nbytes, const bp_note_params* params, float* note_out,
                              uint8_t* cand_bits, int8_t* bend_map, int* status);
+/* The three posteriorgrams the LAST bp_infer_*_candidates call of this handle left on the device, n_frames rows each
+ * ([n][88], [n][88], [n][264]; host or device destinations): what that call's *status == 1 asks for (a NaN in the maps: the
+ * host decoder needs the maps themselves, bp_notes_decode) without running the track again.  BP_ERR_INVALID_ARG when
+ * n_frames is not the row count of that call or another call has used the handle's track buffer since. */
+int bp_track_maps(bp_handle h, int64_t n_frames, float* note, float* onset, float* contour, int mem_kind);
 /* The sequential half (host): output_to_notes_polyphonic from the candidates (note_creation.py:404-509), pitch bends read
  * from bend_map, frame times as bp_notes_decode.  `note` is only read. */
 int bp_notes_decode_candidates(const float* note, const uint8_t* cand_bits, const int8_t* bend_map, int64_t n_frames,

@@ -1279,3 +1279,42 @@ def test_whole_path_is_run_to_run_deterministic():
     tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "experiments", "determinism_stress.py")
     res = subprocess.run([sys.executable, tool, "150"], capture_output=True, text=True, timeout=600, env=_ab_env())
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_track_maps_gives_the_nan_fallback_its_maps_without_a_second_pass():
+    """when bp_infer_pcm_raw_candidates reports status 1 (a NaN in the maps, or an onset threshold <= 0 as
+    here) the caller needs the maps themselves; bp_track_maps hands over the three posteriorgrams that call left on the device — bit for bit what
+    bp_infer_pcm_raw returns for the same samples — and refuses once the handle's track buffer has been used again."""
+    import ctypes as C
+
+    from basic_pitch_amd import Model, _native
+    from basic_pitch_amd.note_creation import _note_params
+
+    rng = np.random.default_rng(5)
+    n = 3 * 22050
+    pcm = (0.2 * np.sin(2 * np.pi * 330.0 * np.arange(n) / 22050.0) + 0.01 * rng.standard_normal(n)).astype(np.float32)
+    pcm = pcm.reshape(-1, 1)
+    m = Model(max_windows=16)
+    want = m.predict_pcm_raw(pcm, _native.BP_PCM_F32, n, 1, 22050)
+    T = want["note"].shape[0]
+    prm = _note_params(0.0, 0.3, 11, True, None, None, True, 11, True)
+    note = np.empty((T, 88), np.float32)
+    bits = np.empty((T, 12), np.uint8)
+    bend = np.empty((T, 88), np.int8)
+    status = C.c_int(0)
+    rc = m._lib.bp_infer_pcm_raw_candidates(m._handle, pcm.ctypes.data, _native.BP_PCM_F32, n, 1, 22050, C.byref(prm),
+                                            note.ctypes.data, bits.ctypes.data, bend.ctypes.data, C.byref(status))
+    assert rc == 0 and status.value == 1
+    got = {k: np.empty_like(want[k]) for k in ("note", "onset", "contour")}
+    assert m._lib.bp_track_maps(m._handle, T + 1, got["note"].ctypes.data, got["onset"].ctypes.data, got["contour"].ctypes.data,
+                                _native.BP_MEM_HOST) == -1
+    rc = m._lib.bp_track_maps(m._handle, T, got["note"].ctypes.data, got["onset"].ctypes.data, got["contour"].ctypes.data,
+                              _native.BP_MEM_HOST)
+    assert rc == 0
+    for k in got:
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+    m.predict_pcm_raw(pcm, _native.BP_PCM_F32, n, 1, 22050)  # the track buffer is used by another call: nothing to hand over
+    assert m._lib.bp_track_maps(m._handle, T, got["note"].ctypes.data, got["onset"].ctypes.data, got["contour"].ctypes.data,
+                                _native.BP_MEM_HOST) == -1
+    m.close()
