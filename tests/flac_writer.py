@@ -165,7 +165,7 @@ def _subframe(bw, s, bps, kind, porder=0, rice2=False, escape=False, lpc_order=8
 
 def encode(pcm, sample_rate, bits, blocksize=1152, plan=None, total_in_header=True, md5_in_header=True, id3=False):
     """pcm: int array [n, channels].  plan(frame_index) -> dict(kind=..., stereo="indep"|"ls"|"sr"|"ms", porder=..,
-    rice2=.., escape=..) chooses how each frame is coded (cycled defaults exercise everything)."""
+    rice2=.., escape=.., lpc_order=1..32) chooses how each frame is coded (cycled defaults exercise everything)."""
     pcm = np.asarray(pcm, dtype=np.int64)
     n, ch = pcm.shape
     kinds = ["fixed2", "lpc", "fixed0", "fixed1", "verbatim", "fixed3", "fixed4", "lpc"]
@@ -223,7 +223,7 @@ def encode(pcm, sample_rate, bits, blocksize=1152, plan=None, total_in_header=Tr
                 kind = "fixed2"
             elif kind.startswith("fixed") and bs <= int(kind[5:]):
                 kind = "verbatim"
-            _subframe(bw, x, w, kind, p["porder"], p["rice2"], p["escape"])
+            _subframe(bw, x, w, kind, p["porder"], p["rice2"], p["escape"], lpc_order=int(p.get("lpc_order", 8)))
         bw.align()
         body = bw.bytes()
         frames += body + struct.pack(">H", crc16(body))

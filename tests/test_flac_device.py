@@ -195,3 +195,24 @@ def test_bench_corpus_encoder(model, tmp_path):
     assert names[0] == names[1] == names[2] == ["tone_basic_pitch.csv", "tone_basic_pitch.mid"]
     for f in names[0]:
         assert outs["wav"][f] == outs["flac_dev"][f] == outs["flac_host"][f], f
+
+
+def test_every_lpc_order_with_the_classes_mixed_in_one_wave(model):
+    """LPC orders 1..32 cycling from frame to frame (the lanes of one wave are frames): the register predictors of 4 / 8 / 12
+    products — the widest class present in the wave serves all its lanes —, the generic path of the orders above 12, partition
+    orders 0..2, Rice and Rice2, escaped partitions; 16- and 24-bit.  device == source == host decoder."""
+    orders = [1, 2, 4, 5, 8, 9, 12, 13, 20, 32, 3, 11, 7, 16, 6, 10]
+    for bits, bs, seed in ((16, 256, 11), (24, 192, 12), (16, 1000, 13)):
+        rng = np.random.default_rng(seed)
+        n = bs * 70 + 31
+        t = np.arange(n)
+        full = 1 << (bits - 1)
+        x = np.stack([0.3 * full * np.sin(t * 0.021) + rng.integers(-full // 64, full // 64, n),
+                      0.2 * full * np.sin(t * 0.0057) + rng.integers(-full // 4096 - 2, full // 4096 + 2, n)], 1).astype(np.int64)
+        plan = lambda fi: dict(kind="lpc", lpc_order=orders[fi % len(orders)], porder=fi % 3, rice2=bool(fi % 2),
+                               escape=(fi % 7 == 6), stereo=("indep", "ms", "ls", "sr")[fi % 4])
+        data = FW.encode(x, 48000, bits, blocksize=bs, plan=plan)
+        got, _ = model.flac_decode_device(data)
+        assert np.array_equal(got, x), (bits, bs)
+        host, _ = _host_ints(data, bits)
+        assert np.array_equal(got, host), (bits, bs)
