@@ -330,9 +330,18 @@ struct FdBits {
     if (on) {
 #ifndef FD_NO_STORE
 #pragma unroll
-      for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(out + t, o + t, 16);
+      for (int t = 0; t < kFdBurst; t += 4) {
+        // streaming stores: a lane's 64 bytes per burst open a fresh cache line that nothing reads before the finalize
+        // kernel; as ordinary stores they cost the decode 12 % (the wait at the next service sits behind their allocation)
+        typedef int32_t I4 __attribute__((ext_vector_type(4)));
+        typedef I4 I4u __attribute__((aligned(4)));
+        I4 v = {o[t], o[t + 1], o[t + 2], o[t + 3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<I4u*>(out + t));
+      }
 #endif
+#ifndef FD_STORE_SAME  // tools only: every burst of a lane lands on the same 64 bytes (what the stores' destinations cost)
       out += kFdBurst;
+#endif
       on = 0;
     }
 #ifndef FD_NO_STORE  // tools only: what the stores cost
