@@ -216,3 +216,43 @@ def test_every_lpc_order_with_the_classes_mixed_in_one_wave(model):
         assert np.array_equal(got, x), (bits, bs)
         host, _ = _host_ints(data, bits)
         assert np.array_equal(got, host), (bits, bs)
+
+
+def test_blocking_wait_lane_sleeps_while_the_device_decodes():
+    """BP_FLAG_BLOCKING_WAIT (the lanes of a file job): the end of a call sleeps between event queries — a blocking-sync event
+    wait polls on this runtime, user time == wall time (tools/experiments/host_cpu.py) — so a lane that waits for 20 decodes
+    of a 20-second stream costs its core a fraction of the wall time, and decodes the same samples."""
+    import ctypes as C
+    import resource
+    import time
+
+    from basic_pitch_amd import Model
+
+    rng = np.random.default_rng(21)
+    n = 20 * 44100
+    t = np.arange(n)
+    x = np.stack([8000 * np.sin(t * 0.02) + rng.integers(-500, 500, n), 6000 * np.sin(t * 0.013) + rng.integers(-300, 300, n)],
+                 1).astype(np.int64)
+    data = FW.encode(x, 44100, 16, blocksize=4096, plan=lambda fi: dict(kind="lpc", porder=3, rice2=False,
+                                                                                          escape=False, stereo="indep"))
+    spin, sleep = Model(max_windows=16), Model(max_windows=16, blocking_wait=True)
+    a, _ = spin.flac_decode_device(data)
+    b, _ = sleep.flac_decode_device(data)
+    assert np.array_equal(a, b) and np.array_equal(a, x)
+    nf = C.c_int64()
+
+    def cost(m):
+        for _ in range(3):
+            m._lib.bp_flac_decode_device(m._handle, data, len(data), None, 0, C.byref(nf))
+        r0, t0 = resource.getrusage(resource.RUSAGE_SELF), time.perf_counter()
+        for _ in range(20):
+            assert m._lib.bp_flac_decode_device(m._handle, data, len(data), None, 0, C.byref(nf)) == 0
+        r1, t1 = resource.getrusage(resource.RUSAGE_SELF), time.perf_counter()
+        return (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime), t1 - t0
+
+    cpu_spin, wall_spin = cost(spin)
+    cpu_sleep, wall_sleep = cost(sleep)
+    assert cpu_sleep < 0.6 * wall_sleep, (cpu_sleep, wall_sleep)
+    assert wall_sleep < 2.0 * wall_spin + 0.01, (wall_sleep, wall_spin)
+    spin.close()
+    sleep.close()
