@@ -261,10 +261,13 @@ __global__ __launch_bounds__(kFdChainThreads) void flac_chain_kernel(const FdCan
 }
 
 // ---- 3. one lane per frame -----------------------------------------------------------------------------------------------------
-// The stream as 32-bit words: `hi` and `lo` hold the next 64 bits, `o` of `hi`'s are consumed, `nx` is the word behind them,
-// loaded two refills ahead of its use (a lane is alone on its chain: nothing else hides a load's latency).  A peek is one
-// funnel shift, a skip an add and — every 32 bits — a rotation of the three words; no 64-bit shifts on the serial path.
-constexpr int kFdLanes = 64;     // lanes (frames) per workgroup: one wave
+// The stream as 32-bit words: `hi` and `lo` hold the next 64 bits, the window starts `s` bits above the bottom of `hi`, `nx`
+// and `n2` are the words behind them, read from the lane's ring in LDS two refills ahead of their use.  A peek is one funnel
+// shift, a skip a subtraction and — every 32 bits — a rotation of the words; no 64-bit shifts on the serial path.
+#ifndef FD_LANES  // tools: 32 or 16 frames per wave are SLOWER (1.42 / 1.38 ms against 1.26: the vector pipe does not skip the
+#define FD_LANES 64  // passes of inactive lanes, and the waves crowd fewer CUs)
+#endif
+constexpr int kFdLanes = FD_LANES;  // lanes (frames) per workgroup: one wave
 constexpr int kFdRing = 128;     // words of its stream a lane holds in LDS
 constexpr int kFdRingRow = 132;  // row stride in words: 16-byte rows for ds_write_b128, the lanes' equal indices on four banks
 constexpr int kFdBurst = 16;     // codes between two services
