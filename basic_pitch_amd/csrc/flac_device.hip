@@ -301,6 +301,7 @@ struct FdBits {
                  // v_alignbit's own shift operand, so a peek is that one instruction whatever the position
   uint32_t* ring;      // LDS, this lane's kFdRing words
   uint32_t rd, wr;     // words read from / committed to the ring (stream word numbers): `lo` is word rd - 3
+  uint32_t wmax;       // the last word a block may start on (inside the buffer's padding)
   typedef uint32_t Block __attribute__((ext_vector_type(4)));
   Block pb0, pb1, pb2, pb3;  // blocks in flight (named, not an array: they live in registers)
   int np;
@@ -311,12 +312,16 @@ struct FdBits {
   int on;              // 0 or kFdBurst
 
   __device__ __forceinline__ Block get(uint32_t word) const {
+    // never behind the 64 zero bytes that follow the file in its buffer: a lane that has lost a corrupt stream (a burst of
+    // maximal unary runs is 16 KB) reads the padding again and again, its frame fails the position check or the CRC-16
+    const uint32_t w = word < wmax ? word : wmax;
     Block b;
-    __builtin_memcpy(&b, org + 4 * (size_t)word, 16);
+    __builtin_memcpy(&b, org + 4 * (size_t)w, 16);
     return b;
   }
   __device__ __forceinline__ void put(uint32_t word, Block b) { __builtin_memcpy(ring + (word & (kFdRing - 1)), &b, 16); }
-  __device__ __forceinline__ void init(const uint8_t* file, uint32_t off, uint32_t* ring_row, int32_t* stage_row) {
+  __device__ __forceinline__ void init(const uint8_t* file, uint32_t off, uint32_t nbytes, uint32_t* ring_row, int32_t* stage_row) {
+    wmax = (nbytes + 48 - off) >> 2;  // off < nbytes: a frame starts inside the file
     org = file + off, off0 = off, s = 0, hi = 0, ring = ring_row, stg = stage_row, out = nullptr, sn = 0, on = 0, wr = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {  // 32 words committed before the first bit is read
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
   int err = 0;
 
   FdBits br;
-  br.init(p.file, fr.offset + fr.hdr_bytes, ring[lane], stage[lane]);
+  br.init(p.file, fr.offset + fr.hdr_bytes, p.st.nbytes, ring[lane], stage[lane]);
   int32_t* const stg = stage[lane];
   int32_t* scr = p.scratch + (size_t)f * p.st.max_block * n_ch;
   const uint32_t guard = fr.end + 16;  // a lane that reads past this has lost the stream

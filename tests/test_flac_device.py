@@ -256,3 +256,32 @@ def test_blocking_wait_lane_sleeps_while_the_device_decodes():
     assert wall_sleep < 2.0 * wall_spin + 0.01, (wall_sleep, wall_spin)
     spin.close()
     sleep.close()
+
+
+def test_corrupt_small_files_are_errors_or_the_host_decoders_samples(model):
+    """A lane that loses a corrupt stream runs ahead of its frame (long unary runs: kilobytes per burst) — it must stay inside
+    the file's buffer (its block loads are clamped to the padding behind the file) and the call must end in an error or, if
+    the damage happens to be decodable, in exactly what the host decoder makes of the same bytes.  Small files: the buffer's
+    slack behind them is smallest."""
+    rng = np.random.default_rng(99)
+    n = 700
+    x = np.stack([3000 * np.sin(np.arange(n) * 0.05) + rng.integers(-200, 200, n)], 1).astype(np.int64)
+    good = FW.encode(x, 16000, 16, blocksize=256, plan=lambda fi: dict(kind="lpc", porder=1, rice2=False, escape=False))
+    start = good.index(b"fLaC") + 42
+    outcomes = {"error": 0, "decoded": 0}
+    for trial in range(150):
+        bad = bytearray(good)
+        for _ in range(1 + trial % 4):
+            pos = int(rng.integers(start, len(bad)))
+            bad[pos] = 0 if trial % 3 == 0 else int(rng.integers(0, 256))  # zeros make long unary runs
+        if trial % 5 == 0:
+            del bad[int(rng.integers(start + 10, len(bad))):]
+        try:
+            got, _ = model.flac_decode_device(bytes(bad))
+        except ValueError:
+            outcomes["error"] += 1
+            continue
+        outcomes["decoded"] += 1
+        host, _ = _host_ints(bytes(bad), 16)
+        assert np.array_equal(got, host), trial
+    assert outcomes["error"] > 100, outcomes
