@@ -55,7 +55,7 @@ D1_BYTES_PER_WINDOW = 174 * 448 * 4 + 172 * 264 * 8 * 4  # zp read + c1 written
 HBM_PEAK_GBS = 8000.0
 DTYPE_F16 = "f32 I/O + accumulate, split-f16 (22-bit hi+lo) MFMA operands, all three products of every layer on f16 MFMA"
 DTYPE_DEFAULT = DTYPE_F16  # since round 3 the default IS the all-f16 split (fp32-class)
-PMC_PROFILE = "r06_a"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
+PMC_PROFILE = "r06_b"  # the committed rocprofv3 --pmc profile `roofline.traffic` is read from
 
 
 def pmc_traffic(kernel_key: str, batch: int):
