@@ -271,26 +271,45 @@ constexpr int kFdLanes = FD_LANES;  // lanes (frames) per workgroup: one wave
 constexpr int kFdRing = 128;     // words of its stream a lane holds in LDS
 constexpr int kFdRingRow = 132;  // row stride in words: 16-byte rows for ds_write_b128, the lanes' equal indices on four banks
 constexpr int kFdBurst = 16;     // codes between two services
-constexpr int kFdStageRow = 20;  // kFdBurst samples + padding (16-byte rows)
+constexpr int kFdSlotRow = 20;   // kFdBurst values + padding (16-byte rows)
+constexpr int kFdSlots = 8;      // bursts a lane's parser may be ahead of its restorer
 
-// A lane's view of its frame: the bit window, the words behind it, the samples on their way out.
+// A frame is decoded by TWO lanes of the same number in two waves of a workgroup: the PARSER walks the bit stream (subframe
+// headers, Rice codes -> residuals), the RESTORER runs the prediction and stores the samples.  The two chains — the bit
+// position, the prediction history — share nothing, and a wave that is alone on its SIMD issues one instruction per ~8
+// cycles on a dependent chain: side by side in one wave they add up (the compiler's schedule does not interleave them,
+// profiles/r06_flac_device.md), in two waves they overlap.  They talk through a mailbox in LDS, per lane: kFdSlots slots of a
+// burst (<= 16 values + a descriptor word), a produced and a consumed counter (release / acquire at workgroup scope).
+enum : uint32_t {
+  kFdMsgResidual = 0,  // n residuals of the current subframe
+  kFdMsgSamples = 1,   // n samples as coded (verbatim subframe)
+  kFdMsgSubframe = 2,  // a subframe begins: order / shift / wasted bits / channel in the lane's descriptor, coefficients and
+                       // warm-up samples in `coefs` / `hist`
+  kFdMsgConstant = 3,  // slot[0] = the value of a constant subframe
+  kFdMsgEnd = 4,       // the frame is parsed (or given up)
+  kFdMsgCodes = 5,     // a full burst of Rice codes as the parser saw them: 16 windows of 32 bits and their 16 lengths (bytes of
+                       // words 16..19), the parameter in bits 16.. of the descriptor — the restorer cuts the values out: the
+                       // parser's chain is the bit position alone (811 us with the values composed by the parser, 795 so)
+};
+constexpr uint32_t kFdSpinCap = 1u << 24;  // reads of a counter before a wave gives its partner up (a bug, not a stream)
+
+// The parser's view of its frame: the bit window and the words behind it.
 //
-// What bounds this kernel is neither arithmetic nor bandwidth but the latency of the lanes' own memory operations, and the
-// fact that a wave has ONE counter for them (vmcnt: loads and stores alike on gfx9).  A lane needs its next word every ~5
-// codes, but SOME lane of the 64 needs one at nearly every code: with a load per refill the wave sat out an L2 / HBM round
-// trip per code (measured: 490 core cycles per Rice code with prediction and stores compiled out, SQ_WAIT_ANY 60 - 68 % of
-// the wave's cycles, 1.2 load instructions per code and wave).  So the lanes touch global memory together, at a SERVICE
-// every kFdBurst codes:
+// What bounds it is neither arithmetic nor bandwidth but the latency of the lanes' own memory operations, and the fact that
+// a wave has ONE counter for them (vmcnt).  A lane needs its next word every ~5 codes, but SOME lane of the 64 needs one at
+// nearly every code: with a load per refill the wave sat out an L2 / HBM round trip per code (measured: 490 core cycles per
+// Rice code with prediction and stores compiled out, SQ_WAIT_ANY 60 - 68 % of the wave's cycles, 1.2 load instructions per
+// code and wave).  So the lanes touch global memory together, at a SERVICE every kFdBurst codes:
 //   * the stream lives in a ring of kFdRing words per lane in LDS; a refill of the window is a ds_read (its own counter,
-//     ~64 cycles, asked for one refill ahead);
+//     ~64 cycles, asked for two refills ahead);
 //   * a service commits the <= 4 blocks of 16 bytes it asked for at the PREVIOUS service (the one wait: everything in
-//     flight is a burst old), asks for the next <= 4 where the ring has room, and sends the previous burst's samples —
-//     staged in LDS — to global memory.  Invariant: a lane that consumes <= 16 words per burst (a code of the fast path is
-//     <= 32 bits) has >= 32 words committed after every service (c' = c - u + 16 while c < 112; >= 109 - 16 above), the
-//     header fields of a subframe (<= 34 + 16 words) sit between two double services (refuel()), a code longer than the
-//     window (unary runs of hundreds of zeros: the test-side encoder writes them) serves itself every four words and is
-//     followed by a refuel.  Should a lane run dry anyway it reads stale words: memory-safe, the frame's CRC-16 fails, the
-//     call reports the stream as not decodable here.
+//     flight is a burst old) and asks for the next 4.  Invariant: a lane that consumes <= 16 words per burst (a code of
+//     the fast path is <= 32 bits) has >= 32 words committed after every service (c' = c - u + 16 while c < 112; >= 109 -
+//     16 above), the header fields of a subframe (<= 34 + 16 words) sit between two double services (refuel()), a code
+//     longer than the window (unary runs of hundreds of zeros: the test-side encoder writes them) serves itself every four
+//     words and is followed by a refuel.  Should a lane run dry anyway it reads stale words: memory-safe, the frame's
+//     CRC-16 fails, the call reports the stream as not decodable here.
+// The parser never stores to global memory (the restorer does): its one wait is for loads alone.
 struct FdBits {
   const uint8_t* org;  // the byte the stream's word 0 starts on (frame offset + header length)
   uint32_t off0;       // its offset from the file's start
@@ -305,11 +324,6 @@ struct FdBits {
   typedef uint32_t Block __attribute__((ext_vector_type(4)));
   Block pb0, pb1, pb2, pb3;  // blocks in flight (named, not an array: they live in registers)
   int np;
-  int32_t* stg;        // LDS, this lane's staged samples
-  int32_t* out;        // where the first of them goes
-  int sn;
-  int32_t o[kFdBurst];  // a full burst's samples stay in registers until the next service
-  int on;              // 0 or kFdBurst
 
   __device__ __forceinline__ Block get(uint32_t word) const {
     // never behind the 64 zero bytes that follow the file in its buffer: a lane that has lost a corrupt stream (a burst of
@@ -320,9 +334,9 @@ struct FdBits {
     return b;
   }
   __device__ __forceinline__ void put(uint32_t word, Block b) { __builtin_memcpy(ring + (word & (kFdRing - 1)), &b, 16); }
-  __device__ __forceinline__ void init(const uint8_t* file, uint32_t off, uint32_t nbytes, uint32_t* ring_row, int32_t* stage_row) {
+  __device__ __forceinline__ void init(const uint8_t* file, uint32_t off, uint32_t nbytes, uint32_t* ring_row) {
     wmax = (nbytes + 48 - off) >> 2;  // off < nbytes: a frame starts inside the file
-    org = file + off, off0 = off, s = 0, hi = 0, ring = ring_row, stg = stage_row, out = nullptr, sn = 0, on = 0, wr = 0;
+    org = file + off, off0 = off, s = 0, hi = 0, ring = ring_row, wr = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {  // 32 words committed before the first bit is read
       pb0 = get(wr), pb1 = get(wr + 4), pb2 = get(wr + 8), pb3 = get(wr + 12);
@@ -332,37 +346,6 @@ struct FdBits {
     pb0 = get(wr), pb1 = get(wr + 4), pb2 = get(wr + 8), pb3 = get(wr + 12);
     np = 4;
     lo = __builtin_bswap32(ring[0]), nx = ring[1], n2 = ring[2], rd = 3;
-  }
-  // the samples of the previous burst leave (they were staged before the wait that opened this service)
-  __device__ __forceinline__ void flush() {
-    if (on) {
-#ifndef FD_NO_STORE
-#pragma unroll
-      for (int t = 0; t < kFdBurst; t += 4) {
-        // streaming stores: a lane's 64 bytes per burst open a fresh cache line that nothing reads before the finalize
-        // kernel; as ordinary stores they cost the decode 12 % (the wait at the next service sits behind their allocation)
-        typedef int32_t I4 __attribute__((ext_vector_type(4)));
-        typedef I4 I4u __attribute__((aligned(4)));
-        I4 v = {o[t], o[t + 1], o[t + 2], o[t + 3]};
-        __builtin_nontemporal_store(v, reinterpret_cast<I4u*>(out + t));
-      }
-#endif
-#ifndef FD_STORE_SAME  // tools only: every burst of a lane lands on the same 64 bytes (what the stores' destinations cost)
-      out += kFdBurst;
-#endif
-      on = 0;
-    }
-#ifndef FD_NO_STORE  // tools only: what the stores cost
-    int t = 0;
-    for (; t + 4 <= sn; t += 4) {
-      int32_t v[4];
-      __builtin_memcpy(v, stg + t, 16);
-      __builtin_memcpy(out + t, v, 16);
-    }
-    for (; t < sn; ++t) out[t] = stg[t];
-#endif
-    out += sn;
-    sn = 0;
   }
   __device__ __forceinline__ void service() {
     if (np > 0) put(wr, pb0);
@@ -375,15 +358,10 @@ struct FdBits {
     // all four asked for whatever the room: a load under a lane mask would make the compiler guard its target registers
     // with a wait of its own — behind the load issued just before; the blocks without room are asked for again next time
     pb0 = get(wr), pb1 = get(wr + 4), pb2 = get(wr + 8), pb3 = get(wr + 12);
-    flush();
   }
   __device__ __forceinline__ void refuel() {  // up to 32 more words committed at once (before a subframe's header fields)
     service();
     service();
-  }
-  __device__ __forceinline__ void begin_row(int32_t* row) {
-    flush();
-    out = row;
   }
   __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)s); }  // the next 32 bits
   __device__ __forceinline__ void skip(int n) {  // n <= 32
@@ -394,7 +372,7 @@ struct FdBits {
       ++rd, s += 32;
     }
   }
-  // the same without a branch (n <= 32 for a valid step): the trip of four codes is one basic block, its instructions
+  // the same without a branch (n <= 32 for a valid step): the burst of sixteen codes is one basic block, its instructions
   // interleave; n2 is read again at every step (the same word until a refill moves rd)
   __device__ __forceinline__ void skip_select(int n) {
     s -= n;
@@ -404,7 +382,11 @@ struct FdBits {
     nx = need ? n2 : nx;
     rd += need ? 1u : 0u;
     s &= 31;  // + 32 where it went below zero (>= -32 for a valid step)
+#ifdef FD_NO_RING_READ  // tools only (wrong samples): what the ring read of every step costs the parser
+    n2 ^= rd;
+#else
     n2 = ring[(rd - 1) & (kFdRing - 1)];
+#endif
   }
   __device__ __forceinline__ uint32_t at() const { return off0 + 4 * (rd - 3); }  // byte offset of the start of `lo`
   __device__ __forceinline__ uint32_t bits(int k) {  // k <= 32
@@ -451,15 +433,16 @@ struct FdBits {
     }
     return (int32_t)(v >> 1) ^ -(int32_t)(v & 1);
   }
-  // the same for a trip that checks afterwards: no branch for the long code, *nmax collects the lengths; a trip with one
-  // beyond the window is decoded again from the trip's start by rice() (what this wrote and skipped then was garbage)
-  __device__ __forceinline__ int32_t rice_window(int k, int* nmax) {
+  // the same for a burst that checks afterwards: no branch for the long code, *nmax collects the lengths; a burst with one
+  // beyond the window is decoded again from its start by rice() (what this stepped over then was garbage).  Returns the
+  // window the code starts in, *n its length: the value is cut out by the restorer (fd_rice_value).
+  __device__ __forceinline__ uint32_t rice_window(int k, int* n_out, int* nmax) {
     const uint32_t w = peek();
     const int n = (w ? __builtin_clz(w) : 32) + 1 + k;
     *nmax = n > *nmax ? n : *nmax;
-    const uint32_t v = ((uint32_t)(n - 1 - k) << k) | __builtin_amdgcn_ubfe(w, (uint32_t)(32 - n), (uint32_t)k);
+    *n_out = n;
     skip_select(n);
-    return (int32_t)(v >> 1) ^ -(int32_t)(v & 1);
+    return w;
   }
   __device__ __forceinline__ uint32_t byte_pos() const { return at() - (uint32_t)((s + 7) >> 3); }  // of the next unread bit
   __device__ __forceinline__ uint32_t bytes_consumed_aligned() {  // after dropping the bits up to the next byte boundary
@@ -467,6 +450,12 @@ struct FdBits {
     return byte_pos();
   }
 };
+
+// the residual of a Rice code of length n <= 32 with parameter k that starts at the top of window w
+__device__ __forceinline__ int32_t fd_rice_value(uint32_t w, int n, int k) {
+  const uint32_t v = ((uint32_t)(n - 1 - k) << k) | __builtin_amdgcn_ubfe(w, (uint32_t)(32 - n), (uint32_t)k);
+  return (int32_t)(v >> 1) ^ -(int32_t)(v & 1);
+}
 
 // Linear prediction with the history in registers, as float64: a restored sample is an int32, a coefficient has <= 15 bits, a
 // sum of <= 12 products stays below 2^51 — every operation is exact.  (The vector pipe runs v_fma_f64 at a fraction of the
@@ -503,8 +492,8 @@ struct FdPred {
     for (int t = 0; t < kFdBurst; ++t) r[t] = (int32_t)((uint32_t)step<ORD>(r[t]) << wasted);
   }
   template <int ORD>
-  __device__ __forceinline__ void some(int32_t* stg, int n, int wasted) {
-    for (int t = 0; t < n; ++t) stg[t] = (int32_t)((uint32_t)step<ORD>(stg[t]) << wasted);
+  __device__ __forceinline__ void some(int32_t* v, int n, int wasted) {
+    for (int t = 0; t < n; ++t) v[t] = (int32_t)((uint32_t)step<ORD>(v[t]) << wasted);
   }
 };
 
@@ -521,15 +510,64 @@ struct FdDecodeParams {
   const uint16_t* crc_tab;  // [8][256]
 };
 
-__global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p) {
-  __shared__ int32_t hist[32][kFdLanes];   // the lane's last 32 restored samples, a ring (orders above 12; warm-up samples)
+// sixteen bytes to a row of scratch as a streaming store: a lane's 64 bytes per burst open a fresh cache line that nothing
+// reads before the finalize kernel (as ordinary stores they cost the single-wave form of this kernel 12 %)
+__device__ __forceinline__ void fd_store4(int32_t* dst, int32_t a, int32_t b, int32_t c, int32_t d) {
+#ifndef FD_NO_STORE  // tools only: what the stores cost
+  typedef int32_t I4 __attribute__((ext_vector_type(4)));
+  typedef I4 I4u __attribute__((aligned(4)));
+  const I4 v = {a, b, c, d};
+  __builtin_nontemporal_store(v, reinterpret_cast<I4u*>(dst));
+#endif
+}
+
+// a frame's CRC-16 (poly 0x8005, no reflection, initial value 0: flac_decode.cpp crc16), eight bytes per table step (tables in
+// LDS), 64 bytes per trip with the next 64 asked for before this trip's steps: the wave waits for memory once per 64 bytes
+// (with 8 bytes per load it waited per load: ~400 us of a 1 ms kernel, tools -DFD_PHASES)
+__device__ __forceinline__ uint32_t fd_crc16(const uint16_t (*crc)[256], const uint8_t* d, uint32_t n) {
+  uint32_t cc = 0, i = 0;
+  auto step8 = [&](uint32_t w0, uint32_t w1) __attribute__((always_inline)) {
+    cc = crc[7][((cc >> 8) ^ w0) & 0xff] ^ crc[6][((cc & 0xff) ^ (w0 >> 8)) & 0xff] ^ crc[5][(w0 >> 16) & 0xff] ^ crc[4][w0 >> 24] ^
+         crc[3][w1 & 0xff] ^ crc[2][(w1 >> 8) & 0xff] ^ crc[1][(w1 >> 16) & 0xff] ^ crc[0][w1 >> 24];
+  };
+  if (n >= 64) {
+    uint32_t q[16], qn[16];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) __builtin_memcpy(q + 4 * b, d + 16 * b, 16);
+    for (; i + 64 <= n; i += 64) {
+      const uint32_t nxt = i + 128 <= n ? i + 64 : i;  // (the last trip loads its own bytes again: no read past the frame)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) __builtin_memcpy(qn + 4 * b, d + nxt + 16 * b, 16);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) step8(q[2 * b], q[2 * b + 1]);
+#pragma unroll
+      for (int b = 0; b < 16; ++b) q[b] = qn[b];
+    }
+  }
+  for (; i + 8 <= n; i += 8) {
+    uint32_t w0, w1;
+    __builtin_memcpy(&w0, d + i, 4);
+    __builtin_memcpy(&w1, d + i + 4, 4);
+    step8(w0, w1);
+  }
+  for (; i < n; ++i) cc = ((cc << 8) & 0xffff) ^ crc[0][((cc >> 8) ^ d[i]) & 0xff];
+  return cc & 0xffff;
+}
+
+__global__ __launch_bounds__(3 * kFdLanes) void flac_decode_kernel(FdDecodeParams p) {
+  __shared__ int32_t hist[32][kFdLanes];   // a subframe's warm-up samples; the last 32 restored samples for the orders above 12
   __shared__ int32_t coefs[32][kFdLanes];
   __shared__ uint16_t crc[8][256];
   __shared__ __attribute__((aligned(16))) uint32_t ring[kFdLanes][kFdRingRow];
-  __shared__ __attribute__((aligned(16))) int32_t stage[kFdLanes][kFdStageRow];
-  for (int i = threadIdx.x; i < 8 * 256; i += kFdLanes) crc[i >> 8][i & 255] = p.crc_tab[i];
+  __shared__ __attribute__((aligned(16))) int32_t mb_val[kFdSlots][kFdLanes][kFdSlotRow];
+  __shared__ uint32_t mb_desc[kFdSlots][kFdLanes];  // count | kind << 8
+  __shared__ uint32_t mb_prod[kFdLanes], mb_cons[kFdLanes];
+  __shared__ int sf_order[kFdLanes], sf_shift[kFdLanes], sf_wasted[kFdLanes], sf_chan[kFdLanes];
+  for (int i = threadIdx.x; i < 8 * 256; i += 3 * kFdLanes) crc[i >> 8][i & 255] = p.crc_tab[i];
+  if (threadIdx.x < kFdLanes) mb_prod[threadIdx.x] = 0, mb_cons[threadIdx.x] = 0;
   __syncthreads();
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (kFdLanes - 1);
+  const int role = threadIdx.x / kFdLanes;  // wave 0 parses, wave 1 restores, wave 2 checks the CRC-16
   const int f = blockIdx.x * kFdLanes + lane;
   if (f >= *p.n_frames) return;
 #ifdef FD_CLOCK  // tools only: the shader clock this kernel runs at (core cycles against the 100 MHz wall clock)
@@ -537,13 +575,193 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
 #endif
   const FdFrame fr = p.frames[f];
   const int bs = (int)fr.blocksize, n_ch = p.st.channels;
+  int32_t* const scr = p.scratch + (size_t)f * p.st.max_block * n_ch;
   int err = 0;
 
+  if (role == 2) {
+    // ================================================ the checker ===============================================================
+    // The chain kernel has fixed where every frame but the last one ends (the next frame's header: number + 1, CRC-8 right):
+    // the CRC-16 over [offset, end - 2) needs nothing from the parser, which only confirms that ITS end is that end.
+    if (f + 1 < *p.n_frames && fr.end >= fr.offset + 2 + fr.hdr_bytes) {
+      const uint32_t cc = fd_crc16(crc, p.file + fr.offset, fr.end - 2 - fr.offset);
+      const uint32_t want = ((uint32_t)p.file[fr.end - 2] << 8) | p.file[fr.end - 1];
+      if (cc != want) atomicOr(p.status, (int)kFdCrc16);
+    }
+    return;
+  }
+  if (role == 1) {
+    // ================================================ the restorer ==============================================================
+#ifdef FD_PHASES
+    const long long rs_start = __builtin_amdgcn_s_memtime();
+    long long rs_idle = 0;
+#endif
+    uint32_t cons = 0, idle = 0;
+    int order = 0, shift = 0, wasted = 0, cls = 0, hat = 0;
+    int32_t* out = scr;
+    FdPred lpc;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) lpc.c[j] = lpc.h[j] = 0.0;
+    lpc.shift = 0;
+    for (bool done = false; !done;) {
+      const uint32_t prod = __hip_atomic_load(&mb_prod[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (prod == cons) {
+        if (++idle > kFdSpinCap) err |= kFdParse, done = true;
+#ifdef FD_PHASES
+        ++rs_idle;
+#endif
+#ifndef FD_SLEEP
+#define FD_SLEEP 1
+#endif
+        __builtin_amdgcn_s_sleep(FD_SLEEP);
+        continue;
+      }
+      idle = 0;
+      const int slot = (int)(cons & (kFdSlots - 1));
+      const uint32_t desc = mb_desc[slot][lane];
+      const int n = (int)(desc & 0xff);
+      const uint32_t kind = (desc >> 8) & 0xff;
+      int32_t* const v = mb_val[slot][lane];
+      if ((kind == kFdMsgResidual && n == kFdBurst) || kind == kFdMsgCodes) {
+        int32_t r[kFdBurst];
+#pragma unroll
+        for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(r + t, v + t, 16);
+        if (kind == kFdMsgCodes) {
+          uint32_t nb[4];
+          __builtin_memcpy(nb, v + kFdBurst, 16);
+          const int k = (int)(desc >> 16);
+#pragma unroll
+          for (int t = 0; t < kFdBurst; ++t)
+            r[t] = fd_rice_value((uint32_t)r[t], (int)__builtin_amdgcn_ubfe(nb[t >> 2], 8u * (t & 3), 8u), k);
+        }
+#ifndef FD_NO_LPC  // tools only: what the prediction costs
+        if (cls >= 1 && cls <= 3) {
+          // the widest class among the lanes here serves them all (the coefficients beyond a lane's order are zero): one pass
+          // of the prediction per burst instead of one per class present in the wave
+          const int wcls = __builtin_amdgcn_ballot_w64(cls == 3) ? 3 : __builtin_amdgcn_ballot_w64(cls == 2) ? 2 : 1;
+          if (wcls == 1) {
+            lpc.burst<4>(r, wasted);
+          } else if (wcls == 2) {
+            lpc.burst<8>(r, wasted);
+          } else {
+            lpc.burst<12>(r, wasted);
+          }
+        } else if (cls == 0) {
+#pragma unroll
+          for (int t = 0; t < kFdBurst; ++t) r[t] = (int32_t)((uint32_t)r[t] << wasted);
+        } else {
+#pragma unroll
+          for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(v + t, r + t, 16);  // (the values, if codes came)
+          for (int t = 0; t < kFdBurst; ++t) {
+            // s[i] = res + (sum_j coef[j] s[i - 1 - j]) >> shift with 64-bit wrapping sums (flac_decode.cpp lpc_restore_n)
+            uint64_t acc = 0;
+            for (int j2 = 0; j2 < order; ++j2)
+              acc += (uint64_t)((int64_t)coefs[j2][lane] * (int64_t)hist[(hat - 1 - j2) & 31][lane]);
+            const int32_t sv = (int32_t)((uint32_t)v[t] + (uint32_t)((int64_t)acc >> shift));
+            hist[hat & 31][lane] = sv;
+            ++hat;
+            v[t] = (int32_t)((uint32_t)sv << wasted);
+          }
+#pragma unroll
+          for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(r + t, v + t, 16);
+        }
+#endif
+#pragma unroll
+        for (int t = 0; t < kFdBurst; t += 4) fd_store4(out + t, r[t], r[t + 1], r[t + 2], r[t + 3]);
+        out += kFdBurst;
+      } else if (kind == kFdMsgResidual) {  // a partition's tail, an escaped partition: in place in the slot
+#ifndef FD_NO_LPC
+        if (cls == 0) {
+          for (int t = 0; t < n; ++t) v[t] = (int32_t)((uint32_t)v[t] << wasted);
+        } else if (cls == 1) {
+          lpc.some<4>(v, n, wasted);
+        } else if (cls == 2) {
+          lpc.some<8>(v, n, wasted);
+        } else if (cls == 3) {
+          lpc.some<12>(v, n, wasted);
+        } else {
+          for (int t = 0; t < n; ++t) {
+            uint64_t acc = 0;
+            for (int j2 = 0; j2 < order; ++j2)
+              acc += (uint64_t)((int64_t)coefs[j2][lane] * (int64_t)hist[(hat - 1 - j2) & 31][lane]);
+            const int32_t sv = (int32_t)((uint32_t)v[t] + (uint32_t)((int64_t)acc >> shift));
+            hist[hat & 31][lane] = sv;
+            ++hat;
+            v[t] = (int32_t)((uint32_t)sv << wasted);
+          }
+        }
+#endif
+#ifndef FD_NO_STORE
+        for (int t = 0; t < n; ++t) out[t] = v[t];
+#endif
+        out += n;
+      } else if (kind == kFdMsgSamples) {
+#ifndef FD_NO_STORE
+        for (int t = 0; t < n; ++t) out[t] = (int32_t)((uint32_t)v[t] << wasted);
+#endif
+        out += n;
+      } else if (kind == kFdMsgSubframe) {
+        order = sf_order[lane], shift = sf_shift[lane], wasted = sf_wasted[lane];
+        out = scr + (size_t)sf_chan[lane] * p.st.max_block;
+        cls = order == 0 ? 0 : order <= 4 ? 1 : order <= 8 ? 2 : order <= 12 ? 3 : 4;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+          const bool live = cls >= 1 && cls <= 3 && j < order;
+          lpc.c[j] = live ? (double)coefs[j][lane] : 0.0;
+          lpc.h[j] = live ? (double)hist[(order - 1 - j) & 31][lane] : 0.0;
+        }
+        lpc.shift = shift;
+        hat = order;
+        for (int i = 0; i < order; ++i) out[i] = (int32_t)((uint32_t)hist[i & 31][lane] << wasted);
+        out += order;
+      } else if (kind == kFdMsgConstant) {
+        const int32_t cv = (int32_t)((uint32_t)v[0] << wasted);
+        for (int i = 0; i < bs; ++i) out[i] = cv;
+      } else {
+        done = true;
+      }
+      ++cons;
+      __hip_atomic_store(&mb_cons[lane], cons, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#ifdef FD_PHASES
+    if (f == 0 || f == 1000)
+      printf("FDPH frame %d restorer: %lld cycles, %lld idle polls, %u messages\n", f, (long long)__builtin_amdgcn_s_memtime() - rs_start, rs_idle, cons);
+#endif
+    if (err) atomicOr(p.status, err);
+    return;
+  }
+
+  // ==================================================== the parser ================================================================
   FdBits br;
-  br.init(p.file, fr.offset + fr.hdr_bytes, p.st.nbytes, ring[lane], stage[lane]);
-  int32_t* const stg = stage[lane];
-  int32_t* scr = p.scratch + (size_t)f * p.st.max_block * n_ch;
+  br.init(p.file, fr.offset + fr.hdr_bytes, p.st.nbytes, ring[lane]);
   const uint32_t guard = fr.end + 16;  // a lane that reads past this has lost the stream
+#ifdef FD_PHASES
+  long long fd_ph[5] = {0, 0, 0, 0, 0};
+  const long long ph_start = __builtin_amdgcn_s_memtime();
+#endif
+  uint32_t prod = 0, cons_seen = 0;
+  // a free slot of this lane's mailbox.  The consumed counter is read again only when the last value seen leaves no slot:
+  // the restorer is the faster of the two, so that is one LDS round trip per kFdSlots bursts, and it rarely has to wait.
+  auto acquire = [&]() __attribute__((always_inline)) -> int32_t* {
+    for (uint32_t spins = 0; prod - cons_seen >= (uint32_t)kFdSlots; ++spins) {
+      cons_seen = __hip_atomic_load(&mb_cons[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (spins > kFdSpinCap) {
+        err |= kFdParse;
+        break;
+      }
+    }
+    return mb_val[prod & (kFdSlots - 1)][lane];
+  };
+  auto publish = [&](uint32_t kind, int n, int extra = 0) __attribute__((always_inline)) {
+    mb_desc[prod & (kFdSlots - 1)][lane] = (uint32_t)n | (kind << 8) | ((uint32_t)extra << 16);
+    ++prod;
+    __hip_atomic_store(&mb_prod[lane], prod, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  // the restorer has taken everything sent so far (before `hist` / `coefs` / the descriptor of the next subframe are written)
+  auto drained = [&]() __attribute__((always_inline)) {
+    for (uint32_t spins = 0; spins <= kFdSpinCap; ++spins)
+      if (__hip_atomic_load(&mb_cons[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == prod) return;
+    err |= kFdParse;
+  };
 
   for (int c = 0; c < n_ch && !err; ++c) {
     const bool side = (fr.ch_code == 8 && c == 1) || (fr.ch_code == 9 && c == 0) || (fr.ch_code == 10 && c == 1);
@@ -558,43 +776,28 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
       err |= kFdParse;
       break;
     }
-    int32_t* row = scr + (size_t)c * p.st.max_block;
-    br.begin_row(row);
     // predictor of this subframe: order, shift, coefficients in LDS (fixed predictors are LPC with binomial coefficients)
     int order = 0, shift = 0;
-    if (type == 0) {  // constant
-      const int32_t v = (int32_t)((uint32_t)br.sbits(bps) << wasted);
-      for (int i = 0; i < bs; ++i) row[i] = v;
-      continue;
-    }
-    if (type == 1) {  // verbatim
-      for (int i = 0; i < bs && br.at() <= guard; ++i) {
-        if ((i & 7) == 0) br.service();
-        row[i] = (int32_t)((uint32_t)br.sbits(bps) << wasted);
+    if (type != 0 && type != 1) {
+      if (type >= 8 && type <= 12) {
+        order = type - 8;
+      } else if (type >= 32) {
+        order = type - 31;
+      } else {
+        err |= kFdParse;
+        break;
       }
-      if (br.at() > guard) err |= kFdParse;
-      continue;
+      if (order > bs) {
+        err |= kFdParse;
+        break;
+      }
     }
+    drained();
     if (type >= 8 && type <= 12) {
-      order = type - 8;
       const int fx[5][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {2, -1, 0, 0}, {3, -3, 1, 0}, {4, -6, 4, -1}};
       for (int j = 0; j < order; ++j) coefs[j][lane] = fx[order][j];
-    } else if (type >= 32) {
-      order = type - 31;
-    } else {
-      err |= kFdParse;
-      break;
     }
-    if (order > bs) {
-      err |= kFdParse;
-      break;
-    }
-    for (int i = 0; i < order; ++i) {
-      const int32_t v = br.sbits(bps);
-      hist[i & 31][lane] = v;
-      row[i] = (int32_t)((uint32_t)v << wasted);
-    }
-    br.out = row + order;  // where the first residual's sample goes
+    for (int i = 0; i < order; ++i) hist[i & 31][lane] = br.sbits(bps);
     br.refuel();
     if (type >= 32) {
       const int prec = (int)br.bits(4) + 1;
@@ -604,6 +807,27 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
         break;
       }
       for (int j = 0; j < order; ++j) coefs[j][lane] = br.sbits(prec);
+    }
+    sf_order[lane] = order, sf_shift[lane] = shift, sf_wasted[lane] = wasted, sf_chan[lane] = c;
+    (void)acquire();
+    publish(kFdMsgSubframe, 0);
+    if (type == 0) {  // constant
+      int32_t* v = acquire();
+      v[0] = br.sbits(bps);
+      publish(kFdMsgConstant, 1);
+      continue;
+    }
+    if (type == 1) {  // verbatim
+      for (int i = 0; i < bs && br.at() <= guard;) {
+        const int n = bs - i < kFdBurst ? bs - i : kFdBurst;
+        br.service();
+        int32_t* v = acquire();
+        for (int t = 0; t < n; ++t) v[t] = br.sbits(bps);
+        publish(kFdMsgSamples, n);
+        i += n;
+      }
+      if (br.at() > guard) err |= kFdParse;
+      continue;
     }
     // residual (RFC 9639 section 9.2.7): partitions of Rice codes or escaped raw values
     const int method = (int)br.bits(2);
@@ -618,51 +842,13 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
       err |= kFdParse;
       break;
     }
-    // the predictor's class: 0 none, 1..3 = 4 / 8 / 12 products in registers, 4 the generic path
-    const int cls = order == 0 ? 0 : order <= 4 ? 1 : order <= 8 ? 2 : order <= 12 ? 3 : 4;
-    FdPred lpc;
-#pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      const bool live = cls >= 1 && cls <= 3 && j < order;
-      lpc.c[j] = live ? (double)coefs[j][lane] : 0.0;
-      lpc.h[j] = live ? (double)hist[(order - 1 - j) & 31][lane] : 0.0;
-    }
-    lpc.shift = shift;
-    int hat = order;  // generic path: index of the sample being restored
-    // n staged residuals -> samples, in place
-    auto restore = [&](int n) __attribute__((always_inline)) {
-#ifdef FD_NO_LPC  // tools only: what the prediction costs
-      return;
-#endif
-      if (cls == 0) {
-        if (wasted)
-          for (int t = 0; t < n; ++t) stg[t] = (int32_t)((uint32_t)stg[t] << wasted);
-      } else if (cls == 1) {
-        lpc.some<4>(stg, n, wasted);
-      } else if (cls == 2) {
-        lpc.some<8>(stg, n, wasted);
-      } else if (cls == 3) {
-        lpc.some<12>(stg, n, wasted);
-      } else {
-        for (int t = 0; t < n; ++t) {
-          // s[i] = res + (sum_j coef[j] s[i - 1 - j]) >> shift with 64-bit wrapping sums (flac_decode.cpp lpc_restore_n)
-          uint64_t acc = 0;
-          for (int j2 = 0; j2 < order; ++j2)
-            acc += (uint64_t)((int64_t)coefs[j2][lane] * (int64_t)hist[(hat - 1 - j2) & 31][lane]);
-          const int32_t v = (int32_t)((uint32_t)stg[t] + (uint32_t)((int64_t)acc >> shift));
-          hist[hat & 31][lane] = v;
-          ++hat;
-          stg[t] = (int32_t)((uint32_t)v << wasted);
-        }
-      }
-    };
     // ONE loop over bursts for the whole subframe, whatever its partitions: the lanes of a wave are frames whose partition
     // orders differ (a libFLAC stream: 0..6 from subframe to subframe), and a loop nest over (partition, burst) would hold
     // every lane at each partition's end until the lane with the longest partition got there.  Here a partition's header is
     // a short branch at the top and every trip is a burst.
     const int psize = bs >> porder;
     int left = 0, part = 0, k = 0, raw = 0;
-    for (int i = order; i < bs && br.at() <= guard;) {
+    for (int i = order; i < bs && br.at() <= guard && !err;) {
       if (left == 0) {  // a partition begins (the first one may hold no residual at all)
         k = (int)br.bits(pbits);
         raw = k == esc ? (int)br.bits(5) : 0;
@@ -673,55 +859,54 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
       const bool escaped = k == esc;
       const int cap = escaped ? 8 : kFdBurst;
       const int n = left < cap ? left : cap;
-      br.service();
-      if (!escaped && n == kFdBurst) {
-        // sixteen codes, residuals and samples in registers all the way to the next service's stores
-        int32_t r[kFdBurst];
-        {
-          const uint32_t hi0 = br.hi, lo0 = br.lo, nx0 = br.nx, n20 = br.n2, rd0 = br.rd;
-          const int s0 = br.s;
-          int nmax = 0;
-#pragma unroll
-          for (int t = 0; t < kFdBurst; ++t) r[t] = br.rice_window(k, &nmax);  // one basic block
-          if (__builtin_expect(nmax > 32, 0)) {  // a code beyond the window somewhere: the burst again, code by code
-            br.hi = hi0, br.lo = lo0, br.nx = nx0, br.n2 = n20, br.rd = rd0, br.s = s0;
-            for (int t = 0; t < kFdBurst; ++t) stg[t] = br.rice(k);
-#pragma unroll
-            for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(r + t, stg + t, 16);
-          }
-        }
-#ifndef FD_NO_LPC
-        if (cls >= 1 && cls <= 3) {
-          // the widest class among the lanes here serves them all (the coefficients beyond a lane's order are zero): one pass
-          // of the prediction per burst instead of one per class present in the wave
-          const int wcls = __builtin_amdgcn_ballot_w64(cls == 3) ? 3 : __builtin_amdgcn_ballot_w64(cls == 2) ? 2 : 1;
-          if (wcls == 1) {
-            lpc.burst<4>(r, wasted);
-          } else if (wcls == 2) {
-            lpc.burst<8>(r, wasted);
-          } else {
-            lpc.burst<12>(r, wasted);
-          }
-        } else {  // no predictor, or the generic one: through the stage
-#pragma unroll
-          for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(stg + t, r + t, 16);
-          restore(n);
-#pragma unroll
-          for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(r + t, stg + t, 16);
-        }
+#ifdef FD_PHASES  // tools only: where the parser's cycles go (s_memtime around the phases of a burst, frame 0)
+      const long long ph0 = __builtin_amdgcn_s_memtime();
 #endif
+      br.service();
+#ifdef FD_PHASES
+      const long long ph1 = __builtin_amdgcn_s_memtime();
+#endif
+      int32_t* v = acquire();
+#ifdef FD_PHASES
+      const long long ph2 = __builtin_amdgcn_s_memtime();
+#endif
+      if (!escaped && n == kFdBurst) {
+        // sixteen codes = one basic block; the residuals cross to the restorer 16 bytes at a time
+        uint32_t w[kFdBurst], nb[4] = {0u, 0u, 0u, 0u};
+        const uint32_t hi0 = br.hi, lo0 = br.lo, nx0 = br.nx, n20 = br.n2, rd0 = br.rd;
+        const int s0 = br.s;
+        int nmax = 0;
 #pragma unroll
-        for (int t = 0; t < kFdBurst; ++t) br.o[t] = r[t];
-        br.on = kFdBurst;
-      } else {
-        if (escaped) {
-          for (int t = 0; t < n; ++t) stg[t] = br.sbits(raw);
-        } else {
-          for (int t = 0; t < n; ++t) stg[t] = br.rice(k);
+        for (int t = 0; t < kFdBurst; ++t) {
+          int len;
+          w[t] = br.rice_window(k, &len, &nmax);
+          nb[t >> 2] |= (uint32_t)len << (8 * (t & 3));
         }
-        restore(n);
-        br.sn = n;
+        if (__builtin_expect(nmax > 32, 0)) {  // a code beyond the window somewhere: the burst again, code by code
+          br.hi = hi0, br.lo = lo0, br.nx = nx0, br.n2 = n20, br.rd = rd0, br.s = s0;
+          for (int t = 0; t < kFdBurst; ++t) v[t] = br.rice(k);
+        } else {
+#pragma unroll
+          for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(v + t, w + t, 16);
+          __builtin_memcpy(v + kFdBurst, nb, 16);
+#ifdef FD_PHASES
+          const long long ph3 = __builtin_amdgcn_s_memtime();
+#endif
+          publish(kFdMsgCodes, kFdBurst, k);
+#ifdef FD_PHASES
+          const long long ph4 = __builtin_amdgcn_s_memtime();
+          fd_ph[0] += ph1 - ph0, fd_ph[1] += ph2 - ph1, fd_ph[2] += ph3 - ph2, fd_ph[3] += ph4 - ph3, fd_ph[4] += 1;
+#endif
+          left -= n;
+          i += n;
+          continue;
+        }
+      } else if (escaped) {
+        for (int t = 0; t < n; ++t) v[t] = br.sbits(raw);
+      } else {
+        for (int t = 0; t < n; ++t) v[t] = br.rice(k);
       }
+      publish(kFdMsgResidual, n);
       left -= n;
       i += n;
     }
@@ -730,28 +915,22 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
       break;
     }
   }
-  br.flush();
+  (void)acquire();
+  publish(kFdMsgEnd, 0);
+#ifdef FD_PHASES
+  const long long ph_parsed = __builtin_amdgcn_s_memtime();
+#endif
   if (!err) {
-    // the frame's CRC-16 over [offset, aligned end), eight bytes per step (flac_decode.cpp crc16)
     const uint32_t body_end = br.bytes_consumed_aligned();
     if (body_end + 2 > fr.end || body_end <= fr.offset) {
       err |= kFdParse;
-    } else {
-      const uint8_t* d = p.file + fr.offset;
-      const uint32_t n = body_end - fr.offset;
-      uint32_t cc = 0, i = 0;
-      for (; i + 8 <= n; i += 8) {
-        uint32_t w0, w1;
-        __builtin_memcpy(&w0, d + i, 4);
-        __builtin_memcpy(&w1, d + i + 4, 4);
-        cc = crc[7][((cc >> 8) ^ w0) & 0xff] ^ crc[6][((cc & 0xff) ^ (w0 >> 8)) & 0xff] ^ crc[5][(w0 >> 16) & 0xff] ^ crc[4][w0 >> 24] ^
-             crc[3][w1 & 0xff] ^ crc[2][(w1 >> 8) & 0xff] ^ crc[1][(w1 >> 16) & 0xff] ^ crc[0][w1 >> 24];
-      }
-      for (; i < n; ++i) cc = ((cc << 8) & 0xffff) ^ crc[0][((cc >> 8) ^ d[i]) & 0xff];
+    } else if (f + 1 < *p.n_frames) {
+      // the next frame must begin right behind the CRC-16, which the checker wave has then computed over the right bytes
+      if (body_end + 2 != fr.end) err |= kFdChain;
+    } else {  // the last frame may be followed by padding / tags: its end is known only now
+      const uint32_t cc = fd_crc16(crc, p.file + fr.offset, body_end - fr.offset);
       const uint32_t want = ((uint32_t)p.file[body_end] << 8) | p.file[body_end + 1];
       if ((cc & 0xffff) != want) err |= kFdCrc16;
-      // the next frame must begin right behind the CRC (the last frame may be followed by padding / tags)
-      if (body_end + 2 != fr.end && f + 1 < *p.n_frames) err |= kFdChain;
     }
   }
 #ifdef FD_CLOCK
@@ -759,6 +938,12 @@ __global__ __launch_bounds__(kFdLanes) void flac_decode_kernel(FdDecodeParams p)
     const long long dc = clock64() - fd_c0, dw = wall_clock64() - fd_w0;
     printf("FDCLK frame %d: %lld core cycles, %lld wall ticks (100 MHz) = %.1f us, %.0f MHz\n", f, dc, dw, dw / 100.0, dc * 100.0 / dw);
   }
+#endif
+#ifdef FD_PHASES
+  if (f == 0 || f == 1000)
+    printf("FDPH frame %d: %lld bursts; cycles per burst: service %.1f, acquire %.1f, codes %.1f, publish %.1f; parse %lld cycles in all (bursts %lld), CRC %lld\n",
+           f, fd_ph[4], 1.0 * fd_ph[0] / fd_ph[4], 1.0 * fd_ph[1] / fd_ph[4], 1.0 * fd_ph[2] / fd_ph[4], 1.0 * fd_ph[3] / fd_ph[4],
+           ph_parsed - ph_start, fd_ph[0] + fd_ph[1] + fd_ph[2] + fd_ph[3], (long long)__builtin_amdgcn_s_memtime() - ph_parsed);
 #endif
 #ifdef FD_DEBUG
   if (err || f < 2) printf("FDDBG frame %d off %u end %u bs %d err %d at %u\n", f, fr.offset, fr.end, bs, err, br.at());
@@ -862,7 +1047,7 @@ int flac_device_decode(FlacDeviceBuffers& b, const FdStream& st, void* d_pcm, hi
                      st, static_cast<FdCand*>(b.packed), b.offs, static_cast<FdFrame*>(b.frames), (int)max_frames, b.meta + 1, b.meta);
   FdDecodeParams p{b.file, static_cast<const FdFrame*>(b.frames), b.meta + 1, st, b.scratch, d_pcm, st.bits <= 16 ? 16 - st.bits : 32 - st.bits,
                    st.bits <= 16 ? 0 : 1, b.meta, b.crc_tab};
-  hipLaunchKernelGGL(flac_decode_kernel, dim3((unsigned)((max_frames + kFdLanes - 1) / kFdLanes)), dim3(kFdLanes), 0, stream, p);
+  hipLaunchKernelGGL(flac_decode_kernel, dim3((unsigned)((max_frames + kFdLanes - 1) / kFdLanes)), dim3(3 * kFdLanes), 0, stream, p);
   hipLaunchKernelGGL(flac_finalize_kernel, dim3((unsigned)((st.max_block + 255) / 256), (unsigned)max_frames), dim3(256), 0, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
