@@ -523,7 +523,7 @@ __device__ __forceinline__ void fd_store4(int32_t* dst, int32_t a, int32_t b, in
 
 // a frame's CRC-16 (poly 0x8005, no reflection, initial value 0: flac_decode.cpp crc16), eight bytes per table step (tables in
 // LDS), 64 bytes per trip with the next 64 asked for before this trip's steps: the wave waits for memory once per 64 bytes
-// (with 8 bytes per load it waited per load: ~400 us of a 1 ms kernel, tools -DFD_PHASES)
+// (with 8 bytes per load it waited per load: ~170 us of a 1 ms kernel)
 __device__ __forceinline__ uint32_t fd_crc16(const uint16_t (*crc)[256], const uint8_t* d, uint32_t n) {
   uint32_t cc = 0, i = 0;
   auto step8 = [&](uint32_t w0, uint32_t w1) __attribute__((always_inline)) {
@@ -591,10 +591,6 @@ __global__ __launch_bounds__(3 * kFdLanes) void flac_decode_kernel(FdDecodeParam
   }
   if (role == 1) {
     // ================================================ the restorer ==============================================================
-#ifdef FD_PHASES
-    const long long rs_start = __builtin_amdgcn_s_memtime();
-    long long rs_idle = 0;
-#endif
     uint32_t cons = 0, idle = 0;
     int order = 0, shift = 0, wasted = 0, cls = 0, hat = 0;
     int32_t* out = scr;
@@ -606,9 +602,6 @@ __global__ __launch_bounds__(3 * kFdLanes) void flac_decode_kernel(FdDecodeParam
       const uint32_t prod = __hip_atomic_load(&mb_prod[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (prod == cons) {
         if (++idle > kFdSpinCap) err |= kFdParse, done = true;
-#ifdef FD_PHASES
-        ++rs_idle;
-#endif
 #ifndef FD_SLEEP
 #define FD_SLEEP 1
 #endif
@@ -722,10 +715,6 @@ __global__ __launch_bounds__(3 * kFdLanes) void flac_decode_kernel(FdDecodeParam
       ++cons;
       __hip_atomic_store(&mb_cons[lane], cons, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-#ifdef FD_PHASES
-    if (f == 0 || f == 1000)
-      printf("FDPH frame %d restorer: %lld cycles, %lld idle polls, %u messages\n", f, (long long)__builtin_amdgcn_s_memtime() - rs_start, rs_idle, cons);
-#endif
     if (err) atomicOr(p.status, err);
     return;
   }
@@ -734,10 +723,6 @@ __global__ __launch_bounds__(3 * kFdLanes) void flac_decode_kernel(FdDecodeParam
   FdBits br;
   br.init(p.file, fr.offset + fr.hdr_bytes, p.st.nbytes, ring[lane]);
   const uint32_t guard = fr.end + 16;  // a lane that reads past this has lost the stream
-#ifdef FD_PHASES
-  long long fd_ph[5] = {0, 0, 0, 0, 0};
-  const long long ph_start = __builtin_amdgcn_s_memtime();
-#endif
   uint32_t prod = 0, cons_seen = 0;
   // a free slot of this lane's mailbox.  The consumed counter is read again only when the last value seen leaves no slot:
   // the restorer is the faster of the two, so that is one LDS round trip per kFdSlots bursts, and it rarely has to wait.
@@ -859,17 +844,8 @@ __global__ __launch_bounds__(3 * kFdLanes) void flac_decode_kernel(FdDecodeParam
       const bool escaped = k == esc;
       const int cap = escaped ? 8 : kFdBurst;
       const int n = left < cap ? left : cap;
-#ifdef FD_PHASES  // tools only: where the parser's cycles go (s_memtime around the phases of a burst, frame 0)
-      const long long ph0 = __builtin_amdgcn_s_memtime();
-#endif
       br.service();
-#ifdef FD_PHASES
-      const long long ph1 = __builtin_amdgcn_s_memtime();
-#endif
       int32_t* v = acquire();
-#ifdef FD_PHASES
-      const long long ph2 = __builtin_amdgcn_s_memtime();
-#endif
       if (!escaped && n == kFdBurst) {
         // sixteen codes = one basic block; the residuals cross to the restorer 16 bytes at a time
         uint32_t w[kFdBurst], nb[4] = {0u, 0u, 0u, 0u};
@@ -889,14 +865,7 @@ __global__ __launch_bounds__(3 * kFdLanes) void flac_decode_kernel(FdDecodeParam
 #pragma unroll
           for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(v + t, w + t, 16);
           __builtin_memcpy(v + kFdBurst, nb, 16);
-#ifdef FD_PHASES
-          const long long ph3 = __builtin_amdgcn_s_memtime();
-#endif
           publish(kFdMsgCodes, kFdBurst, k);
-#ifdef FD_PHASES
-          const long long ph4 = __builtin_amdgcn_s_memtime();
-          fd_ph[0] += ph1 - ph0, fd_ph[1] += ph2 - ph1, fd_ph[2] += ph3 - ph2, fd_ph[3] += ph4 - ph3, fd_ph[4] += 1;
-#endif
           left -= n;
           i += n;
           continue;
@@ -917,9 +886,6 @@ __global__ __launch_bounds__(3 * kFdLanes) void flac_decode_kernel(FdDecodeParam
   }
   (void)acquire();
   publish(kFdMsgEnd, 0);
-#ifdef FD_PHASES
-  const long long ph_parsed = __builtin_amdgcn_s_memtime();
-#endif
   if (!err) {
     const uint32_t body_end = br.bytes_consumed_aligned();
     if (body_end + 2 > fr.end || body_end <= fr.offset) {
@@ -938,12 +904,6 @@ __global__ __launch_bounds__(3 * kFdLanes) void flac_decode_kernel(FdDecodeParam
     const long long dc = clock64() - fd_c0, dw = wall_clock64() - fd_w0;
     printf("FDCLK frame %d: %lld core cycles, %lld wall ticks (100 MHz) = %.1f us, %.0f MHz\n", f, dc, dw, dw / 100.0, dc * 100.0 / dw);
   }
-#endif
-#ifdef FD_PHASES
-  if (f == 0 || f == 1000)
-    printf("FDPH frame %d: %lld bursts; cycles per burst: service %.1f, acquire %.1f, codes %.1f, publish %.1f; parse %lld cycles in all (bursts %lld), CRC %lld\n",
-           f, fd_ph[4], 1.0 * fd_ph[0] / fd_ph[4], 1.0 * fd_ph[1] / fd_ph[4], 1.0 * fd_ph[2] / fd_ph[4], 1.0 * fd_ph[3] / fd_ph[4],
-           ph_parsed - ph_start, fd_ph[0] + fd_ph[1] + fd_ph[2] + fd_ph[3], (long long)__builtin_amdgcn_s_memtime() - ph_parsed);
 #endif
 #ifdef FD_DEBUG
   if (err || f < 2) printf("FDDBG frame %d off %u end %u bs %d err %d at %u\n", f, fr.offset, fr.end, bs, err, br.at());
