@@ -16,12 +16,13 @@
 //                           size): a sync pattern inside compressed data passes the CRC-8 once in ~10^7 bytes and the number
 //                           check practically never — and if it did, the chain as a whole or the frame's CRC-16 fails and
 //                           the call reports the file as not decodable here;
-//   3. flac_decode_kernel   ONE LANE PER FRAME: subframe headers, Rice / escaped residuals from a 32-bit funnel-shift window
-//                           over a ring of the lane's stream in LDS (the lanes of a wave load and store TOGETHER, at a
-//                           service every 16 codes: see FdBits), prediction (constant, verbatim, fixed order 0..4, LPC order
-//                           1..12 as exact float64 FMAs on a register history, 13..32 with 64-bit sums on an LDS ring),
-//                           wasted bits, the frame's CRC-16 (eight bytes per step, tables in LDS); the channels as coded go
-//                           to scratch rows;
+//   3. flac_decode_kernel   A LANE TRIO PER FRAME (three waves per 64 frames): the parser — subframe headers, Rice / escaped
+//                           residuals from a 32-bit funnel-shift window over a ring of the lane's stream in LDS (the lanes
+//                           of a wave load TOGETHER, at a service every 16 codes: see FdBits) —, the restorer — prediction
+//                           (constant, verbatim, fixed order 0..4, LPC order 1..12 as exact float64 FMAs on a register
+//                           history, 13..32 with 64-bit sums on an LDS ring), wasted bits, the channels as coded to scratch
+//                           rows —, fed through a mailbox in LDS, and the checker — the frame's CRC-16 (eight bytes per
+//                           step, tables in LDS);
 //   4. flac_finalize_kernel the parallel tail, a thread per sample: stereo decorrelation and the interleaved 16- or 32-bit
 //                           PCM the ingest kernels read (audio_ingest.hip downmix_raw_kernel) — bit for bit what the host
 //                           decoder produces.  A three-minute stereo file is ~1,940 frames = 31 waves; the serial decode of
