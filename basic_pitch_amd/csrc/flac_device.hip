@@ -288,9 +288,9 @@ enum : uint32_t {
                        // warm-up samples in `coefs` / `hist`
   kFdMsgConstant = 3,  // slot[0] = the value of a constant subframe
   kFdMsgEnd = 4,       // the frame is parsed (or given up)
-  kFdMsgCodes = 5,     // a full burst of Rice codes as the parser saw them: 16 windows of 32 bits and their 16 lengths (bytes of
-                       // words 16..19), the parameter in bits 16.. of the descriptor — the restorer cuts the values out: the
-                       // parser's chain is the bit position alone (811 us with the values composed by the parser, 795 so)
+  kFdMsgCodes = 5,     // a full burst of Rice codes as the parser saw them: the 16 windows of 32 bits they start in, the parameter
+                       // in bits 16.. of the descriptor — the restorer finds each code's length again and cuts the value out:
+                       // the parser's chain is the bit position alone (811 us with the values composed by the parser, 795 so)
 };
 constexpr uint32_t kFdSpinCap = 1u << 24;  // reads of a counter before a wave gives its partner up (a bug, not a stream)
 
@@ -436,12 +436,11 @@ struct FdBits {
   }
   // the same for a burst that checks afterwards: no branch for the long code, *nmax collects the lengths; a burst with one
   // beyond the window is decoded again from its start by rice() (what this stepped over then was garbage).  Returns the
-  // window the code starts in, *n its length: the value is cut out by the restorer (fd_rice_value).
-  __device__ __forceinline__ uint32_t rice_window(int k, int* n_out, int* nmax) {
+  // window the code starts in: the value is cut out by the restorer (fd_rice_value).
+  __device__ __forceinline__ uint32_t rice_window(int k, int* nmax) {
     const uint32_t w = peek();
     const int n = (w ? __builtin_clz(w) : 32) + 1 + k;
     *nmax = n > *nmax ? n : *nmax;
-    *n_out = n;
     skip_select(n);
     return w;
   }
@@ -452,9 +451,10 @@ struct FdBits {
   }
 };
 
-// the residual of a Rice code of length n <= 32 with parameter k that starts at the top of window w
-__device__ __forceinline__ int32_t fd_rice_value(uint32_t w, int n, int k) {
-  const uint32_t v = ((uint32_t)(n - 1 - k) << k) | __builtin_amdgcn_ubfe(w, (uint32_t)(32 - n), (uint32_t)k);
+// the residual of the Rice code with parameter k that starts at the top of window w and ends inside it (w != 0)
+__device__ __forceinline__ int32_t fd_rice_value(uint32_t w, int k) {
+  const int lz = __builtin_clz(w);
+  const uint32_t v = ((uint32_t)lz << k) | __builtin_amdgcn_ubfe(w, (uint32_t)(31 - lz - k), (uint32_t)k);
   return (int32_t)(v >> 1) ^ -(int32_t)(v & 1);
 }
 
@@ -620,12 +620,9 @@ __global__ __launch_bounds__(3 * kFdLanes) void flac_decode_kernel(FdDecodeParam
 #pragma unroll
         for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(r + t, v + t, 16);
         if (kind == kFdMsgCodes) {
-          uint32_t nb[4];
-          __builtin_memcpy(nb, v + kFdBurst, 16);
           const int k = (int)(desc >> 16);
 #pragma unroll
-          for (int t = 0; t < kFdBurst; ++t)
-            r[t] = fd_rice_value((uint32_t)r[t], (int)__builtin_amdgcn_ubfe(nb[t >> 2], 8u * (t & 3), 8u), k);
+          for (int t = 0; t < kFdBurst; ++t) r[t] = fd_rice_value((uint32_t)r[t], k);
         }
 #ifndef FD_NO_LPC  // tools only: what the prediction costs
         if (cls >= 1 && cls <= 3) {
@@ -849,23 +846,18 @@ __global__ __launch_bounds__(3 * kFdLanes) void flac_decode_kernel(FdDecodeParam
       int32_t* v = acquire();
       if (!escaped && n == kFdBurst) {
         // sixteen codes = one basic block; the residuals cross to the restorer 16 bytes at a time
-        uint32_t w[kFdBurst], nb[4] = {0u, 0u, 0u, 0u};
+        uint32_t w[kFdBurst];
         const uint32_t hi0 = br.hi, lo0 = br.lo, nx0 = br.nx, n20 = br.n2, rd0 = br.rd;
         const int s0 = br.s;
         int nmax = 0;
 #pragma unroll
-        for (int t = 0; t < kFdBurst; ++t) {
-          int len;
-          w[t] = br.rice_window(k, &len, &nmax);
-          nb[t >> 2] |= (uint32_t)len << (8 * (t & 3));
-        }
+        for (int t = 0; t < kFdBurst; ++t) w[t] = br.rice_window(k, &nmax);
         if (__builtin_expect(nmax > 32, 0)) {  // a code beyond the window somewhere: the burst again, code by code
           br.hi = hi0, br.lo = lo0, br.nx = nx0, br.n2 = n20, br.rd = rd0, br.s = s0;
           for (int t = 0; t < kFdBurst; ++t) v[t] = br.rice(k);
         } else {
 #pragma unroll
           for (int t = 0; t < kFdBurst; t += 4) __builtin_memcpy(v + t, w + t, 16);
-          __builtin_memcpy(v + kFdBurst, nb, 16);
           publish(kFdMsgCodes, kFdBurst, k);
           left -= n;
           i += n;
